@@ -1,0 +1,177 @@
+/*
+ * oddio_hip.h -- C ABI of the MI355X-native oddio hot path (libodd_hip.so).
+ *
+ * This is the drop-in boundary for oddio's SpatialScene / Mixer sample loop.  The reference crate
+ * (oddio 0.7.4) has no FFI layer of its own: its operator API is the Rust trait pair
+ * `Signal` / `Seek` (src/signal.rs:14-58), the driver `oddio::run` (src/lib.rs:90-93) and the
+ * scene / mixer controls (src/spatial.rs:289-349, src/mixer.rs:18-44).  Each entry point below
+ * names the reference item it replaces; INTEGRATION.md shows the Rust `extern "C"` shim a
+ * maintainer would add so that `HipSpatialScene: Signal<Frame = [f32; 2]>` forwards here.
+ *
+ * Conventions
+ *   - plain C types only; every function returns 0 on success or a negative ODDIO_HIP_E* / a
+ *     positive hipError_t on failure; oddio_hip_last_error() gives a thread-local message.
+ *   - vectors are float[3] (x,y,z); quaternions are float[4] = (s, x, y, z) like mint::Quaternion.
+ *   - `out` buffers are interleaved stereo [L0,R0,L1,R1,...] == oddio::frame_stereo's view
+ *     (src/lib.rs:98-100), caller-owned and fully overwritten (src/spatial.rs:389-391).
+ *   - threading mirrors the reference: exactly one thread calls the sample / run entry points of a scene/mixer;
+ *     control calls (play / set_motion / set_listener_rotation / stop) may come from another
+ *     thread and take effect at the top of the next *_sample (src/set.rs:141-168, src/swap.rs).
+ *   - no device allocation happens inside *_sample; the GPU submission makes it soft real time.
+ */
+#ifndef ODDIO_HIP_H
+#define ODDIO_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ODDIO_HIP_ABI_VERSION 1
+
+enum {
+    ODDIO_HIP_OK = 0,
+    ODDIO_HIP_EINVAL = -1,    /* bad argument */
+    ODDIO_HIP_ENOMEM = -2,    /* capacity (max_sources / max_frames) exceeded or allocation failed */
+    ODDIO_HIP_ENODEV = -3,    /* no usable HIP device */
+    ODDIO_HIP_ESTATE = -4,    /* unknown / released handle */
+};
+
+enum { /* oddio_hip_scene_set_postfx */
+    ODDIO_HIP_POSTFX_NONE = 0,
+    ODDIO_HIP_POSTFX_REINHARD = 1, /* oddio::Reinhard::new(scene), src/reinhard.rs:28-35 */
+    ODDIO_HIP_POSTFX_TANH = 2,     /* oddio::Tanh::new(scene),     src/tanh.rs:22-29 */
+};
+
+enum { /* oddio_hip_scene_set_mode */
+    ODDIO_HIP_MODE_FAST = 0,    /* sources spread over the whole chip; deterministic tree sum */
+    ODDIO_HIP_MODE_ORDERED = 1, /* one wavefront walks the set in the reference's reverse-index
+                                   order: bit-comparable with the sequential f32 sum of
+                                   src/spatial.rs:204,460 (slow; for parity tests <= ~4096 sources) */
+};
+
+typedef struct oddio_hip_frames oddio_hip_frames; /* == Arc<Frames<f32>>, src/frames.rs:19-22 */
+typedef struct oddio_hip_scene oddio_hip_scene;   /* == SpatialScene + SpatialSceneControl */
+typedef struct oddio_hip_mixer oddio_hip_mixer;   /* == Mixer<[f32;2]> + MixerControl */
+
+/* ---- library ---- */
+int oddio_hip_abi_version(void);
+const char* oddio_hip_last_error(void);
+int oddio_hip_device_count(int* count);
+
+/* ---- Frames<f32> (src/frames.rs:26-47 `Frames::from_slice`) ----
+ * Uploads `len` mono samples once; the handle is reference counted like the Arc.  Empty clips are
+ * rejected (the reference panics on them in get_pair, src/frames.rs:111). */
+int oddio_hip_frames_from_slice(int device, uint32_t rate, const float* samples, size_t len,
+                                oddio_hip_frames** out);
+/* Same, but `dev_samples` is already a device pointer on `device`.  copy != 0: D2D copy;
+ * copy == 0: borrow (caller keeps the memory alive; `len` must be a multiple of 4 floats and the
+ * pointer 16-byte aligned). */
+int oddio_hip_frames_from_device(int device, uint32_t rate, const float* dev_samples, size_t len,
+                                 int copy, oddio_hip_frames** out);
+int oddio_hip_frames_retain(oddio_hip_frames* f);
+int oddio_hip_frames_release(oddio_hip_frames* f);
+int oddio_hip_frames_info(const oddio_hip_frames* f, uint32_t* rate, size_t* len);
+
+/* ---- SpatialScene (src/spatial.rs:160-189 `SpatialScene::new`) ---- */
+int oddio_hip_scene_create(int device, uint32_t max_sources, uint32_t max_frames,
+                           oddio_hip_scene** out);
+int oddio_hip_scene_destroy(oddio_hip_scene* scene);
+
+/* SpatialSceneControl::play (src/spatial.rs:289-302) of a seekable mono signal with
+ * SpatialOptions{position, velocity, radius} (src/spatial.rs:354-371).  The signal is one of:
+ *   FramesSignal::new(frames, start_seconds)  (src/frames.rs:156-169), optionally wrapped in
+ *   FixedGain::new(.., gain_db) (src/gain.rs:18-23; pass NAN for "no FixedGain wrapper");
+ *   Sine::new(phase, frequency_hz)            (src/sine.rs:18-23);
+ *   Constant::new(value)                      (src/constant.rs).
+ * `*source_id` is the handle (== the returned `Spatial`). */
+int oddio_hip_scene_play_frames(oddio_hip_scene* scene, oddio_hip_frames* frames,
+                                double start_seconds, float fixed_gain_db, const float position[3],
+                                const float velocity[3], float radius, uint32_t* source_id);
+int oddio_hip_scene_play_sine(oddio_hip_scene* scene, float phase, float frequency_hz,
+                              float fixed_gain_db, const float position[3],
+                              const float velocity[3], float radius, uint32_t* source_id);
+int oddio_hip_scene_play_constant(oddio_hip_scene* scene, float value, const float position[3],
+                                  const float velocity[3], float radius, uint32_t* source_id);
+/* Bulk form of play_frames for large scenes: n sources, arrays of length n (positions and
+ * velocities are [n][3]); ids receives n handles (may be NULL). */
+int oddio_hip_scene_play_frames_batch(oddio_hip_scene* scene, size_t n,
+                                      oddio_hip_frames* const* frames, const double* start_seconds,
+                                      const float* fixed_gain_db /* NULL: none */,
+                                      const float* positions, const float* velocities,
+                                      const float* radii, uint32_t* ids);
+
+/* Spatial::set_motion (src/spatial.rs:137-149) */
+int oddio_hip_source_set_motion(oddio_hip_scene* scene, uint32_t source_id, const float position[3],
+                                const float velocity[3], int discontinuity);
+/* Spatial::is_finished (src/spatial.rs:154-156): true once the source ended AND its propagation
+ * delay has elapsed (src/spatial.rs:243-261). */
+int oddio_hip_source_is_finished(oddio_hip_scene* scene, uint32_t source_id, int* finished);
+/* Dropping the `Spatial` handle: the id may be reused once the source has been removed. */
+int oddio_hip_source_release(oddio_hip_scene* scene, uint32_t source_id);
+/* FramesSignalControl::playback_position (src/frames.rs:238-240), as of the last sample call. */
+int oddio_hip_source_playback_position(oddio_hip_scene* scene, uint32_t source_id, double* seconds);
+
+/* SpatialSceneControl::set_listener_rotation (src/spatial.rs:345-349); stores the inverse. */
+int oddio_hip_scene_set_listener_rotation(oddio_hip_scene* scene, const float rotation_sxyz[4]);
+
+int oddio_hip_scene_set_postfx(oddio_hip_scene* scene, int postfx);
+int oddio_hip_scene_set_mode(oddio_hip_scene* scene, int mode);
+/* Number of live sources in the set after the last sample call (== `scene.recv.len()` in the
+ * reference's own test, src/spatial.rs:643). */
+int oddio_hip_scene_len(oddio_hip_scene* scene, size_t* len);
+
+/* Signal::sample for SpatialScene (src/spatial.rs:376-471): renders n_frames stereo frames
+ * separated by `interval` seconds into host memory `out` (2*n_frames floats).  n_frames may be 0
+ * (the walk -- motion ingest, finished bookkeeping -- still runs, as in the reference). */
+int oddio_hip_scene_sample(oddio_hip_scene* scene, float interval, float* out, size_t n_frames);
+/* oddio::run (src/lib.rs:90-93): interval = 1.0 / sample_rate as f32. */
+int oddio_hip_scene_run(oddio_hip_scene* scene, uint32_t sample_rate, float* out, size_t n_frames);
+/* Same as _sample, but `dev_out` is device memory on the scene's device and the call only
+ * enqueues work on the scene's stream (no host synchronisation); source removal bookkeeping is
+ * picked up one call later.  Used for multi-GPU reduction and benchmarking. */
+int oddio_hip_scene_sample_device(oddio_hip_scene* scene, float interval, float* dev_out,
+                                  size_t n_frames);
+/* Renders the post-mix filter only (Reinhard/Tanh) over a device buffer of 2*n_frames floats;
+ * used after the cross-GPU sum of partial stereo buffers (sharded scenes). */
+int oddio_hip_postfx_device(int device, int postfx, float* dev_buf, size_t n_frames, void* hip_stream);
+/* Block until everything enqueued on the scene's stream has finished. */
+int oddio_hip_scene_synchronize(oddio_hip_scene* scene);
+/* The scene's hipStream_t (for callers that order their own work after sample_device). */
+int oddio_hip_scene_stream(oddio_hip_scene* scene, void** hip_stream);
+/* Seek::seek applied to every live source (src/signal.rs:48-51): t += seconds. */
+int oddio_hip_scene_seek_all(oddio_hip_scene* scene, float seconds);
+
+/* Per-kernel timing of the most recent *_sample* call, measured with hipEvents on the scene's
+ * stream (milliseconds): [0] prepass, [1] mix, [2] reduce+postfx.  Blocks until that call's work
+ * has finished.  Enabled by oddio_hip_scene_set_profiling(scene, 1). */
+int oddio_hip_scene_set_profiling(oddio_hip_scene* scene, int enable);
+int oddio_hip_scene_last_kernel_ms(oddio_hip_scene* scene, float ms[3]);
+
+/* ---- Mixer<[f32;2]> (src/mixer.rs:70-81 `Mixer::new`) ---- */
+int oddio_hip_mixer_create(int device, uint32_t max_sources, uint32_t max_frames,
+                           oddio_hip_mixer** out);
+int oddio_hip_mixer_destroy(oddio_hip_mixer* mixer);
+/* MixerControl::play (src/mixer.rs:18-26) of MonoToStereo::new(inner) (src/signal.rs:61-91) with
+ * inner = Sine / FramesSignal (optionally FixedGain-wrapped) / Constant, as above. */
+int oddio_hip_mixer_play_sine(oddio_hip_mixer* mixer, float phase, float frequency_hz,
+                              float fixed_gain_db, uint32_t* source_id);
+int oddio_hip_mixer_play_frames(oddio_hip_mixer* mixer, oddio_hip_frames* frames,
+                                double start_seconds, float fixed_gain_db, uint32_t* source_id);
+int oddio_hip_mixer_play_constant(oddio_hip_mixer* mixer, float value, uint32_t* source_id);
+/* Mixed::stop / Mixed::is_stopped (src/mixer.rs:34-43) */
+int oddio_hip_mixer_stop(oddio_hip_mixer* mixer, uint32_t source_id);
+int oddio_hip_mixer_is_stopped(oddio_hip_mixer* mixer, uint32_t source_id, int* stopped);
+int oddio_hip_mixer_len(oddio_hip_mixer* mixer, size_t* len);
+int oddio_hip_mixer_set_postfx(oddio_hip_mixer* mixer, int postfx);
+int oddio_hip_mixer_set_mode(oddio_hip_mixer* mixer, int mode);
+/* Signal::sample for Mixer (src/mixer.rs:92-119) / oddio::run */
+int oddio_hip_mixer_sample(oddio_hip_mixer* mixer, float interval, float* out, size_t n_frames);
+int oddio_hip_mixer_run(oddio_hip_mixer* mixer, uint32_t sample_rate, float* out, size_t n_frames);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ODDIO_HIP_H */

@@ -1,0 +1,111 @@
+"""ctypes loader for libodd_hip.so (the C ABI of include/oddio_hip.h).
+
+The HIP extension is the product: if the shared library is missing this module raises -- there is
+no CPU fallback anywhere in the package.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import re
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+SO_PATH = os.path.join(_HERE, "libodd_hip.so")
+HEADER = os.path.join(os.path.dirname(_HERE), "include", "oddio_hip.h")
+
+
+def build(force: bool = False) -> str:
+    """Compile libodd_hip.so for gfx950 with hipcc (cross-compiles without a GPU)."""
+    src_dir = os.path.join(_HERE, "csrc")
+    newest = max(os.path.getmtime(os.path.join(src_dir, f)) for f in os.listdir(src_dir))
+    newest = max(newest, os.path.getmtime(HEADER))
+    if force or not os.path.exists(SO_PATH) or os.path.getmtime(SO_PATH) < newest:
+        subprocess.check_call(["make", "-C", src_dir, "-s"])
+    return SO_PATH
+
+
+def declared_symbols() -> list[str]:
+    """Every function include/oddio_hip.h declares."""
+    text = open(HEADER).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(oddio_hip_[a-z0-9_]+)\s*\(", text)))
+
+
+class OddioHipError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"oddio_hip error {code}: {msg}")
+        self.code = code
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(SO_PATH):
+        raise ImportError(
+            f"{SO_PATH} is missing: the HIP extension has not been built "
+            "(run `python -c 'import __graft_entry__ as g; g.build()'`). There is no CPU fallback.")
+    L = C.CDLL(SO_PATH)
+    vp, f32, f64, u32, sz, i32 = C.c_void_p, C.c_float, C.c_double, C.c_uint32, C.c_size_t, C.c_int
+    fp, u32p, vpp = C.POINTER(C.c_float), C.POINTER(C.c_uint32), C.POINTER(C.c_void_p)
+    sig = {
+        "oddio_hip_abi_version": (i32, []),
+        "oddio_hip_last_error": (C.c_char_p, []),
+        "oddio_hip_device_count": (i32, [C.POINTER(i32)]),
+        "oddio_hip_frames_from_slice": (i32, [i32, u32, fp, sz, vpp]),
+        "oddio_hip_frames_from_device": (i32, [i32, u32, vp, sz, i32, vpp]),
+        "oddio_hip_frames_retain": (i32, [vp]),
+        "oddio_hip_frames_release": (i32, [vp]),
+        "oddio_hip_frames_info": (i32, [vp, u32p, C.POINTER(sz)]),
+        "oddio_hip_scene_create": (i32, [i32, u32, u32, vpp]),
+        "oddio_hip_scene_destroy": (i32, [vp]),
+        "oddio_hip_scene_play_frames": (i32, [vp, vp, f64, f32, fp, fp, f32, u32p]),
+        "oddio_hip_scene_play_sine": (i32, [vp, f32, f32, f32, fp, fp, f32, u32p]),
+        "oddio_hip_scene_play_constant": (i32, [vp, f32, fp, fp, f32, u32p]),
+        "oddio_hip_scene_play_frames_batch": (i32, [vp, sz, vpp, C.POINTER(f64), fp, fp, fp, fp, u32p]),
+        "oddio_hip_source_set_motion": (i32, [vp, u32, fp, fp, i32]),
+        "oddio_hip_source_is_finished": (i32, [vp, u32, C.POINTER(i32)]),
+        "oddio_hip_source_release": (i32, [vp, u32]),
+        "oddio_hip_source_playback_position": (i32, [vp, u32, C.POINTER(f64)]),
+        "oddio_hip_scene_set_listener_rotation": (i32, [vp, fp]),
+        "oddio_hip_scene_set_postfx": (i32, [vp, i32]),
+        "oddio_hip_scene_set_mode": (i32, [vp, i32]),
+        "oddio_hip_scene_len": (i32, [vp, C.POINTER(sz)]),
+        "oddio_hip_scene_sample": (i32, [vp, f32, fp, sz]),
+        "oddio_hip_scene_run": (i32, [vp, u32, fp, sz]),
+        "oddio_hip_scene_sample_device": (i32, [vp, f32, vp, sz]),
+        "oddio_hip_postfx_device": (i32, [i32, i32, vp, sz, vp]),
+        "oddio_hip_scene_synchronize": (i32, [vp]),
+        "oddio_hip_scene_stream": (i32, [vp, vpp]),
+        "oddio_hip_scene_seek_all": (i32, [vp, f32]),
+        "oddio_hip_scene_set_profiling": (i32, [vp, i32]),
+        "oddio_hip_scene_last_kernel_ms": (i32, [vp, fp]),
+        "oddio_hip_mixer_create": (i32, [i32, u32, u32, vpp]),
+        "oddio_hip_mixer_destroy": (i32, [vp]),
+        "oddio_hip_mixer_play_sine": (i32, [vp, f32, f32, f32, u32p]),
+        "oddio_hip_mixer_play_frames": (i32, [vp, vp, f64, f32, u32p]),
+        "oddio_hip_mixer_play_constant": (i32, [vp, f32, u32p]),
+        "oddio_hip_mixer_stop": (i32, [vp, u32]),
+        "oddio_hip_mixer_is_stopped": (i32, [vp, u32, C.POINTER(i32)]),
+        "oddio_hip_mixer_len": (i32, [vp, C.POINTER(sz)]),
+        "oddio_hip_mixer_set_postfx": (i32, [vp, i32]),
+        "oddio_hip_mixer_set_mode": (i32, [vp, i32]),
+        "oddio_hip_mixer_sample": (i32, [vp, f32, fp, sz]),
+        "oddio_hip_mixer_run": (i32, [vp, u32, fp, sz]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(L, name)   # AttributeError if the library does not export a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    L._signatures = sig
+    _lib = L
+    return L
+
+
+def check(rc: int):
+    if rc != 0:
+        raise OddioHipError(rc, lib().oddio_hip_last_error().decode("utf-8", "replace"))

@@ -1,0 +1,398 @@
+"""Host-side mirror of the reference's operator interface for the hot path, over the C ABI.
+
+Same names, argument meaning and error behaviour as oddio 0.7.4 (paths relative to the reference
+crate root):
+
+    Frames.from_slice / FramesSignal(frames, start)   src/frames.rs:26-47, :156-169
+    Sine(phase, hz), Constant(x), FixedGain(sig, db)   src/sine.rs:18-23, src/constant.rs, src/gain.rs:18-23
+    SpatialScene() -> (control, scene)                 src/spatial.rs:170-188
+    SpatialSceneControl.play / set_listener_rotation   src/spatial.rs:289-302, :345-349
+    Spatial.set_motion / is_finished                   src/spatial.rs:137-156
+    Mixer() -> (control, mixer), MixerControl.play     src/mixer.rs:70-81, :18-26
+    Mixed.stop / is_stopped                            src/mixer.rs:34-43
+    MonoToStereo, Reinhard, Tanh                       src/signal.rs:61-91, src/reinhard.rs, src/tanh.rs
+    run(signal, sample_rate, out), frame_stereo        src/lib.rs:90-104
+
+Signals here are *descriptions* until they are moved into a scene or mixer (as in the reference,
+`play` takes ownership); the per-sample work happens on the GPU inside `sample`.  Filters that the
+device path does not implement raise TypeError at `play` -- nothing silently falls back to a CPU.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+
+import numpy as np
+
+from . import _lib
+
+POSTFX_NONE, POSTFX_REINHARD, POSTFX_TANH = 0, 1, 2
+MODE_FAST, MODE_ORDERED = 0, 1
+
+
+def _fp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+def _vec3(v):
+    a = np.ascontiguousarray(np.asarray(v, dtype=np.float32).reshape(3))
+    return a
+
+
+class Frames:
+    """oddio::Frames<f32> held in HBM (src/frames.rs:19-47).  Reference counted like the Arc."""
+
+    def __init__(self, handle, rate, length, device, keepalive=None):
+        self._h, self.rate, self.len, self.device, self._keepalive = handle, rate, length, device, keepalive
+
+    @classmethod
+    def from_slice(cls, rate: int, samples, device: int = 0) -> "Frames":
+        a = np.ascontiguousarray(np.asarray(samples, dtype=np.float32))
+        if a.ndim != 1:
+            raise TypeError("spatial scenes and MonoToStereo take mono clips (Frame = Sample, src/spatial.rs:291)")
+        h = C.c_void_p()
+        _lib.check(_lib.lib().oddio_hip_frames_from_slice(device, int(rate), _fp(a), a.shape[0], C.byref(h)))
+        return cls(h, int(rate), a.shape[0], device)
+
+    @classmethod
+    def from_device_ptr(cls, rate: int, dev_ptr: int, length: int, device: int = 0, copy: bool = False, keepalive=None) -> "Frames":
+        h = C.c_void_p()
+        _lib.check(_lib.lib().oddio_hip_frames_from_device(device, int(rate), C.c_void_p(dev_ptr), int(length), int(copy), C.byref(h)))
+        return cls(h, int(rate), int(length), device, keepalive)
+
+    def runtime(self) -> float:  # frames.rs:85-87
+        return self.len / float(self.rate)
+
+    def __len__(self):
+        return self.len
+
+    def __del__(self):
+        try:
+            if self._h:
+                _lib.lib().oddio_hip_frames_release(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+
+class Signal:
+    channels = 1
+    seekable = True
+
+
+class FramesSignal(Signal):
+    def __init__(self, frames: Frames, start_seconds: float = 0.0):
+        self.frames, self.start_seconds = frames, float(start_seconds)
+
+    @classmethod
+    def new(cls, frames, start_seconds):
+        return cls(frames, start_seconds)
+
+
+class Sine(Signal):
+    def __init__(self, phase: float, frequency_hz: float):
+        self.phase, self.frequency_hz = np.float32(phase), np.float32(frequency_hz)
+
+
+class Constant(Signal):
+    def __init__(self, value: float):
+        self.value = np.float32(value)
+
+
+class FixedGain(Signal):
+    def __init__(self, inner: Signal, db: float):
+        if not isinstance(inner, (FramesSignal, Sine)):
+            raise TypeError("FixedGain is supported around FramesSignal / Sine")
+        self.inner, self.db = inner, np.float32(db)
+
+
+class MonoToStereo(Signal):
+    channels = 2
+
+    def __init__(self, inner: Signal):
+        if inner.channels != 1:
+            raise TypeError("MonoToStereo takes a mono signal (src/signal.rs:70)")
+        self.inner = inner
+
+
+def _unwrap(signal):
+    """-> (leaf, fixed_gain_db or NaN)"""
+    db = math.nan
+    if isinstance(signal, FixedGain):
+        db = float(signal.db)
+        signal = signal.inner
+    if not isinstance(signal, (FramesSignal, Sine, Constant)):
+        raise TypeError(f"{type(signal).__name__} is not implemented on the device path "
+                        "(supported: FramesSignal, Sine, Constant, FixedGain around them)")
+    return signal, db
+
+
+class SpatialOptions:
+    """src/spatial.rs:354-371 (default radius 0.1)."""
+
+    def __init__(self, position=(0.0, 0.0, 0.0), velocity=(0.0, 0.0, 0.0), radius=0.1):
+        self.position, self.velocity, self.radius = position, velocity, radius
+
+
+class Spatial:
+    """Handle returned by SpatialSceneControl.play (src/spatial.rs:119-157)."""
+
+    def __init__(self, scene, sid):
+        self._scene, self.id = scene, sid
+
+    def set_motion(self, position, velocity, discontinuity: bool):
+        _lib.check(_lib.lib().oddio_hip_source_set_motion(self._scene._h, self.id, _fp(_vec3(position)), _fp(_vec3(velocity)), int(bool(discontinuity))))
+
+    def is_finished(self) -> bool:
+        out = C.c_int()
+        _lib.check(_lib.lib().oddio_hip_source_is_finished(self._scene._h, self.id, C.byref(out)))
+        return bool(out.value)
+
+    def playback_position(self) -> float:
+        out = C.c_double()
+        _lib.check(_lib.lib().oddio_hip_source_playback_position(self._scene._h, self.id, C.byref(out)))
+        return out.value
+
+
+class _SceneSignal(Signal):
+    """The `SpatialScene` half: implements Signal<Frame = [f32; 2]> (src/spatial.rs:373-477)."""
+    channels = 2
+    seekable = False
+
+    def __init__(self, device, max_sources, max_frames):
+        self._h = C.c_void_p()
+        self.device = device
+        self.max_frames = max_frames
+        _lib.check(_lib.lib().oddio_hip_scene_create(device, int(max_sources), int(max_frames), C.byref(self._h)))
+        self._keep = []
+
+    def sample(self, interval, out: np.ndarray):
+        assert out.dtype == np.float32 and out.flags.c_contiguous and (out.ndim == 2 and out.shape[1] == 2 or out.shape[0] == 0)
+        _lib.check(_lib.lib().oddio_hip_scene_sample(self._h, np.float32(interval), _fp(out), out.shape[0]))
+        return out
+
+    def sample_n(self, interval, n):
+        return self.sample(interval, np.zeros((n, 2), dtype=np.float32))
+
+    def sample_device(self, interval, dev_ptr: int, n_frames: int):
+        _lib.check(_lib.lib().oddio_hip_scene_sample_device(self._h, np.float32(interval), C.c_void_p(dev_ptr), int(n_frames)))
+
+    def synchronize(self):
+        _lib.check(_lib.lib().oddio_hip_scene_synchronize(self._h))
+
+    def stream(self) -> int:
+        p = C.c_void_p()
+        _lib.check(_lib.lib().oddio_hip_scene_stream(self._h, C.byref(p)))
+        return p.value or 0
+
+    def seek_all(self, seconds):
+        _lib.check(_lib.lib().oddio_hip_scene_seek_all(self._h, np.float32(seconds)))
+
+    def is_finished(self):
+        return False  # spatial.rs:473-476
+
+    def set_postfx(self, kind):
+        _lib.check(_lib.lib().oddio_hip_scene_set_postfx(self._h, int(kind)))
+
+    def set_mode(self, mode):
+        _lib.check(_lib.lib().oddio_hip_scene_set_mode(self._h, int(mode)))
+
+    def set_profiling(self, on):
+        _lib.check(_lib.lib().oddio_hip_scene_set_profiling(self._h, int(bool(on))))
+
+    def last_kernel_ms(self):
+        ms = (C.c_float * 3)()
+        _lib.check(_lib.lib().oddio_hip_scene_last_kernel_ms(self._h, ms))
+        return [ms[0], ms[1], ms[2]]
+
+    def __len__(self):
+        n = C.c_size_t()
+        _lib.check(_lib.lib().oddio_hip_scene_len(self._h, C.byref(n)))
+        return n.value
+
+    def close(self):
+        if self._h:
+            _lib.lib().oddio_hip_scene_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class SpatialSceneControl:
+    """src/spatial.rs:267-350"""
+
+    def __init__(self, scene: _SceneSignal):
+        self._scene = scene
+
+    def play(self, signal: Signal, options: SpatialOptions) -> Spatial:
+        if signal.channels != 1:
+            raise TypeError("signals in a spatial scene must be single-channel (src/spatial.rs:278-279)")
+        leaf, db = _unwrap(signal)
+        L, s = _lib.lib(), self._scene
+        sid = C.c_uint32()
+        pos, vel = _vec3(options.position), _vec3(options.velocity)
+        if isinstance(leaf, FramesSignal):
+            s._keep.append(leaf.frames)
+            _lib.check(L.oddio_hip_scene_play_frames(s._h, leaf.frames._h, leaf.start_seconds, db, _fp(pos), _fp(vel), np.float32(options.radius), C.byref(sid)))
+        elif isinstance(leaf, Sine):
+            _lib.check(L.oddio_hip_scene_play_sine(s._h, leaf.phase, leaf.frequency_hz, db, _fp(pos), _fp(vel), np.float32(options.radius), C.byref(sid)))
+        else:
+            _lib.check(L.oddio_hip_scene_play_constant(s._h, leaf.value, _fp(pos), _fp(vel), np.float32(options.radius), C.byref(sid)))
+        return Spatial(s, sid.value)
+
+    def play_frames_batch(self, frames_list, start_seconds, positions, velocities, radii, fixed_gain_db=None):
+        """Bulk `play(FramesSignal::new(frames[i], start[i]), SpatialOptions{..})` for large scenes."""
+        n = len(frames_list)
+        s = self._scene
+        s._keep.extend(frames_list)
+        arr = (C.c_void_p * n)(*[f._h.value for f in frames_list])
+        st = np.ascontiguousarray(np.asarray(start_seconds, dtype=np.float64).reshape(n))
+        pos = np.ascontiguousarray(np.asarray(positions, dtype=np.float32).reshape(n, 3))
+        vel = np.ascontiguousarray(np.asarray(velocities, dtype=np.float32).reshape(n, 3))
+        rad = np.ascontiguousarray(np.asarray(radii, dtype=np.float32).reshape(n))
+        ids = np.zeros(n, dtype=np.uint32)
+        fg = None
+        if fixed_gain_db is not None:
+            fg = np.ascontiguousarray(np.asarray(fixed_gain_db, dtype=np.float32).reshape(n))
+        _lib.check(_lib.lib().oddio_hip_scene_play_frames_batch(
+            s._h, n, arr, st.ctypes.data_as(C.POINTER(C.c_double)), _fp(fg) if fg is not None else None,
+            _fp(pos), _fp(vel), _fp(rad), ids.ctypes.data_as(C.POINTER(C.c_uint32))))
+        return [Spatial(s, int(i)) for i in ids]
+
+    def set_listener_rotation(self, rotation_sxyz):
+        q = np.ascontiguousarray(np.asarray(rotation_sxyz, dtype=np.float32).reshape(4))
+        _lib.check(_lib.lib().oddio_hip_scene_set_listener_rotation(self._scene._h, _fp(q)))
+
+
+def SpatialScene(device: int = 0, max_sources: int = 4096, max_frames: int = 4096):
+    """SpatialScene::new() -> (SpatialSceneControl, SpatialScene)  (src/spatial.rs:170-188)."""
+    scene = _SceneSignal(device, max_sources, max_frames)
+    return SpatialSceneControl(scene), scene
+
+
+class Reinhard(Signal):
+    """Reinhard::new(scene_or_mixer) (src/reinhard.rs): fused into the reduce kernel's epilogue."""
+    channels = 2
+    seekable = False
+    _KIND = POSTFX_REINHARD
+
+    def __init__(self, inner):
+        if not isinstance(inner, (_SceneSignal, _MixerSignal)):
+            raise TypeError("device post-filters wrap a SpatialScene or a Mixer")
+        self.inner = inner
+        inner.set_postfx(self._KIND)
+
+    def sample(self, interval, out):
+        return self.inner.sample(interval, out)
+
+    def sample_n(self, interval, n):
+        return self.inner.sample_n(interval, n)
+
+    def is_finished(self):
+        return self.inner.is_finished()
+
+
+class Tanh(Reinhard):
+    """Tanh::new(scene_or_mixer) (src/tanh.rs)."""
+    _KIND = POSTFX_TANH
+
+
+class Mixed:
+    """src/mixer.rs:30-44"""
+
+    def __init__(self, mixer, sid):
+        self._m, self.id = mixer, sid
+
+    def stop(self):
+        _lib.check(_lib.lib().oddio_hip_mixer_stop(self._m._h, self.id))
+
+    def is_stopped(self) -> bool:
+        out = C.c_int()
+        _lib.check(_lib.lib().oddio_hip_mixer_is_stopped(self._m._h, self.id, C.byref(out)))
+        return bool(out.value)
+
+
+class _MixerSignal(Signal):
+    channels = 2
+    seekable = False
+
+    def __init__(self, device, max_sources, max_frames):
+        self._h = C.c_void_p()
+        _lib.check(_lib.lib().oddio_hip_mixer_create(device, int(max_sources), int(max_frames), C.byref(self._h)))
+        self._keep = []
+
+    def sample(self, interval, out):
+        assert out.dtype == np.float32 and out.flags.c_contiguous
+        _lib.check(_lib.lib().oddio_hip_mixer_sample(self._h, np.float32(interval), _fp(out), out.shape[0]))
+        return out
+
+    def sample_n(self, interval, n):
+        return self.sample(interval, np.zeros((n, 2), dtype=np.float32))
+
+    def is_finished(self):
+        return False
+
+    def set_postfx(self, kind):
+        _lib.check(_lib.lib().oddio_hip_mixer_set_postfx(self._h, int(kind)))
+
+    def set_mode(self, mode):
+        _lib.check(_lib.lib().oddio_hip_mixer_set_mode(self._h, int(mode)))
+
+    def __len__(self):
+        n = C.c_size_t()
+        _lib.check(_lib.lib().oddio_hip_mixer_len(self._h, C.byref(n)))
+        return n.value
+
+    def close(self):
+        if self._h:
+            _lib.lib().oddio_hip_mixer_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class MixerControl:
+    """src/mixer.rs:7-27 for Mixer<[f32;2]>"""
+
+    def __init__(self, mixer):
+        self._m = mixer
+
+    def play(self, signal: Signal) -> Mixed:
+        if not isinstance(signal, MonoToStereo):
+            raise TypeError("the device Mixer is Mixer<[f32;2]>: play MonoToStereo::new(mono signal)")
+        leaf, db = _unwrap(signal.inner)
+        L, m = _lib.lib(), self._m
+        sid = C.c_uint32()
+        if isinstance(leaf, FramesSignal):
+            m._keep.append(leaf.frames)
+            _lib.check(L.oddio_hip_mixer_play_frames(m._h, leaf.frames._h, leaf.start_seconds, db, C.byref(sid)))
+        elif isinstance(leaf, Sine):
+            _lib.check(L.oddio_hip_mixer_play_sine(m._h, leaf.phase, leaf.frequency_hz, db, C.byref(sid)))
+        else:
+            _lib.check(L.oddio_hip_mixer_play_constant(m._h, leaf.value, C.byref(sid)))
+        return Mixed(m, sid.value)
+
+
+def Mixer(device: int = 0, max_sources: int = 4096, max_frames: int = 4096):
+    """Mixer::new() -> (MixerControl, Mixer)  (src/mixer.rs:70-81)."""
+    m = _MixerSignal(device, max_sources, max_frames)
+    return MixerControl(m), m
+
+
+def run(signal, sample_rate: int, out: np.ndarray):
+    """oddio::run (src/lib.rs:90-93): interval = 1.0 / sample_rate as f32."""
+    interval = np.float32(1.0) / np.float32(sample_rate)
+    return signal.sample(interval, out)
+
+
+def frame_stereo(xs: np.ndarray) -> np.ndarray:
+    """oddio::frame_stereo (src/lib.rs:98-100): view interleaved [2n] floats as [n, 2] frames."""
+    return xs.reshape(-1, 2)

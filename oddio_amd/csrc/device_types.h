@@ -1,0 +1,101 @@
+// device_types.h -- source-table layout shared by the host scene and the gfx950 kernels.
+//
+// One SpatialScene (src/spatial.rs:160-189) is a structure of arrays in HBM, indexed by *slot*
+// (the position in the reference's `Set`, src/set.rs:141-188).  Per slot:
+//   SrcStatic  (32 B)  what was passed to play(): clip, rate, FixedGain, radius, kind
+//   SrcDyn     (64 B)  what the audio thread mutates: cursor t / phase, Motion, State, finished_for
+//   SrcPending (32 B)  the control thread's latest Motion (swap.rs "pending" slot)
+//   EarParams  (2x32 B) written by the prepass each callback, read by the mix kernel
+#pragma once
+#include <stdint.h>
+
+namespace oddio_hip {
+
+enum : uint32_t { KIND_FRAMES = 0, KIND_SINE = 1, KIND_CONSTANT = 2 };
+enum : uint32_t { DYN_HAS_FINISHED_FOR = 1u, DYN_STOPPED = 2u };
+enum : uint32_t { PEND_FRESH = 1u, PEND_DISCONTINUITY = 2u };
+enum : uint32_t { EAR_SKIP = 1u };
+
+struct alignas(16) SrcStatic {
+    const float* clip;      // device pointer, 16-byte aligned, tail padded to a multiple of 4 floats
+    uint32_t clip_len;      // samples (>= 1)
+    uint32_t clip_rate;     // Hz (Frames::rate, frames.rs:20 holds it as f64)
+    float fixed_gain;       // FixedGain linear factor (gain.rs:20); 1.0 when there is no wrapper
+    float radius;           // SpatialOptions::radius
+    float freq_or_value;    // Sine: rad/s (sine.rs:21); Constant: the value
+    uint32_t kind;
+};
+static_assert(sizeof(SrcStatic) == 32, "SrcStatic layout");
+
+struct alignas(16) SrcDyn {
+    double t;               // FramesSignal::t seconds (frames.rs:145)
+    float phase;            // Sine::phase (sine.rs:7)
+    float state_dt;         // State::dt (spatial.rs:491)
+    float tgt_pos[3];       // Motion received (spatial.rs:480-485)
+    float tgt_vel[3];
+    float prev_pos[3];      // State::prev_position (spatial.rs:489)
+    float finished_for;     // Common::finished_for payload (spatial.rs:89)
+    uint32_t flags;         // DYN_*
+    uint32_t id;            // handle id (the returned `Spatial`), reported when the source stops
+};
+static_assert(sizeof(SrcDyn) == 64, "SrcDyn layout");
+
+struct alignas(16) SrcPending {
+    float pos[3];
+    float vel[3];
+    uint32_t flags;         // PEND_*
+    uint32_t pad;
+};
+static_assert(sizeof(SrcPending) == 32, "SrcPending layout");
+
+struct alignas(16) EarParams {
+    double t_ear;           // inner cursor after seek(prev_state.offset) (spatial.rs:449)
+    float dt;               // effective_elapsed / N (spatial.rs:452)
+    float g0;               // prev_state.gain
+    float dg;               // d_gain (spatial.rs:453)
+    float phase_ear;        // Sine phase after seek(prev_state.offset)
+    uint32_t flags;         // EAR_SKIP: source stopped / not mixed this callback
+    uint32_t pad;
+};
+static_assert(sizeof(EarParams) == 32, "EarParams layout");
+
+struct SceneParams {
+    float prev_rot[4];      // (s,x,y,z) listener rotation used for the callback's start
+    float rot[4];           //           ... and for its end (spatial.rs:382-386)
+    float interval;
+    float elapsed;          // interval * N as f32 (spatial.rs:394)
+    uint32_t n_frames;
+    uint32_t n_sources;     // live slots
+};
+
+// Mixer<[f32;2]> of MonoToStereo<mono source> (mixer.rs, signal.rs:61-91)
+struct alignas(16) MixStatic {
+    const float* clip;
+    uint32_t clip_len;
+    uint32_t clip_rate;
+    float fixed_gain;
+    float freq_or_value;
+    uint32_t kind;
+    uint32_t pad;
+};
+static_assert(sizeof(MixStatic) == 32, "MixStatic layout");
+
+enum : uint32_t { MIXDYN_STOPPED = 2u, MIXDYN_STOP_REQUESTED = 4u };
+
+struct alignas(16) MixDyn {
+    double t;               // FramesSignal::t
+    float phase;            // Sine::phase
+    uint32_t flags;         // MIXDYN_*
+    uint32_t id;            // handle id (the returned `Mixed`)
+    uint32_t pad[3];
+};
+static_assert(sizeof(MixDyn) == 32, "MixDyn layout");
+
+struct alignas(16) MixParams {   // written by mixer_prepass each callback
+    double t_start;         // cursor at the start of the callback
+    float phase_start;
+    uint32_t flags;         // EAR_SKIP
+};
+static_assert(sizeof(MixParams) == 16, "MixParams layout");
+
+}  // namespace oddio_hip

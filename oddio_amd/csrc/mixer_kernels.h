@@ -1,0 +1,259 @@
+// mixer_kernels.h -- gfx950 kernels for Mixer<[f32;2]> of MonoToStereo<mono source>
+// (src/mixer.rs:92-119, src/signal.rs:61-91).  Same exact-cursor scheme as kernels.h, with the
+// Mixer's 1024-frame staging chunk (mixer.rs:77) as the unit: one tile == one chunk.
+#pragma once
+#include "kernels.h"
+
+namespace oddio_hip {
+
+// one thread per slot: stop / finished scan (mixer.rs:100-106) and cursor bookkeeping
+__global__ __launch_bounds__(256) void mixer_prepass(uint32_t n_sources, uint32_t n_frames, float interval,
+                                                     const MixStatic* __restrict__ st, MixDyn* __restrict__ dyn,
+                                                     MixParams* __restrict__ par, uint32_t* __restrict__ stopped_hdr,
+                                                     uint32_t stopped_cap) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_sources) return;
+    MixDyn d = dyn[i];
+    const MixStatic s = st[i];
+    MixParams p = {};
+    if (d.flags & MIXDYN_STOPPED) { p.flags = EAR_SKIP; par[i] = p; return; }
+    bool fin = (d.flags & MIXDYN_STOP_REQUESTED) != 0;
+    if (s.kind == KIND_FRAMES) fin = fin || d.t >= (double)(s.clip_len - 1u) / (double)s.clip_rate;   // frames.rs:204-206
+    if (fin) {
+        d.flags |= MIXDYN_STOPPED;
+        const uint32_t k = atomicAdd(&stopped_hdr[0], 1u);
+        if (k < stopped_cap) stopped_hdr[1 + k] = d.id;
+        p.flags = EAR_SKIP;
+        par[i] = p;
+        dyn[i] = d;
+        return;
+    }
+    p.t_start = d.t;
+    p.phase_start = d.phase;
+    for (uint32_t done = 0; done < n_frames; done += 1024u) {
+        const uint32_t len = (n_frames - done) < 1024u ? (n_frames - done) : 1024u;
+        if (s.kind == KIND_FRAMES) d.t = d.t + (double)interval * (double)len;                          // frames.rs:198
+        else if (s.kind == KIND_SINE) d.phase = fmodf(d.phase + (interval * (float)len) * s.freq_or_value, ODDIO_TAU);   // sine.rs:39
+    }
+    par[i] = p;
+    dyn[i] = d;
+}
+
+constexpr int MIXER_GROUP = 64;
+constexpr int MIXER_CKPT_STRIDE = 65;
+
+struct MixerLds {
+    float ckpt[64 * MIXER_CKPT_STRIDE];   // [phase-A lane = source][64 checkpoints]
+    int cinfo[64 * 4];                    // per source: {wrel, frac bits, fast, path}
+    int sinfo[64 * 2];                    // per source: {ws, count}
+    float win[WIN_PAD];
+};
+
+template <bool FULL>
+__global__ __launch_bounds__(64) void mixer_mix(uint32_t n_sources, uint32_t n_frames, float interval,
+                                                const MixStatic* __restrict__ st, const MixParams* __restrict__ par,
+                                                float* __restrict__ partials, uint32_t groups_per_wave, uint32_t n_groups) {
+    __shared__ MixerLds L;
+    const int lane = threadIdx.x;
+    const uint32_t wave = blockIdx.x, tile = blockIdx.y;
+    float acc[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) acc[k] = 0.0f;
+    const uint32_t frame0 = tile * TILE_FRAMES + 16u * (uint32_t)lane;
+    const uint32_t g_lo = wave * groups_per_wave;
+    uint32_t g_hi = g_lo + groups_per_wave;
+    if (g_hi > n_groups) g_hi = n_groups;
+    const int len_tile = (int)n_frames - (int)(tile * TILE_FRAMES) > TILE_FRAMES ? TILE_FRAMES : (int)n_frames - (int)(tile * TILE_FRAMES);
+
+    for (uint32_t g = g_hi; g-- > g_lo;) {
+        // ---- phase A: one lane per source ----
+        const uint32_t srcA = g * MIXER_GROUP + (uint32_t)lane;
+        const bool validA = srcA < n_sources;
+        MixParams mp = {};
+        MixStatic ss = {};
+        mp.flags = EAR_SKIP;
+        if (validA) { mp = par[srcA]; ss = st[srcA]; }
+        const bool live = validA && !(mp.flags & EAR_SKIP);
+        int path = PATH_SKIP, fast = 0, wbase = 0, ws = 0, count = 0;
+        float frac0 = 0.0f, ds = 0.0f, ph = mp.phase_start;
+        int generic = 0;
+        if (live && ss.kind == KIND_FRAMES) {
+            double t_c = mp.t_start;
+            for (uint32_t cc = 0; cc < tile; ++cc) t_c = t_c + (double)interval * 1024.0;
+            const double s0 = t_c * (double)ss.clip_rate;
+            ds = interval * (float)ss.clip_rate;
+            const long long base = f64_as_isize(s0);
+            frac0 = (float)(s0 - (double)base);
+            fast = fabsf(ds - 1.0f) <= FLT_EPSILON;
+            if (!(fabs(s0) < 1.0e9) || !(fabsf(ds) < 16384.0f)) generic = 1;
+            wbase = (int)base;
+        } else if (live && ss.kind == KIND_SINE) {
+            for (uint32_t cc = 0; cc < tile; ++cc) ph = fmodf(ph + (interval * 1024.0f) * ss.freq_or_value, ODDIO_TAU);
+        }
+        float x = frac0;
+        {
+            float* ck = &L.ckpt[lane * MIXER_CKPT_STRIDE];
+#pragma unroll 1
+            for (int b = 0; b < 63; ++b) {
+                ck[b] = x;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) x = x + ds;
+            }
+            ck[63] = x;
+#pragma unroll
+            for (int i = 0; i < 15; ++i) x = x + ds;   // offset at frame 1023
+        }
+        if (live) {
+            if (ss.kind == KIND_SINE) path = PATH_SINE;
+            else if (ss.kind == KIND_CONSTANT) path = PATH_CONST;
+            else {
+                int i0, i1;
+                if (fast) { i0 = wbase; i1 = wbase + 1023; }
+                else {
+                    if (!(fabsf(x) < 8.0e6f)) generic = 1;
+                    i0 = wbase + (int)frac0;
+                    i1 = wbase + (int)x;
+                }
+                const int lo = i0 < i1 ? i0 : i1, hi = i0 < i1 ? i1 : i0;
+                ws = lo & ~3;
+                count = hi + 2 - ws;
+                path = (generic || count > WIN_CAP) ? PATH_GENERIC : PATH_LDS;
+            }
+        }
+        L.cinfo[lane * 4 + 0] = wbase - ws;
+        L.cinfo[lane * 4 + 1] = __float_as_int(frac0);
+        L.cinfo[lane * 4 + 2] = fast;
+        L.cinfo[lane * 4 + 3] = path;
+        L.sinfo[lane * 2 + 0] = ws;
+        L.sinfo[lane * 2 + 1] = count;
+        wave_sync();
+
+        // ---- phase B: one source at a time, lane l owns frames 16l..16l+15 of the tile ----
+#pragma unroll 1
+        for (int j = MIXER_GROUP - 1; j >= 0; --j) {
+            const int path_j = __builtin_amdgcn_readfirstlane(L.cinfo[j * 4 + 3]);
+            if (path_j == PATH_SKIP) continue;
+            const float fg = rl_f(ss.fixed_gain, j);
+            const bool active = FULL || frame0 < n_frames;
+            if (path_j == PATH_LDS) {
+                const int ws_j = __builtin_amdgcn_readfirstlane(L.sinfo[j * 2 + 0]);
+                const int count_j = __builtin_amdgcn_readfirstlane(L.sinfo[j * 2 + 1]);
+                const uint64_t cp = ((uint64_t)(uint32_t)rl_i((int)((uint64_t)ss.clip >> 32), j) << 32) |
+                                    (uint64_t)(uint32_t)rl_i((int)((uint64_t)ss.clip & 0xffffffffu), j);
+                const float* clip = (const float*)cp;
+                const int clip_len4 = (int)((rl_i((int)ss.clip_len, j) + 3) & ~3);
+                const int nvec = (count_j + 3) >> 2;
+                wave_sync();
+                for (int v = lane; v < nvec; v += 64) {
+                    const int idx = ws_j + 4 * v;
+                    float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (idx >= 0 && idx < clip_len4) val = *reinterpret_cast<const float4*>(clip + idx);
+                    const int li = 4 * v;
+                    const int pos = li + (li >> 4);
+                    L.win[pos + 0] = val.x; L.win[pos + 1] = val.y; L.win[pos + 2] = val.z; L.win[pos + 3] = val.w;
+                    if ((li & 15) == 0 && li > 0) L.win[pos - 1] = val.x;
+                }
+                wave_sync();
+                if (active) {
+                    const int wrel = rl_i(L.cinfo[j * 4 + 0], 0);
+                    const float fracf = __int_as_float(rl_i(L.cinfo[j * 4 + 1], 0));
+                    const int fast_j = rl_i(L.cinfo[j * 4 + 2], 0);
+                    const float ds_j = rl_f(ds, j);
+                    if (fast_j) {
+                        const int w0 = wrel + 16 * lane;
+                        float a = L.win[w0 + (w0 >> 4)];
+#pragma unroll
+                        for (int i = 0; i < 16; ++i) {
+                            const int w1 = w0 + i + 1;
+                            const float bb = L.win[w1 + (w1 >> 4)];
+                            float v = a + fracf * (bb - a);
+                            v = v * fg;
+                            if (FULL || frame0 + (uint32_t)i < n_frames) acc[i] = acc[i] + v;
+                            a = bb;
+                        }
+                    } else {
+                        float xx = L.ckpt[j * MIXER_CKPT_STRIDE + lane];
+#pragma unroll
+                        for (int i = 0; i < 16; ++i) {
+                            const int tr = (int)xx;
+                            const float fr = xx - (float)tr;
+                            const int w = wrel + tr;
+                            const int pos = w + (w >> 4);
+                            const float a = L.win[pos], bb = L.win[pos + 1];
+                            float v = a + fr * (bb - a);
+                            v = v * fg;
+                            if (FULL || frame0 + (uint32_t)i < n_frames) acc[i] = acc[i] + v;
+                            xx = xx + ds_j;
+                        }
+                    }
+                }
+            } else if (path_j == PATH_GENERIC) {
+                const uint64_t cp = ((uint64_t)(uint32_t)rl_i((int)((uint64_t)ss.clip >> 32), j) << 32) |
+                                    (uint64_t)(uint32_t)rl_i((int)((uint64_t)ss.clip & 0xffffffffu), j);
+                const float* clip = (const float*)cp;
+                const uint32_t clen = (uint32_t)rl_i((int)ss.clip_len, j), crate = (uint32_t)rl_i((int)ss.clip_rate, j);
+                const long long tb = __double_as_longlong(mp.t_start);
+                const double t0 = __longlong_as_double(((long long)rl_i((int)(tb >> 32), j) << 32) | (long long)(uint32_t)rl_i((int)(tb & 0xffffffff), j));
+                if (active) {
+                    double t_c = t0;
+                    for (uint32_t cc = 0; cc < tile; ++cc) t_c = t_c + (double)interval * 1024.0;
+                    const double s0 = t_c * (double)crate;
+                    const float dsg = interval * (float)crate;
+                    const long long base = f64_as_isize(s0);
+                    const float f0 = (float)(s0 - (double)base);
+                    const bool fastg = fabsf(dsg - 1.0f) <= FLT_EPSILON;
+                    float xx = f0;
+                    if (!fastg) for (int k = 0; k < 16 * lane; ++k) xx = xx + dsg;
+#pragma unroll 1
+                    for (int i = 0; i < 16; ++i) {
+                        long long idx; float fr;
+                        if (fastg) { idx = base + (long long)(16 * lane + i); fr = f0; }
+                        else { const long long tr = (long long)xx; idx = base + tr; fr = xx - (float)tr; }
+                        const float a = clip_at(clip, clen, idx), bb = clip_at(clip, clen, idx + 1);
+                        float v = a + fr * (bb - a);
+                        v = v * fg;
+                        if (FULL || frame0 + (uint32_t)i < n_frames) acc[i] = acc[i] + v;
+                        xx = xx + dsg;
+                    }
+                }
+            } else {
+                const float fv = rl_f(ss.freq_or_value, j);
+                const float ph_j = rl_f(ph, j);
+                if (active) {
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) {
+                        float v;
+                        if (path_j == PATH_SINE) {
+                            const float t = interval * (float)(16 * lane + i);   // sine.rs:36
+                            v = sinf(t * fv + ph_j);
+                        } else {
+                            v = fv;
+                        }
+                        v = v * fg;
+                        if (FULL || frame0 + (uint32_t)i < n_frames) acc[i] = acc[i] + v;
+                    }
+                }
+            }
+        }
+        wave_sync();
+    }
+    (void)len_tile;
+    // MonoToStereo: duplicate (signal.rs:73-80); Mixer adds per channel (mixer.rs:114-116)
+    float4* dst = reinterpret_cast<float4*>(partials + ((size_t)tile * gridDim.x + wave) * (2 * TILE_FRAMES) + 32 * lane);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) dst[q] = make_float4(acc[2 * q], acc[2 * q], acc[2 * q + 1], acc[2 * q + 1]);
+}
+
+struct MixerMove { uint32_t dst, src; };
+__global__ void mixer_apply_moves(const MixerMove* __restrict__ mv, uint32_t n, MixStatic* st, MixDyn* dyn) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    st[mv[i].dst] = st[mv[i].src];
+    dyn[mv[i].dst] = dyn[mv[i].src];
+}
+__global__ void mixer_request_stop(const uint32_t* __restrict__ slots, uint32_t n, MixDyn* dyn) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dyn[slots[i]].flags |= MIXDYN_STOP_REQUESTED;
+}
+
+}  // namespace oddio_hip

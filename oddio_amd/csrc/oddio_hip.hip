@@ -1,0 +1,725 @@
+// oddio_hip.hip -- host side of libodd_hip.so: the scene/mixer objects and the C ABI of
+// include/oddio_hip.h.  gfx950 only.  The host logic mirrors the reference's control plane at the
+// boundary: `Set` insert/update/swap_remove (src/set.rs:55-66,141-188), the `swap` "latest value"
+// hand-off for Motion / listener rotation (src/swap.rs:36-64), and SpatialScene::sample's
+// prologue (src/spatial.rs:376-394).
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <atomic>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "../../include/oddio_hip.h"
+#include "kernels.h"
+#include "mixer_kernels.h"
+
+using namespace oddio_hip;
+
+// ---------------------------------------------------------------------------------------------
+// errors
+// ---------------------------------------------------------------------------------------------
+static thread_local std::string g_last_error;
+
+static int fail(int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_last_error = buf;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                              \
+    do {                                                                                           \
+        hipError_t _e = (expr);                                                                    \
+        if (_e != hipSuccess)                                                                      \
+            return fail((int)_e, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+    } while (0)
+
+struct DeviceGuard {
+    int prev = -1;
+    bool ok = false;
+    explicit DeviceGuard(int dev) {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        ok = hipSetDevice(dev) == hipSuccess;
+    }
+    ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
+};
+
+// ---------------------------------------------------------------------------------------------
+// Frames
+// ---------------------------------------------------------------------------------------------
+struct oddio_hip_frames {
+    int device = 0;
+    uint32_t rate = 0;
+    size_t len = 0;
+    float* dev = nullptr;
+    bool owned = true;
+    std::atomic<int> refs{1};
+};
+
+static int frames_alloc(int device, uint32_t rate, size_t len, oddio_hip_frames** out) {
+    if (!out) return fail(ODDIO_HIP_EINVAL, "out is NULL");
+    if (len == 0) return fail(ODDIO_HIP_EINVAL, "empty clip (the reference panics in Frames::get_pair, frames.rs:111)");
+    if (len > 0x7fffff00u) return fail(ODDIO_HIP_EINVAL, "clip too long (%zu samples)", len);
+    if (rate == 0) return fail(ODDIO_HIP_EINVAL, "rate must be > 0");
+    auto* f = new oddio_hip_frames();
+    f->device = device; f->rate = rate; f->len = len;
+    const size_t padded = (len + 3) & ~size_t(3);
+    DeviceGuard g(device);
+    if (!g.ok) { delete f; return fail(ODDIO_HIP_ENODEV, "hipSetDevice(%d) failed", device); }
+    hipError_t e = hipMalloc(&f->dev, padded * sizeof(float));
+    if (e != hipSuccess) { delete f; return fail(ODDIO_HIP_ENOMEM, "hipMalloc(%zu floats): %s", padded, hipGetErrorString(e)); }
+    e = hipMemset(f->dev + (padded - 4), 0, 4 * sizeof(float));   // zero tail pad: S(i) = 0 for i >= len
+    if (e != hipSuccess) { (void)hipFree(f->dev); delete f; return fail((int)e, "hipMemset: %s", hipGetErrorString(e)); }
+    *out = f;
+    return 0;
+}
+
+extern "C" int oddio_hip_frames_from_slice(int device, uint32_t rate, const float* samples, size_t len, oddio_hip_frames** out) {
+    if (!samples && len) return fail(ODDIO_HIP_EINVAL, "samples is NULL");
+    oddio_hip_frames* f = nullptr;
+    int rc = frames_alloc(device, rate, len, &f);
+    if (rc) return rc;
+    DeviceGuard g(device);
+    hipError_t e = hipMemcpy(f->dev, samples, len * sizeof(float), hipMemcpyHostToDevice);
+    if (e != hipSuccess) { (void)hipFree(f->dev); delete f; return fail((int)e, "hipMemcpy H2D: %s", hipGetErrorString(e)); }
+    *out = f;
+    return 0;
+}
+
+extern "C" int oddio_hip_frames_from_device(int device, uint32_t rate, const float* dev_samples, size_t len, int copy, oddio_hip_frames** out) {
+    if (!dev_samples || !out) return fail(ODDIO_HIP_EINVAL, "NULL argument");
+    if (copy) {
+        oddio_hip_frames* f = nullptr;
+        int rc = frames_alloc(device, rate, len, &f);
+        if (rc) return rc;
+        DeviceGuard g(device);
+        hipError_t e = hipMemcpy(f->dev, dev_samples, len * sizeof(float), hipMemcpyDeviceToDevice);
+        if (e != hipSuccess) { (void)hipFree(f->dev); delete f; return fail((int)e, "hipMemcpy D2D: %s", hipGetErrorString(e)); }
+        *out = f;
+        return 0;
+    }
+    if (len == 0 || (len & 3) || ((uintptr_t)dev_samples & 15)) return fail(ODDIO_HIP_EINVAL, "borrowed clips need len %% 4 == 0 and 16-byte alignment");
+    if (len > 0x7fffff00u || rate == 0) return fail(ODDIO_HIP_EINVAL, "bad len/rate");
+    auto* f = new oddio_hip_frames();
+    f->device = device; f->rate = rate; f->len = len; f->dev = const_cast<float*>(dev_samples); f->owned = false;
+    *out = f;
+    return 0;
+}
+
+extern "C" int oddio_hip_frames_retain(oddio_hip_frames* f) {
+    if (!f) return fail(ODDIO_HIP_EINVAL, "NULL frames");
+    f->refs.fetch_add(1, std::memory_order_relaxed);
+    return 0;
+}
+extern "C" int oddio_hip_frames_release(oddio_hip_frames* f) {
+    if (!f) return fail(ODDIO_HIP_EINVAL, "NULL frames");
+    if (f->refs.fetch_sub(1, std::memory_order_acq_rel) == 1) {
+        if (f->owned && f->dev) { DeviceGuard g(f->device); (void)hipFree(f->dev); }
+        delete f;
+    }
+    return 0;
+}
+extern "C" int oddio_hip_frames_info(const oddio_hip_frames* f, uint32_t* rate, size_t* len) {
+    if (!f) return fail(ODDIO_HIP_EINVAL, "NULL frames");
+    if (rate) *rate = f->rate;
+    if (len) *len = f->len;
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// library
+// ---------------------------------------------------------------------------------------------
+extern "C" int oddio_hip_abi_version(void) { return ODDIO_HIP_ABI_VERSION; }
+extern "C" const char* oddio_hip_last_error(void) { return g_last_error.c_str(); }
+extern "C" int oddio_hip_device_count(int* count) {
+    if (!count) return fail(ODDIO_HIP_EINVAL, "count is NULL");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) { *count = 0; return fail(ODDIO_HIP_ENODEV, "hipGetDeviceCount: %s", hipGetErrorString(e)); }
+    *count = n;
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// SpatialScene
+// ---------------------------------------------------------------------------------------------
+namespace {
+
+struct HandleRec {
+    uint32_t slot = 0xffffffffu;   // current slot while in the set
+    bool in_set = false;           // inserted (after update()) and not yet removed
+    bool queued = false;           // play() called, not yet update()d
+    bool finished = false;         // Spatial::is_finished
+    bool released = false;         // handle dropped by the user
+    oddio_hip_frames* frames = nullptr;
+};
+
+struct PendingPlay { uint32_t id; SrcStatic st; SrcDyn dyn; };
+struct PendingMotion { uint32_t id; float pos[3]; float vel[3]; uint32_t disc; };
+
+constexpr uint32_t STOPPED_CAP = 4096;   // ids returned inline with each callback; more => second fetch
+constexpr int RING = 2;
+
+}  // namespace
+
+struct oddio_hip_scene {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    uint32_t max_sources = 0, max_frames = 0, waves_cap = 0, tiles_max = 0;
+    // device arrays
+    SrcStatic* d_static = nullptr;
+    SrcDyn* d_dyn = nullptr;
+    SrcPending* d_pend = nullptr;
+    EarParams* d_ear = nullptr;
+    uint32_t* d_stopped[RING] = {nullptr, nullptr};
+    float* d_partials = nullptr;
+    float* d_out = nullptr;
+    MotionUpdate* d_motion = nullptr;
+    SlotMove* d_moves = nullptr;
+    // pinned staging
+    uint32_t* h_stopped[RING] = {nullptr, nullptr};
+    float* h_out = nullptr;
+    hipEvent_t ev_stopped[RING] = {nullptr, nullptr};
+    bool ring_busy[RING] = {false, false};
+    uint32_t ring_nsrc[RING] = {0, 0};
+    uint64_t call_index = 0;
+    // control plane (guarded by mu)
+    std::mutex mu;
+    std::vector<PendingPlay> pending_plays;
+    std::vector<PendingMotion> pending_motion;
+    bool rot_fresh = false;
+    float rot_pending[4] = {1, 0, 0, 0};
+    std::vector<HandleRec> handles;
+    std::vector<uint32_t> free_ids;
+    size_t live_count = 0;                 // queued + in_set
+    // audio-thread state
+    float rot[4] = {1, 0, 0, 0};
+    uint32_t len = 0;                      // live slots
+    std::vector<uint32_t> id_of_slot;
+    int postfx = 0, mode = 0;
+    bool profiling = false;
+    hipEvent_t ev_prof[4] = {nullptr, nullptr, nullptr, nullptr};
+    bool prof_valid = false;
+};
+
+static int scene_free(oddio_hip_scene* s) {
+    DeviceGuard g(s->device);
+    if (s->stream) (void)hipStreamSynchronize(s->stream);
+    for (auto& h : s->handles) if (h.frames) { oddio_hip_frames_release(h.frames); h.frames = nullptr; }
+    for (auto& p : s->pending_plays) (void)p;
+    (void)hipFree(s->d_static); (void)hipFree(s->d_dyn); (void)hipFree(s->d_pend); (void)hipFree(s->d_ear);
+    (void)hipFree(s->d_partials); (void)hipFree(s->d_out); (void)hipFree(s->d_motion); (void)hipFree(s->d_moves);
+    for (int r = 0; r < RING; ++r) {
+        (void)hipFree(s->d_stopped[r]);
+        if (s->h_stopped[r]) (void)hipHostFree(s->h_stopped[r]);
+        if (s->ev_stopped[r]) (void)hipEventDestroy(s->ev_stopped[r]);
+    }
+    if (s->h_out) (void)hipHostFree(s->h_out);
+    for (auto& e : s->ev_prof) if (e) (void)hipEventDestroy(e);
+    if (s->stream) (void)hipStreamDestroy(s->stream);
+    delete s;
+    return 0;
+}
+
+extern "C" int oddio_hip_scene_create(int device, uint32_t max_sources, uint32_t max_frames, oddio_hip_scene** out) {
+    if (!out) return fail(ODDIO_HIP_EINVAL, "out is NULL");
+    if (max_sources == 0 || max_frames == 0) return fail(ODDIO_HIP_EINVAL, "max_sources and max_frames must be > 0");
+    if (max_frames > (1u << 20)) return fail(ODDIO_HIP_EINVAL, "max_frames too large");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev)
+        return fail(ODDIO_HIP_ENODEV, "no HIP device %d (count %d)", device, ndev);
+    DeviceGuard g(device);
+    if (!g.ok) return fail(ODDIO_HIP_ENODEV, "hipSetDevice(%d) failed", device);
+    auto* s = new oddio_hip_scene();
+    s->device = device; s->max_sources = max_sources; s->max_frames = max_frames;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess) { delete s; return fail(ODDIO_HIP_ENODEV, "hipGetDeviceProperties failed"); }
+    s->waves_cap = (uint32_t)prop.multiProcessorCount * 8u;
+    if (s->waves_cap == 0) s->waves_cap = 2048;
+    s->tiles_max = (max_frames + TILE_FRAMES - 1) / TILE_FRAMES;
+    const size_t cap = max_sources;
+    const uint32_t groups = (max_sources + MIX_GROUP - 1) / MIX_GROUP;
+    const uint32_t waves = std::min(groups, s->waves_cap);
+#define SC_TRY(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { int rc = fail(_e == hipErrorOutOfMemory ? ODDIO_HIP_ENOMEM : (int)_e, "%s: %s", #expr, hipGetErrorString(_e)); scene_free(s); return rc; } } while (0)
+    SC_TRY(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
+    SC_TRY(hipMalloc(&s->d_static, cap * sizeof(SrcStatic)));
+    SC_TRY(hipMalloc(&s->d_dyn, cap * sizeof(SrcDyn)));
+    SC_TRY(hipMalloc(&s->d_pend, cap * sizeof(SrcPending)));
+    SC_TRY(hipMalloc(&s->d_ear, cap * 2 * sizeof(EarParams)));
+    SC_TRY(hipMalloc(&s->d_partials, (size_t)s->tiles_max * waves * 2 * TILE_FRAMES * sizeof(float)));
+    SC_TRY(hipMalloc(&s->d_out, (size_t)s->tiles_max * 2 * TILE_FRAMES * sizeof(float)));
+    SC_TRY(hipMalloc(&s->d_motion, cap * sizeof(MotionUpdate)));
+    SC_TRY(hipMalloc(&s->d_moves, cap * sizeof(SlotMove)));
+    SC_TRY(hipHostMalloc(&s->h_out, (size_t)2 * max_frames * sizeof(float), hipHostMallocDefault));
+    for (int r = 0; r < RING; ++r) {
+        SC_TRY(hipMalloc(&s->d_stopped[r], (1 + STOPPED_CAP) * sizeof(uint32_t)));
+        SC_TRY(hipHostMalloc(&s->h_stopped[r], (1 + STOPPED_CAP) * sizeof(uint32_t), hipHostMallocDefault));
+        SC_TRY(hipEventCreateWithFlags(&s->ev_stopped[r], hipEventDisableTiming));
+    }
+    for (auto& e : s->ev_prof) SC_TRY(hipEventCreate(&e));
+    SC_TRY(hipMemsetAsync(s->d_pend, 0, cap * sizeof(SrcPending), s->stream));
+    SC_TRY(hipStreamSynchronize(s->stream));
+#undef SC_TRY
+    s->id_of_slot.resize(cap);
+    *out = s;
+    return 0;
+}
+
+extern "C" int oddio_hip_scene_destroy(oddio_hip_scene* s) {
+    if (!s) return fail(ODDIO_HIP_EINVAL, "NULL scene");
+    return scene_free(s);
+}
+
+// ---- control plane --------------------------------------------------------------------------
+static uint32_t alloc_id_locked(oddio_hip_scene* s) {
+    if (!s->free_ids.empty()) { uint32_t id = s->free_ids.back(); s->free_ids.pop_back(); s->handles[id] = HandleRec(); return id; }
+    s->handles.emplace_back();
+    return (uint32_t)s->handles.size() - 1;
+}
+
+static float db_to_gain(float db) { return std::isnan(db) ? 1.0f : powf(10.0f, db / 20.0f); }   // gain.rs:20
+
+static int scene_play_common(oddio_hip_scene* s, SrcStatic st, double start_seconds, float phase, oddio_hip_frames* frames,
+                             const float pos[3], const float vel[3], float radius, uint32_t* source_id) {
+    if (!s || !pos || !vel) return fail(ODDIO_HIP_EINVAL, "NULL argument");
+    st.radius = radius;
+    SrcDyn d = {};
+    d.t = start_seconds;
+    d.phase = phase;
+    d.state_dt = 0.0f;                                   // State::new, spatial.rs:495-499
+    for (int k = 0; k < 3; ++k) { d.tgt_pos[k] = pos[k]; d.tgt_vel[k] = vel[k]; d.prev_pos[k] = pos[k]; }
+    d.finished_for = 0.0f;
+    d.flags = 0;
+    std::lock_guard<std::mutex> lk(s->mu);
+    if (s->live_count >= s->max_sources) return fail(ODDIO_HIP_ENOMEM, "scene is full (max_sources = %u)", s->max_sources);
+    s->live_count++;
+    const uint32_t id = alloc_id_locked(s);
+    d.id = id;
+    HandleRec& h = s->handles[id];
+    h.queued = true;
+    h.frames = frames;
+    if (frames) oddio_hip_frames_retain(frames);
+    s->pending_plays.push_back({id, st, d});
+    if (source_id) *source_id = id;
+    return 0;
+}
+
+extern "C" int oddio_hip_scene_play_frames(oddio_hip_scene* s, oddio_hip_frames* frames, double start_seconds, float fixed_gain_db,
+                                           const float position[3], const float velocity[3], float radius, uint32_t* source_id) {
+    if (!s || !frames) return fail(ODDIO_HIP_EINVAL, "NULL argument");
+    if (frames->device != s->device) return fail(ODDIO_HIP_EINVAL, "frames live on device %d, scene on %d", frames->device, s->device);
+    SrcStatic st = {};
+    st.clip = frames->dev; st.clip_len = (uint32_t)frames->len; st.clip_rate = frames->rate;
+    st.fixed_gain = db_to_gain(fixed_gain_db); st.kind = KIND_FRAMES;
+    return scene_play_common(s, st, start_seconds, 0.0f, frames, position, velocity, radius, source_id);
+}
+
+extern "C" int oddio_hip_scene_play_frames_batch(oddio_hip_scene* s, size_t n, oddio_hip_frames* const* frames, const double* start_seconds,
+                                                 const float* fixed_gain_db, const float* positions, const float* velocities,
+                                                 const float* radii, uint32_t* ids) {
+    if (!s || !frames || !start_seconds || !positions || !velocities || !radii) return fail(ODDIO_HIP_EINVAL, "NULL argument");
+    {
+        std::lock_guard<std::mutex> lk(s->mu);
+        if (s->live_count + n > s->max_sources) return fail(ODDIO_HIP_ENOMEM, "scene would overflow (max_sources = %u)", s->max_sources);
+        for (size_t i = 0; i < n; ++i)
+            if (!frames[i] || frames[i]->device != s->device) return fail(ODDIO_HIP_EINVAL, "frames[%zu] invalid", i);
+        s->live_count += n;
+        s->pending_plays.reserve(s->pending_plays.size() + n);
+        s->handles.reserve(s->handles.size() + n);
+        for (size_t i = 0; i < n; ++i) {
+            oddio_hip_frames* f = frames[i];
+            SrcStatic st = {};
+            st.clip = f->dev; st.clip_len = (uint32_t)f->len; st.clip_rate = f->rate;
+            st.fixed_gain = fixed_gain_db ? db_to_gain(fixed_gain_db[i]) : 1.0f; st.kind = KIND_FRAMES;
+            st.radius = radii[i];
+            SrcDyn d = {};
+            d.t = start_seconds[i];
+            for (int k = 0; k < 3; ++k) { d.tgt_pos[k] = positions[3 * i + k]; d.tgt_vel[k] = velocities[3 * i + k]; d.prev_pos[k] = positions[3 * i + k]; }
+            const uint32_t id = alloc_id_locked(s);
+            d.id = id;
+            HandleRec& h = s->handles[id];
+            h.queued = true; h.frames = f;
+            oddio_hip_frames_retain(f);
+            s->pending_plays.push_back({id, st, d});
+            if (ids) ids[i] = id;
+        }
+    }
+    return 0;
+}
+
+extern "C" int oddio_hip_scene_play_sine(oddio_hip_scene* s, float phase, float frequency_hz, float fixed_gain_db,
+                                         const float position[3], const float velocity[3], float radius, uint32_t* source_id) {
+    SrcStatic st = {};
+    st.freq_or_value = frequency_hz * ODDIO_TAU;   // sine.rs:21
+    st.fixed_gain = db_to_gain(fixed_gain_db); st.kind = KIND_SINE;
+    return scene_play_common(s, st, 0.0, phase, nullptr, position, velocity, radius, source_id);
+}
+
+extern "C" int oddio_hip_scene_play_constant(oddio_hip_scene* s, float value, const float position[3], const float velocity[3],
+                                             float radius, uint32_t* source_id) {
+    SrcStatic st = {};
+    st.freq_or_value = value; st.fixed_gain = 1.0f; st.kind = KIND_CONSTANT;
+    return scene_play_common(s, st, 0.0, 0.0f, nullptr, position, velocity, radius, source_id);
+}
+
+extern "C" int oddio_hip_source_set_motion(oddio_hip_scene* s, uint32_t id, const float position[3], const float velocity[3], int discontinuity) {
+    if (!s || !position || !velocity) return fail(ODDIO_HIP_EINVAL, "NULL argument");
+    std::lock_guard<std::mutex> lk(s->mu);
+    if (id >= s->handles.size() || s->handles[id].released) return fail(ODDIO_HIP_ESTATE, "unknown source id %u", id);
+    PendingMotion m;
+    m.id = id;
+    for (int k = 0; k < 3; ++k) { m.pos[k] = position[k]; m.vel[k] = velocity[k]; }
+    m.disc = discontinuity ? 1u : 0u;
+    s->pending_motion.push_back(m);
+    return 0;
+}
+
+extern "C" int oddio_hip_source_is_finished(oddio_hip_scene* s, uint32_t id, int* finished) {
+    if (!s || !finished) return fail(ODDIO_HIP_EINVAL, "NULL argument");
+    std::lock_guard<std::mutex> lk(s->mu);
+    if (id >= s->handles.size() || s->handles[id].released) return fail(ODDIO_HIP_ESTATE, "unknown source id %u", id);
+    *finished = s->handles[id].finished ? 1 : 0;
+    return 0;
+}
+
+extern "C" int oddio_hip_source_release(oddio_hip_scene* s, uint32_t id) {
+    if (!s) return fail(ODDIO_HIP_EINVAL, "NULL scene");
+    std::lock_guard<std::mutex> lk(s->mu);
+    if (id >= s->handles.size() || s->handles[id].released) return fail(ODDIO_HIP_ESTATE, "unknown source id %u", id);
+    HandleRec& h = s->handles[id];
+    h.released = true;
+    if (!h.in_set && !h.queued) s->free_ids.push_back(id);   // already removed: id reusable now
+    return 0;
+}
+
+extern "C" int oddio_hip_scene_set_listener_rotation(oddio_hip_scene* s, const float q[4]) {
+    if (!s || !q) return fail(ODDIO_HIP_EINVAL, "NULL argument");
+    std::lock_guard<std::mutex> lk(s->mu);
+    s->rot_pending[0] = q[0]; s->rot_pending[1] = -q[1]; s->rot_pending[2] = -q[2]; s->rot_pending[3] = -q[3];   // invert_quat, spatial.rs:346
+    s->rot_fresh = true;
+    return 0;
+}
+
+extern "C" int oddio_hip_scene_set_postfx(oddio_hip_scene* s, int postfx) {
+    if (!s || postfx < 0 || postfx > 2) return fail(ODDIO_HIP_EINVAL, "bad postfx");
+    s->postfx = postfx;
+    return 0;
+}
+extern "C" int oddio_hip_scene_set_mode(oddio_hip_scene* s, int mode) {
+    if (!s || mode < 0 || mode > 1) return fail(ODDIO_HIP_EINVAL, "bad mode");
+    s->mode = mode;
+    return 0;
+}
+extern "C" int oddio_hip_scene_len(oddio_hip_scene* s, size_t* len) {
+    if (!s || !len) return fail(ODDIO_HIP_EINVAL, "NULL argument");
+    *len = s->len;
+    return 0;
+}
+extern "C" int oddio_hip_scene_set_profiling(oddio_hip_scene* s, int enable) {
+    if (!s) return fail(ODDIO_HIP_EINVAL, "NULL scene");
+    s->profiling = enable != 0;
+    s->prof_valid = false;
+    return 0;
+}
+extern "C" int oddio_hip_scene_last_kernel_ms(oddio_hip_scene* s, float ms[3]) {
+    if (!s || !ms) return fail(ODDIO_HIP_EINVAL, "NULL argument");
+    if (!s->prof_valid) return fail(ODDIO_HIP_ESTATE, "no profiled call yet");
+    DeviceGuard g(s->device);
+    HIP_TRY(hipEventSynchronize(s->ev_prof[3]));
+    for (int k = 0; k < 3; ++k) HIP_TRY(hipEventElapsedTime(&ms[k], s->ev_prof[k], s->ev_prof[k + 1]));
+    return 0;
+}
+extern "C" int oddio_hip_scene_synchronize(oddio_hip_scene* s) {
+    if (!s) return fail(ODDIO_HIP_EINVAL, "NULL scene");
+    DeviceGuard g(s->device);
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    return 0;
+}
+extern "C" int oddio_hip_scene_stream(oddio_hip_scene* s, void** stream) {
+    if (!s || !stream) return fail(ODDIO_HIP_EINVAL, "NULL argument");
+    *stream = (void*)s->stream;
+    return 0;
+}
+
+// ---- the audio-thread side ------------------------------------------------------------------
+
+// Applies one harvested list of stopped ids: Set::remove == Vec::swap_remove in the walk's
+// descending slot order (spatial.rs:204,258-261; set.rs:183-188).
+static int apply_stopped(oddio_hip_scene* s, std::vector<uint32_t>& ids) {
+    if (ids.empty()) return 0;
+    std::vector<uint32_t> slots;
+    {
+        std::lock_guard<std::mutex> lk(s->mu);
+        for (uint32_t id : ids) {
+            if (id >= s->handles.size()) continue;
+            HandleRec& h = s->handles[id];
+            if (!h.in_set) continue;
+            slots.push_back(h.slot);
+        }
+    }
+    std::sort(slots.begin(), slots.end(), std::greater<uint32_t>());
+    // simulate the swap_removes on the id map, tracking where each surviving element started
+    std::unordered_map<uint32_t, uint32_t> origin;   // current slot -> original slot of its (moved) occupant
+    uint32_t len = s->len;
+    std::vector<uint32_t> removed_ids;
+    for (uint32_t slot : slots) {
+        removed_ids.push_back(s->id_of_slot[slot]);
+        const uint32_t last = len - 1;
+        if (slot != last) {
+            auto it = origin.find(last);
+            origin[slot] = it == origin.end() ? last : it->second;
+            s->id_of_slot[slot] = s->id_of_slot[last];
+        }
+        origin.erase(last);
+        len--;
+    }
+    std::vector<SlotMove> moves;
+    for (auto& kv : origin) if (kv.first < len) moves.push_back({kv.first, kv.second});
+    {
+        std::lock_guard<std::mutex> lk(s->mu);
+        for (uint32_t id : removed_ids) {
+            HandleRec& h = s->handles[id];
+            h.in_set = false; h.finished = true; h.slot = 0xffffffffu;
+            s->live_count--;
+            if (h.frames) { oddio_hip_frames_release(h.frames); h.frames = nullptr; }
+            if (h.released) s->free_ids.push_back(id);
+        }
+        for (const SlotMove& m : moves) s->handles[s->id_of_slot[m.dst]].slot = m.dst;
+    }
+    s->len = len;
+    if (!moves.empty()) {
+        // sources move from original (surviving) slots into stopped slots: reads and writes are disjoint
+        HIP_TRY(hipMemcpyAsync(s->d_moves, moves.data(), moves.size() * sizeof(SlotMove), hipMemcpyHostToDevice, s->stream));
+        HIP_TRY(hipStreamSynchronize(s->stream));   // `moves` is pageable host memory
+        const uint32_t n = (uint32_t)moves.size();
+        hipLaunchKernelGGL(apply_slot_moves, dim3((n + 255) / 256), dim3(256), 0, s->stream, s->d_moves, n, s->d_static, s->d_dyn, s->d_pend);
+        HIP_TRY(hipGetLastError());
+    }
+    return 0;
+}
+
+static int harvest_ring(oddio_hip_scene* s, int r) {
+    if (!s->ring_busy[r]) return 0;
+    HIP_TRY(hipEventSynchronize(s->ev_stopped[r]));
+    s->ring_busy[r] = false;
+    uint32_t count = s->h_stopped[r][0];
+    if (count == 0) return 0;
+    std::vector<uint32_t> ids;
+    if (count <= STOPPED_CAP) {
+        ids.assign(s->h_stopped[r] + 1, s->h_stopped[r] + 1 + count);
+    } else {
+        // mass removal: more ids than the inline list holds -> read the flags of every slot
+        HIP_TRY(hipStreamSynchronize(s->stream));
+        std::vector<SrcDyn> dyn(s->ring_nsrc[r]);
+        HIP_TRY(hipMemcpy(dyn.data(), s->d_dyn, dyn.size() * sizeof(SrcDyn), hipMemcpyDeviceToHost));
+        for (const SrcDyn& d : dyn) if (d.flags & DYN_STOPPED) ids.push_back(d.id);
+    }
+    return apply_stopped(s, ids);
+}
+
+static int scene_sample_impl(oddio_hip_scene* s, float interval, float* host_out, float* dev_out, size_t n_frames) {
+    if (!s) return fail(ODDIO_HIP_EINVAL, "NULL scene");
+    if (n_frames > s->max_frames) return fail(ODDIO_HIP_ENOMEM, "n_frames %zu > max_frames %u", n_frames, s->max_frames);
+    if (n_frames && !host_out && !dev_out) return fail(ODDIO_HIP_EINVAL, "out is NULL");
+    DeviceGuard g(s->device);
+    if (!g.ok) return fail(ODDIO_HIP_ENODEV, "hipSetDevice(%d) failed", s->device);
+    const int r = (int)(s->call_index & 1);
+    s->call_index++;
+    int rc = harvest_ring(s, r);   // the list this ring slot still holds (two calls ago in device mode)
+    if (rc) return rc;
+
+    // ---- set.update(): drain control messages (set.rs:141-168) ----
+    std::vector<PendingPlay> plays;
+    std::vector<PendingMotion> motions;
+    bool rot_fresh;
+    float rot_new[4];
+    {
+        std::lock_guard<std::mutex> lk(s->mu);
+        plays.swap(s->pending_plays);
+        motions.swap(s->pending_motion);
+        rot_fresh = s->rot_fresh;
+        s->rot_fresh = false;
+        memcpy(rot_new, s->rot_pending, sizeof(rot_new));
+    }
+    if (!plays.empty()) {
+        const uint32_t first = s->len;
+        const size_t k = plays.size();
+        if (first + k > s->max_sources) return fail(ODDIO_HIP_ENOMEM, "scene overflow");
+        std::vector<SrcStatic> hs(k);
+        std::vector<SrcDyn> hd(k);
+        {
+            std::lock_guard<std::mutex> lk(s->mu);
+            for (size_t i = 0; i < k; ++i) {
+                hs[i] = plays[i].st; hd[i] = plays[i].dyn;
+                const uint32_t slot = first + (uint32_t)i;
+                s->id_of_slot[slot] = plays[i].id;
+                HandleRec& h = s->handles[plays[i].id];
+                h.slot = slot; h.in_set = true; h.queued = false;
+            }
+        }
+        HIP_TRY(hipMemcpyAsync(s->d_static + first, hs.data(), k * sizeof(SrcStatic), hipMemcpyHostToDevice, s->stream));
+        HIP_TRY(hipMemcpyAsync(s->d_dyn + first, hd.data(), k * sizeof(SrcDyn), hipMemcpyHostToDevice, s->stream));
+        HIP_TRY(hipMemsetAsync(s->d_pend + first, 0, k * sizeof(SrcPending), s->stream));
+        HIP_TRY(hipStreamSynchronize(s->stream));   // hs/hd are pageable and go out of scope
+        s->len = first + (uint32_t)k;
+    }
+    if (!motions.empty()) {
+        // swap.rs semantics: only the latest value per source survives until refresh()
+        std::vector<MotionUpdate> ups;
+        {
+            std::lock_guard<std::mutex> lk(s->mu);
+            std::unordered_map<uint32_t, size_t> latest;
+            for (size_t i = 0; i < motions.size(); ++i) latest[motions[i].id] = i;
+            for (size_t i = 0; i < motions.size(); ++i) {
+                if (latest[motions[i].id] != i) continue;
+                const HandleRec& h = s->handles[motions[i].id];
+                if (!h.in_set) continue;
+                MotionUpdate u;
+                u.slot = h.slot;
+                for (int c = 0; c < 3; ++c) { u.pos[c] = motions[i].pos[c]; u.vel[c] = motions[i].vel[c]; }
+                u.discontinuity = motions[i].disc;
+                ups.push_back(u);
+            }
+        }
+        if (!ups.empty()) {
+            HIP_TRY(hipMemcpyAsync(s->d_motion, ups.data(), ups.size() * sizeof(MotionUpdate), hipMemcpyHostToDevice, s->stream));
+            HIP_TRY(hipStreamSynchronize(s->stream));
+            const uint32_t n = (uint32_t)ups.size();
+            hipLaunchKernelGGL(apply_motion_updates, dim3((n + 255) / 256), dim3(256), 0, s->stream, s->d_motion, n, s->d_pend);
+            HIP_TRY(hipGetLastError());
+        }
+    }
+
+    // ---- listener rotation (spatial.rs:382-386) ----
+    SceneParams P;
+    memcpy(P.prev_rot, s->rot, sizeof(P.prev_rot));
+    if (rot_fresh) memcpy(s->rot, rot_new, sizeof(s->rot));
+    memcpy(P.rot, s->rot, sizeof(P.rot));
+    P.interval = interval;
+    P.elapsed = interval * (float)n_frames;   // spatial.rs:394
+    P.n_frames = (uint32_t)n_frames;
+    P.n_sources = s->len;
+
+    float* out_dev = dev_out ? dev_out : s->d_out;
+    const bool prof = s->profiling;
+    HIP_TRY(hipMemsetAsync(s->d_stopped[r], 0, sizeof(uint32_t), s->stream));
+    if (prof) HIP_TRY(hipEventRecord(s->ev_prof[0], s->stream));
+    if (s->len > 0) {
+        hipLaunchKernelGGL(spatial_prepass, dim3((s->len + 255) / 256), dim3(256), 0, s->stream, P, s->d_static, s->d_dyn, s->d_pend,
+                           s->d_ear, s->d_stopped[r], STOPPED_CAP);
+        HIP_TRY(hipGetLastError());
+    }
+    if (prof) HIP_TRY(hipEventRecord(s->ev_prof[1], s->stream));
+    uint32_t n_waves = 0;
+    const uint32_t n_tiles = ((uint32_t)n_frames + TILE_FRAMES - 1) / TILE_FRAMES;
+    if (n_frames > 0 && s->len > 0) {
+        const uint32_t n_groups = (s->len + MIX_GROUP - 1) / MIX_GROUP;
+        uint32_t waves = s->mode == ODDIO_HIP_MODE_ORDERED ? 1u : std::min(n_groups, s->waves_cap);
+        const uint32_t gpw = (n_groups + waves - 1) / waves;
+        waves = (n_groups + gpw - 1) / gpw;
+        n_waves = waves;
+        const bool full = (n_frames % TILE_FRAMES) == 0;
+        if (full)
+            hipLaunchKernelGGL(spatial_mix<true>, dim3(waves, n_tiles), dim3(64), 0, s->stream, P, s->d_static, s->d_ear, s->d_partials, gpw, n_groups);
+        else
+            hipLaunchKernelGGL(spatial_mix<false>, dim3(waves, n_tiles), dim3(64), 0, s->stream, P, s->d_static, s->d_ear, s->d_partials, gpw, n_groups);
+        HIP_TRY(hipGetLastError());
+    }
+    if (prof) HIP_TRY(hipEventRecord(s->ev_prof[2], s->stream));
+    if (n_frames > 0) {
+        const uint32_t n_out = 2u * (uint32_t)n_frames;
+        if (n_waves > 0) {
+            hipLaunchKernelGGL(reduce_partials, dim3((n_out + 63) / 64), dim3(1024), 0, s->stream, s->d_partials, out_dev, n_waves,
+                               (uint32_t)n_frames, s->postfx);
+        } else {
+            hipLaunchKernelGGL(zero_kernel, dim3((n_out + 255) / 256), dim3(256), 0, s->stream, out_dev, n_out);   // spatial.rs:389-391
+        }
+        HIP_TRY(hipGetLastError());
+    }
+    if (prof) { HIP_TRY(hipEventRecord(s->ev_prof[3], s->stream)); s->prof_valid = true; }
+
+    // ---- results back ----
+    HIP_TRY(hipMemcpyAsync(s->h_stopped[r], s->d_stopped[r], (1 + STOPPED_CAP) * sizeof(uint32_t), hipMemcpyDeviceToHost, s->stream));
+    HIP_TRY(hipEventRecord(s->ev_stopped[r], s->stream));
+    s->ring_busy[r] = true;
+    s->ring_nsrc[r] = s->len;
+    if (host_out || !dev_out) {
+        if (n_frames > 0 && host_out) {
+            HIP_TRY(hipMemcpyAsync(s->h_out, out_dev, 2 * n_frames * sizeof(float), hipMemcpyDeviceToHost, s->stream));
+        }
+        HIP_TRY(hipStreamSynchronize(s->stream));
+        if (n_frames > 0 && host_out) memcpy(host_out, s->h_out, 2 * n_frames * sizeof(float));
+        // host mode: removals take effect within the call, like the reference's walk
+        rc = harvest_ring(s, r ^ 1);
+        if (rc) return rc;
+        rc = harvest_ring(s, r);
+        if (rc) return rc;
+    }
+    return 0;
+}
+
+extern "C" int oddio_hip_scene_sample(oddio_hip_scene* s, float interval, float* out, size_t n_frames) {
+    return scene_sample_impl(s, interval, out, nullptr, n_frames);
+}
+extern "C" int oddio_hip_scene_run(oddio_hip_scene* s, uint32_t sample_rate, float* out, size_t n_frames) {
+    const float interval = 1.0f / (float)sample_rate;   // lib.rs:91
+    return scene_sample_impl(s, interval, out, nullptr, n_frames);
+}
+extern "C" int oddio_hip_scene_sample_device(oddio_hip_scene* s, float interval, float* dev_out, size_t n_frames) {
+    if (!dev_out && n_frames) return fail(ODDIO_HIP_EINVAL, "dev_out is NULL");
+    return scene_sample_impl(s, interval, nullptr, dev_out, n_frames);
+}
+
+extern "C" int oddio_hip_postfx_device(int device, int postfx, float* dev_buf, size_t n_frames, void* stream) {
+    if (!dev_buf || postfx < 0 || postfx > 2) return fail(ODDIO_HIP_EINVAL, "bad argument");
+    if (postfx == 0 || n_frames == 0) return 0;
+    DeviceGuard g(device);
+    const uint32_t n = 2u * (uint32_t)n_frames;
+    hipLaunchKernelGGL(postfx_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, dev_buf, n, postfx);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+extern "C" int oddio_hip_scene_seek_all(oddio_hip_scene* s, float seconds) {
+    if (!s) return fail(ODDIO_HIP_EINVAL, "NULL scene");
+    if (s->len == 0) return 0;
+    DeviceGuard g(s->device);
+    hipLaunchKernelGGL(seek_all_kernel, dim3((s->len + 255) / 256), dim3(256), 0, s->stream, s->d_dyn, s->d_static, s->len, seconds);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+extern "C" int oddio_hip_source_playback_position(oddio_hip_scene* s, uint32_t id, double* seconds) {
+    if (!s || !seconds) return fail(ODDIO_HIP_EINVAL, "NULL argument");
+    uint32_t slot;
+    {
+        std::lock_guard<std::mutex> lk(s->mu);
+        if (id >= s->handles.size() || !s->handles[id].in_set) return fail(ODDIO_HIP_ESTATE, "source %u is not in the set", id);
+        slot = s->handles[id].slot;
+    }
+    DeviceGuard g(s->device);
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    SrcDyn d;
+    SrcStatic st;
+    HIP_TRY(hipMemcpy(&d, s->d_dyn + slot, sizeof(d), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(&st, s->d_static + slot, sizeof(st), hipMemcpyDeviceToHost));
+    if (st.kind != KIND_FRAMES) return fail(ODDIO_HIP_ESTATE, "source %u is not a FramesSignal", id);
+    // frames.rs:199-200, :238-240: (t * rate) as isize, read back as isize as f64 / rate
+    const double rate = (double)st.clip_rate;
+    double sp = d.t * rate;
+    sp = sp != sp ? 0.0 : std::trunc(sp);
+    *seconds = sp / rate;
+    return 0;
+}
+
+#include "mixer_host.inc"

@@ -1,0 +1,346 @@
+"""Independent numpy-float32 restatement of the oddio hot path (second implementation).
+
+TEST INFRASTRUCTURE ONLY.  Written from the operation-order specification (SURVEY.md Appendix A,
+which cites src/spatial.rs:376-471, src/frames.rs:176-213, src/sine.rs:18-47, src/mixer.rs:92-119,
+src/math/mod.rs:33-94), deliberately NOT from oracle/oddio_oracle.c: different structure
+(array-at-a-time, functional state), so that bit-equality between the two on seeded scenes is
+evidence that both follow the specification (tests/test_oracle_cross.py).
+
+Every arithmetic op is a separately rounded IEEE f32 op (numpy never fuses), f64 where the
+reference uses f64.  Transcendentals go through glibc (ctypes -> libm sinf/tanhf/powf/fmodf),
+which is what Rust's std f32::sin/tanh/powf/% resolve to on Linux.
+"""
+from __future__ import annotations
+
+import ctypes
+import ctypes.util
+
+import numpy as np
+
+f32 = np.float32
+f64 = np.float64
+
+_libm = ctypes.CDLL(ctypes.util.find_library("m") or "libm.so.6")
+for _n in ("sinf", "tanhf"):
+    getattr(_libm, _n).restype = ctypes.c_float
+    getattr(_libm, _n).argtypes = [ctypes.c_float]
+for _n in ("powf", "fmodf"):
+    getattr(_libm, _n).restype = ctypes.c_float
+    getattr(_libm, _n).argtypes = [ctypes.c_float, ctypes.c_float]
+
+
+def sinf(x):
+    x = np.asarray(x, dtype=f32)
+    return np.array([_libm.sinf(float(v)) for v in x.ravel()], dtype=f32).reshape(x.shape)
+
+
+def tanhf(x):
+    x = np.asarray(x, dtype=f32)
+    return np.array([_libm.tanhf(float(v)) for v in x.ravel()], dtype=f32).reshape(x.shape)
+
+
+def powf(a, b):
+    return f32(_libm.powf(float(f32(a)), float(f32(b))))
+
+
+def fmodf(a, b):
+    return f32(_libm.fmodf(float(f32(a)), float(f32(b))))
+
+
+TAU = f32(6.2831855)
+EPS = f32(1.1920929e-7)
+C_SOUND = f32(343.0)
+INV_NEG_C = f32(-1.0) / f32(343.0)
+HEAD = f32(0.1075)
+SMOOTH = f32(0.5)
+SQRT17 = np.sqrt(f32(17.0))
+DZ = f32(-1.0) / SQRT17
+ONE, HALF, ZERO = f32(1.0), f32(0.5), f32(0.0)
+
+
+def _trunc_i64(x64):
+    """Rust `f64 as isize`."""
+    x64 = float(x64)
+    if x64 != x64:
+        return 0
+    return int(max(min(x64, 9.2e18), -9.2e18))
+
+
+# ---------------------------------------------------------------------------------------------
+# quaternion / vector helpers on float32 arrays of shape [3] / [4]=(s,x,y,z)
+# ---------------------------------------------------------------------------------------------
+
+def quat_mul(q, r):
+    qs, qx, qy, qz = (f32(v) for v in q)
+    rs, rx, ry, rz = (f32(v) for v in r)
+    return np.array([
+        qs * rs - qx * rx - qy * ry - qz * rz,
+        qs * rx + qx * rs + qy * rz - qz * ry,
+        qs * ry - qx * rz + qy * rs + qz * rx,
+        qs * rz + qx * ry - qy * rx + qz * rs,
+    ], dtype=f32)
+
+
+def conj(q):
+    return np.array([q[0], -q[1], -q[2], -q[3]], dtype=f32)
+
+
+def rotate(q, p):
+    pq = np.array([0.0, p[0], p[1], p[2]], dtype=f32)
+    return quat_mul(q, quat_mul(pq, conj(q)))[1:]
+
+
+def norm(v):
+    s = f32(0.0)
+    for c in v:
+        s = s + f32(c) * f32(c)
+    return np.sqrt(s)
+
+
+def ear_state(p, ear, radius):
+    p = np.asarray(p, dtype=f32)
+    ex = -HEAD if ear == 0 else HEAD
+    v = np.array([p[0] - ex, p[1] - ZERO, p[2] - ZERO], dtype=f32)
+    distance = norm(v)
+    offset = distance * INV_NEG_C
+    distance_gain = f32(radius) / max(distance, f32(radius))
+    if distance < f32(1e-3):
+        stereo = HALF + HALF
+    else:
+        k = HALF / distance
+        q = p * k
+        dx = (f32(-1.0) if ear == 0 else f32(1.0)) * f32(4.0) / SQRT17
+        d = ZERO + dx * q[0]
+        d = d + ZERO * q[1]
+        d = d + DZ * q[2]
+        stereo = HALF + d
+    return f32(offset), f32(stereo * distance_gain)
+
+
+# ---------------------------------------------------------------------------------------------
+# sources: plain dicts, functional sample()
+# ---------------------------------------------------------------------------------------------
+
+def frames_source(rate, samples, start_seconds=0.0, fixed_gain_db=None):
+    s = {"kind": "frames", "rate": int(rate), "samples": np.asarray(samples, dtype=f32), "t": f64(start_seconds)}
+    if fixed_gain_db is not None:
+        s["fixed_gain"] = powf(10.0, f32(fixed_gain_db) / f32(20.0))
+    return s
+
+
+def sine_source(phase, hz, fixed_gain_db=None):
+    s = {"kind": "sine", "phase": f32(phase), "freq": f32(hz) * TAU}
+    if fixed_gain_db is not None:
+        s["fixed_gain"] = powf(10.0, f32(fixed_gain_db) / f32(20.0))
+    return s
+
+
+def constant_source(value):
+    return {"kind": "constant", "value": f32(value)}
+
+
+def _gather_pair(samples, idx):
+    """pair(i) = (S(i), S(i+1)) with S(i) = samples[i] inside the clip, 0 outside."""
+    n = samples.shape[0]
+    def S(i):
+        ok = (i >= 0) & (i < n)
+        return np.where(ok, samples[np.clip(i, 0, max(n - 1, 0))], ZERO).astype(f32)
+    return S(idx), S(idx + 1)
+
+
+def src_sample(src, interval, n):
+    interval = f32(interval)
+    kind = src["kind"]
+    if kind == "frames":
+        rate64 = f64(src["rate"])
+        s0 = src["t"] * rate64
+        ds = interval * f32(src["rate"])
+        base = _trunc_i64(s0)
+        frac0 = f32(s0 - f64(base))
+        if abs(ds - ONE) <= EPS:
+            idx = base + np.arange(n, dtype=np.int64)
+            a, b = _gather_pair(src["samples"], idx)
+            out = a + frac0 * (b - a)
+        else:
+            steps = np.full(n, ds, dtype=f32)
+            if n:
+                steps[0] = frac0
+            offs = np.cumsum(steps, dtype=f32)  # strictly sequential f32 accumulation
+            tr = offs.astype(np.int64)           # toward zero
+            fr = offs - tr.astype(f32)
+            a, b = _gather_pair(src["samples"], base + tr)
+            out = a + fr * (b - a)
+        src["t"] = src["t"] + f64(interval) * f64(n)
+        out = out.astype(f32)
+    elif kind == "sine":
+        i = np.arange(n, dtype=f32)
+        out = sinf((interval * i) * src["freq"] + src["phase"])
+        src["phase"] = fmodf(src["phase"] + (interval * f32(n)) * src["freq"], TAU)
+    elif kind == "constant":
+        out = np.full(n, src["value"], dtype=f32)
+    else:
+        raise ValueError(kind)
+    if "fixed_gain" in src:
+        out = out * src["fixed_gain"]
+    return out
+
+
+def src_seek(src, seconds):
+    seconds = f32(seconds)
+    if src["kind"] == "frames":
+        src["t"] = src["t"] + f64(seconds)
+    elif src["kind"] == "sine":
+        src["phase"] = fmodf(src["phase"] + seconds * src["freq"], TAU)
+
+
+def src_is_finished(src):
+    if src["kind"] == "frames":
+        return bool(src["t"] >= f64(len(src["samples"]) - 1) / f64(src["rate"]))
+    return False
+
+
+# ---------------------------------------------------------------------------------------------
+# SpatialScene (seekable sources)
+# ---------------------------------------------------------------------------------------------
+
+class Scene:
+    def __init__(self):
+        self.set = []
+        self.pending = []
+        self.all = []
+        self.rot = np.array([1, 0, 0, 0], dtype=f32)
+        self.rot_pending = None
+
+    def play(self, src, position, velocity=(0, 0, 0), radius=0.1):
+        e = {
+            "src": src, "radius": f32(radius),
+            "pos": np.asarray(position, dtype=f32).copy(), "vel": np.asarray(velocity, dtype=f32).copy(),
+            "pending": None, "prev_position": np.asarray(position, dtype=f32).copy(), "dt": f32(0.0),
+            "finished_for": None, "stopped": False,
+        }
+        self.pending.append(e)
+        self.all.append(e)
+        return len(self.all) - 1
+
+    def set_motion(self, h, position, velocity, discontinuity):
+        self.all[h]["pending"] = (np.asarray(position, dtype=f32).copy(), np.asarray(velocity, dtype=f32).copy(), bool(discontinuity))
+
+    def set_listener_rotation(self, q):
+        self.rot_pending = conj(np.asarray(q, dtype=f32))
+
+    def is_finished(self, h):
+        return self.all[h]["stopped"]
+
+    @staticmethod
+    def _smoothed(e, dt_arg, pos, vel):
+        dt = e["dt"] + f32(dt_arg)
+        c = vel * dt
+        naive = e["prev_position"] + c
+        intended = pos + c
+        r = min(dt / SMOOTH, ONE)
+        ir = ONE - r
+        return (ir * naive + r * intended).astype(f32)
+
+    def sample(self, interval, n, acc_dtype=np.float32):
+        interval = f32(interval)
+        prev_rot = self.rot
+        if self.rot_pending is not None:
+            self.rot = self.rot_pending
+            self.rot_pending = None
+        rot = self.rot
+        out = np.zeros((n, 2), dtype=acc_dtype)
+        elapsed = interval * f32(n)
+        nf = f32(n)
+        self.set.extend(self.pending)
+        self.pending = []
+        i = len(self.set) - 1
+        while i >= 0:
+            e = self.set[i]
+            if e["pending"] is not None:
+                old_pos, old_vel = e["pos"], e["vel"]
+                npos, nvel, disc = e["pending"]
+                e["pending"] = None
+                e["prev_position"] = npos.copy() if disc else self._smoothed(e, 0.0, old_pos, old_vel)
+                e["pos"], e["vel"] = npos, nvel
+                e["dt"] = f32(0.0)
+            p0 = rotate(prev_rot, self._smoothed(e, 0.0, e["pos"], e["vel"]))
+            p1 = rotate(rot, self._smoothed(e, elapsed, e["pos"], e["vel"]))
+            e["dt"] = e["dt"] + elapsed
+            distance = norm(p0)
+            if e["finished_for"] is not None:
+                if e["finished_for"] > distance / C_SOUND:
+                    e["stopped"] = True
+                else:
+                    e["finished_for"] = e["finished_for"] + elapsed
+            elif src_is_finished(e["src"]):
+                e["finished_for"] = elapsed
+            if e["stopped"]:
+                self.set[i] = self.set[-1]
+                self.set.pop()
+                i -= 1
+                continue
+            src = e["src"]
+            for ear in (0, 1):
+                off0, g0 = ear_state(p0, ear, e["radius"])
+                off1, g1 = ear_state(p1, ear, e["radius"])
+                src_seek(src, off0)
+                eff = (elapsed + off1) - off0
+                dt = eff / nf
+                d_gain = (g1 - g0) / nf
+                for c0 in range(0, n, 256):
+                    ln = min(256, n - c0)
+                    buf = src_sample(src, dt, ln)
+                    gain = g0 + np.arange(c0, c0 + ln, dtype=f32) * d_gain
+                    contrib = (buf * gain).astype(f32)
+                    out[c0:c0 + ln, ear] = out[c0:c0 + ln, ear] + contrib.astype(acc_dtype)
+                src_seek(src, (-eff) - off0)
+            src_seek(src, elapsed)
+            i -= 1
+        return out
+
+
+# ---------------------------------------------------------------------------------------------
+# Mixer (stereo, MonoToStereo<mono source>) and post filters
+# ---------------------------------------------------------------------------------------------
+
+class Mixer:
+    """Mixer<[f32;2]> of MonoToStereo<src> (mixer.rs:92-119, signal.rs:73-80) or Mixer<f32>."""
+
+    def __init__(self, channels=2):
+        self.channels = channels
+        self.set = []
+        self.pending = []
+
+    def play(self, src):
+        e = {"src": src, "stop": False}
+        self.pending.append(e)
+        return e
+
+    def sample(self, interval, n):
+        self.set.extend(self.pending)
+        self.pending = []
+        out = np.zeros((n, self.channels), dtype=f32)
+        i = len(self.set) - 1
+        while i >= 0:
+            e = self.set[i]
+            if e["stop"] or src_is_finished(e["src"]):
+                e["stop"] = True
+                self.set[i] = self.set[-1]
+                self.set.pop()
+                i -= 1
+                continue
+            for c0 in range(0, n, 1024):
+                ln = min(1024, n - c0)
+                mono = src_sample(e["src"], interval, ln)
+                out[c0:c0 + ln, :] = out[c0:c0 + ln, :] + mono[:, None]
+            i -= 1
+        return out if self.channels == 2 else out
+
+
+def reinhard(x):
+    x = np.asarray(x, dtype=f32)
+    return (x / (ONE + np.abs(x))).astype(f32)
+
+
+def tanh_clip(x):
+    return tanhf(x)
