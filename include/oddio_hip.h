@@ -106,6 +106,10 @@ int oddio_hip_scene_play_frames_batch(oddio_hip_scene* scene, size_t n,
 /* Spatial::set_motion (src/spatial.rs:137-149) */
 int oddio_hip_source_set_motion(oddio_hip_scene* scene, uint32_t source_id, const float position[3],
                                 const float velocity[3], int discontinuity);
+/* Bulk form of set_motion: n handles, positions/velocities [n][3], one discontinuity flag. */
+int oddio_hip_scene_set_motion_batch(oddio_hip_scene* scene, size_t n, const uint32_t* source_ids,
+                                     const float* positions, const float* velocities,
+                                     int discontinuity);
 /* Spatial::is_finished (src/spatial.rs:154-156): true once the source ended AND its propagation
  * delay has elapsed (src/spatial.rs:243-261). */
 int oddio_hip_source_is_finished(oddio_hip_scene* scene, uint32_t source_id, int* finished);
@@ -149,6 +153,11 @@ int oddio_hip_scene_seek_all(oddio_hip_scene* scene, float seconds);
  * has finished.  Enabled by oddio_hip_scene_set_profiling(scene, 1). */
 int oddio_hip_scene_set_profiling(oddio_hip_scene* scene, int enable);
 int oddio_hip_scene_last_kernel_ms(oddio_hip_scene* scene, float ms[3]);
+/* The same for up to `max_calls` most recent profiled calls (oldest first; ms is [n][3]); the
+ * library keeps the last 512.  Lets a benchmark time the mix kernel over its whole timed region
+ * without synchronising inside it. */
+int oddio_hip_scene_kernel_ms_history(oddio_hip_scene* scene, float* ms, size_t max_calls,
+                                      size_t* n_calls);
 
 /* ---- Mixer<[f32;2]> (src/mixer.rs:70-81 `Mixer::new`) ---- */
 int oddio_hip_mixer_create(int device, uint32_t max_sources, uint32_t max_frames,

@@ -84,6 +84,8 @@ def lib():
         "oddio_hip_scene_seek_all": (i32, [vp, f32]),
         "oddio_hip_scene_set_profiling": (i32, [vp, i32]),
         "oddio_hip_scene_last_kernel_ms": (i32, [vp, fp]),
+        "oddio_hip_scene_kernel_ms_history": (i32, [vp, fp, sz, C.POINTER(sz)]),
+        "oddio_hip_scene_set_motion_batch": (i32, [vp, sz, u32p, fp, fp, i32]),
         "oddio_hip_mixer_create": (i32, [i32, u32, u32, vpp]),
         "oddio_hip_mixer_destroy": (i32, [vp]),
         "oddio_hip_mixer_play_sine": (i32, [vp, f32, f32, f32, u32p]),

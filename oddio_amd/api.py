@@ -205,6 +205,13 @@ class _SceneSignal(Signal):
         _lib.check(_lib.lib().oddio_hip_scene_last_kernel_ms(self._h, ms))
         return [ms[0], ms[1], ms[2]]
 
+    def kernel_ms_history(self, max_calls=512):
+        """[n, 3] milliseconds (prepass, mix, reduce+postfx) of the most recent profiled calls."""
+        buf = np.zeros((max_calls, 3), dtype=np.float32)
+        n = C.c_size_t()
+        _lib.check(_lib.lib().oddio_hip_scene_kernel_ms_history(self._h, _fp(buf), max_calls, C.byref(n)))
+        return buf[:n.value].copy()
+
     def __len__(self):
         n = C.c_size_t()
         _lib.check(_lib.lib().oddio_hip_scene_len(self._h, C.byref(n)))
@@ -262,6 +269,17 @@ class SpatialSceneControl:
             s._h, n, arr, st.ctypes.data_as(C.POINTER(C.c_double)), _fp(fg) if fg is not None else None,
             _fp(pos), _fp(vel), _fp(rad), ids.ctypes.data_as(C.POINTER(C.c_uint32))))
         return [Spatial(s, int(i)) for i in ids]
+
+    def set_motion_batch(self, handles, positions, velocities, discontinuity: bool):
+        if isinstance(handles, np.ndarray):
+            ids = np.ascontiguousarray(handles.astype(np.uint32, copy=False))
+        else:
+            ids = np.ascontiguousarray(np.array([h.id for h in handles], dtype=np.uint32))
+        n = len(ids)
+        pos = np.ascontiguousarray(np.asarray(positions, dtype=np.float32).reshape(n, 3))
+        vel = np.ascontiguousarray(np.asarray(velocities, dtype=np.float32).reshape(n, 3))
+        _lib.check(_lib.lib().oddio_hip_scene_set_motion_batch(
+            self._scene._h, n, ids.ctypes.data_as(C.POINTER(C.c_uint32)), _fp(pos), _fp(vel), int(bool(discontinuity))))
 
     def set_listener_rotation(self, rotation_sxyz):
         q = np.ascontiguousarray(np.asarray(rotation_sxyz, dtype=np.float32).reshape(4))

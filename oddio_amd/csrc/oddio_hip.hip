@@ -161,6 +161,7 @@ struct HandleRec {
     bool queued = false;           // play() called, not yet update()d
     bool finished = false;         // Spatial::is_finished
     bool released = false;         // handle dropped by the user
+    uint64_t motion_epoch = 0;     // dedupe stamp for set_motion
     oddio_hip_frames* frames = nullptr;
 };
 
@@ -202,14 +203,16 @@ struct oddio_hip_scene {
     std::vector<HandleRec> handles;
     std::vector<uint32_t> free_ids;
     size_t live_count = 0;                 // queued + in_set
+    uint64_t motion_epoch = 0;
     // audio-thread state
     float rot[4] = {1, 0, 0, 0};
     uint32_t len = 0;                      // live slots
     std::vector<uint32_t> id_of_slot;
     int postfx = 0, mode = 0;
     bool profiling = false;
-    hipEvent_t ev_prof[4] = {nullptr, nullptr, nullptr, nullptr};
-    bool prof_valid = false;
+    static constexpr int PROF_RING = 512;
+    std::vector<hipEvent_t> ev_prof;       // PROF_RING x 4 events, created on first use
+    uint64_t prof_calls = 0;               // profiled calls so far
 };
 
 static int scene_free(oddio_hip_scene* s) {
@@ -266,7 +269,6 @@ extern "C" int oddio_hip_scene_create(int device, uint32_t max_sources, uint32_t
         SC_TRY(hipHostMalloc(&s->h_stopped[r], (1 + STOPPED_CAP) * sizeof(uint32_t), hipHostMallocDefault));
         SC_TRY(hipEventCreateWithFlags(&s->ev_stopped[r], hipEventDisableTiming));
     }
-    for (auto& e : s->ev_prof) SC_TRY(hipEventCreate(&e));
     SC_TRY(hipMemsetAsync(s->d_pend, 0, cap * sizeof(SrcPending), s->stream));
     SC_TRY(hipStreamSynchronize(s->stream));
 #undef SC_TRY
@@ -384,6 +386,22 @@ extern "C" int oddio_hip_source_set_motion(oddio_hip_scene* s, uint32_t id, cons
     return 0;
 }
 
+extern "C" int oddio_hip_scene_set_motion_batch(oddio_hip_scene* s, size_t n, const uint32_t* ids, const float* positions,
+                                                const float* velocities, int discontinuity) {
+    if (!s || !ids || !positions || !velocities) return fail(ODDIO_HIP_EINVAL, "NULL argument");
+    std::lock_guard<std::mutex> lk(s->mu);
+    s->pending_motion.reserve(s->pending_motion.size() + n);
+    for (size_t i = 0; i < n; ++i) {
+        if (ids[i] >= s->handles.size() || s->handles[ids[i]].released) return fail(ODDIO_HIP_ESTATE, "unknown source id %u", ids[i]);
+        PendingMotion m;
+        m.id = ids[i];
+        for (int k = 0; k < 3; ++k) { m.pos[k] = positions[3 * i + k]; m.vel[k] = velocities[3 * i + k]; }
+        m.disc = discontinuity ? 1u : 0u;
+        s->pending_motion.push_back(m);
+    }
+    return 0;
+}
+
 extern "C" int oddio_hip_source_is_finished(oddio_hip_scene* s, uint32_t id, int* finished) {
     if (!s || !finished) return fail(ODDIO_HIP_EINVAL, "NULL argument");
     std::lock_guard<std::mutex> lk(s->mu);
@@ -427,16 +445,34 @@ extern "C" int oddio_hip_scene_len(oddio_hip_scene* s, size_t* len) {
 }
 extern "C" int oddio_hip_scene_set_profiling(oddio_hip_scene* s, int enable) {
     if (!s) return fail(ODDIO_HIP_EINVAL, "NULL scene");
+    DeviceGuard g(s->device);
+    if (enable && s->ev_prof.empty()) {
+        s->ev_prof.assign((size_t)oddio_hip_scene::PROF_RING * 4, nullptr);
+        for (auto& e : s->ev_prof) HIP_TRY(hipEventCreate(&e));
+    }
     s->profiling = enable != 0;
-    s->prof_valid = false;
+    s->prof_calls = 0;
+    return 0;
+}
+extern "C" int oddio_hip_scene_kernel_ms_history(oddio_hip_scene* s, float* ms, size_t max_calls, size_t* n_calls) {
+    if (!s || !ms || !n_calls) return fail(ODDIO_HIP_EINVAL, "NULL argument");
+    DeviceGuard g(s->device);
+    const uint64_t have = std::min<uint64_t>(s->prof_calls, oddio_hip_scene::PROF_RING);
+    const uint64_t n = std::min<uint64_t>(have, max_calls);
+    for (uint64_t i = 0; i < n; ++i) {
+        const uint64_t call = s->prof_calls - n + i;
+        hipEvent_t* ev = &s->ev_prof[(call % oddio_hip_scene::PROF_RING) * 4];
+        HIP_TRY(hipEventSynchronize(ev[3]));
+        for (int k = 0; k < 3; ++k) HIP_TRY(hipEventElapsedTime(&ms[3 * i + k], ev[k], ev[k + 1]));
+    }
+    *n_calls = (size_t)n;
     return 0;
 }
 extern "C" int oddio_hip_scene_last_kernel_ms(oddio_hip_scene* s, float ms[3]) {
-    if (!s || !ms) return fail(ODDIO_HIP_EINVAL, "NULL argument");
-    if (!s->prof_valid) return fail(ODDIO_HIP_ESTATE, "no profiled call yet");
-    DeviceGuard g(s->device);
-    HIP_TRY(hipEventSynchronize(s->ev_prof[3]));
-    for (int k = 0; k < 3; ++k) HIP_TRY(hipEventElapsedTime(&ms[k], s->ev_prof[k], s->ev_prof[k + 1]));
+    size_t n = 0;
+    int rc = oddio_hip_scene_kernel_ms_history(s, ms, 1, &n);
+    if (rc) return rc;
+    if (n == 0) return fail(ODDIO_HIP_ESTATE, "no profiled call yet");
     return 0;
 }
 extern "C" int oddio_hip_scene_synchronize(oddio_hip_scene* s) {
@@ -578,11 +614,11 @@ static int scene_sample_impl(oddio_hip_scene* s, float interval, float* host_out
         std::vector<MotionUpdate> ups;
         {
             std::lock_guard<std::mutex> lk(s->mu);
-            std::unordered_map<uint32_t, size_t> latest;
-            for (size_t i = 0; i < motions.size(); ++i) latest[motions[i].id] = i;
-            for (size_t i = 0; i < motions.size(); ++i) {
-                if (latest[motions[i].id] != i) continue;
-                const HandleRec& h = s->handles[motions[i].id];
+            s->motion_epoch++;
+            for (size_t i = motions.size(); i-- > 0;) {      // newest first: the latest value per source wins
+                HandleRec& h = s->handles[motions[i].id];
+                if (h.motion_epoch == s->motion_epoch) continue;
+                h.motion_epoch = s->motion_epoch;
                 if (!h.in_set) continue;
                 MotionUpdate u;
                 u.slot = h.slot;
@@ -611,15 +647,16 @@ static int scene_sample_impl(oddio_hip_scene* s, float interval, float* host_out
     P.n_sources = s->len;
 
     float* out_dev = dev_out ? dev_out : s->d_out;
-    const bool prof = s->profiling;
+    const bool prof = s->profiling && !s->ev_prof.empty();
+    hipEvent_t* pev = prof ? &s->ev_prof[(s->prof_calls % oddio_hip_scene::PROF_RING) * 4] : nullptr;
     HIP_TRY(hipMemsetAsync(s->d_stopped[r], 0, sizeof(uint32_t), s->stream));
-    if (prof) HIP_TRY(hipEventRecord(s->ev_prof[0], s->stream));
+    if (prof) HIP_TRY(hipEventRecord(pev[0], s->stream));
     if (s->len > 0) {
         hipLaunchKernelGGL(spatial_prepass, dim3((s->len + 255) / 256), dim3(256), 0, s->stream, P, s->d_static, s->d_dyn, s->d_pend,
                            s->d_ear, s->d_stopped[r], STOPPED_CAP);
         HIP_TRY(hipGetLastError());
     }
-    if (prof) HIP_TRY(hipEventRecord(s->ev_prof[1], s->stream));
+    if (prof) HIP_TRY(hipEventRecord(pev[1], s->stream));
     uint32_t n_waves = 0;
     const uint32_t n_tiles = ((uint32_t)n_frames + TILE_FRAMES - 1) / TILE_FRAMES;
     if (n_frames > 0 && s->len > 0) {
@@ -635,7 +672,7 @@ static int scene_sample_impl(oddio_hip_scene* s, float interval, float* host_out
             hipLaunchKernelGGL(spatial_mix<false>, dim3(waves, n_tiles), dim3(64), 0, s->stream, P, s->d_static, s->d_ear, s->d_partials, gpw, n_groups);
         HIP_TRY(hipGetLastError());
     }
-    if (prof) HIP_TRY(hipEventRecord(s->ev_prof[2], s->stream));
+    if (prof) HIP_TRY(hipEventRecord(pev[2], s->stream));
     if (n_frames > 0) {
         const uint32_t n_out = 2u * (uint32_t)n_frames;
         if (n_waves > 0) {
@@ -646,7 +683,7 @@ static int scene_sample_impl(oddio_hip_scene* s, float interval, float* host_out
         }
         HIP_TRY(hipGetLastError());
     }
-    if (prof) { HIP_TRY(hipEventRecord(s->ev_prof[3], s->stream)); s->prof_valid = true; }
+    if (prof) { HIP_TRY(hipEventRecord(pev[3], s->stream)); s->prof_calls++; }
 
     // ---- results back ----
     HIP_TRY(hipMemcpyAsync(s->h_stopped[r], s->d_stopped[r], (1 + STOPPED_CAP) * sizeof(uint32_t), hipMemcpyDeviceToHost, s->stream));
