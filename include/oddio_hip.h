@@ -159,6 +159,11 @@ int oddio_hip_scene_last_kernel_ms(oddio_hip_scene* scene, float ms[3]);
 int oddio_hip_scene_kernel_ms_history(oddio_hip_scene* scene, float* ms, size_t max_calls,
                                       size_t* n_calls);
 
+/* Debug: the runtime's view of the mix kernel's residency (64-thread blocks per CU) and its
+ * register / LDS footprint. */
+int oddio_hip_debug_mix_occupancy(int device, int* blocks_per_cu, int* num_cus, int* vgprs,
+                                  int* lds_bytes);
+
 /* ---- Mixer<[f32;2]> (src/mixer.rs:70-81 `Mixer::new`) ---- */
 int oddio_hip_mixer_create(int device, uint32_t max_sources, uint32_t max_frames,
                            oddio_hip_mixer** out);

@@ -11,7 +11,7 @@ import re
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-SO_PATH = os.path.join(_HERE, "libodd_hip.so")
+SO_PATH = os.environ.get("ODDIO_HIP_LIB") or os.path.join(_HERE, "libodd_hip.so")   # env override: kernel A/B builds
 HEADER = os.path.join(os.path.dirname(_HERE), "include", "oddio_hip.h")
 
 
@@ -86,6 +86,7 @@ def lib():
         "oddio_hip_scene_last_kernel_ms": (i32, [vp, fp]),
         "oddio_hip_scene_kernel_ms_history": (i32, [vp, fp, sz, C.POINTER(sz)]),
         "oddio_hip_scene_set_motion_batch": (i32, [vp, sz, u32p, fp, fp, i32]),
+        "oddio_hip_debug_mix_occupancy": (i32, [i32, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]),
         "oddio_hip_mixer_create": (i32, [i32, u32, u32, vpp]),
         "oddio_hip_mixer_destroy": (i32, [vp]),
         "oddio_hip_mixer_play_sine": (i32, [vp, f32, f32, f32, u32p]),

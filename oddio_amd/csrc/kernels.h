@@ -214,182 +214,278 @@ __global__ __launch_bounds__(256) void spatial_prepass(SceneParams P, const SrcS
 // ---------------------------------------------------------------------------------------------
 // mix kernel
 // ---------------------------------------------------------------------------------------------
-constexpr int MIX_GROUP = 8;                 // sources per phase-A step
-constexpr int WIN_CAP = 1536;                // samples staged per source (covers ds <= ~1.46 at N=1024)
-constexpr int WIN_PAD = WIN_CAP + WIN_CAP / 16 + 16;
-constexpr int CKPT_STRIDE = 17;
-constexpr int TILE_FRAMES = 1024;            // frames per wave pass = 4 chunks of 256 (spatial.rs:393)
+// Shape (measured on MI355X, tools/ubench/valu_cost.hip and the PMC passes under profiles/):
+// one wave issues a VALU op only every ~5 cycles, a SIMD needs >= 4 resident waves to saturate,
+// v_pk_*_f32 costs two scalar ops, and the kernel is VALU-issue bound (LDS ~1/3 busy).  So it is
+// built for 16 waves per CU (<= 128 VGPRs, <= 10 KB LDS per wave) and for the fewest VALU
+// instructions per output sample (11 in the common path):
+//   * a wave renders a 512-frame tile (2 chunks of 256, spatial.rs:393) of its sources: lanes
+//     0-31 are the left ear, 32-63 the right ear; lane (e, c, b) owns the 16 consecutive frames
+//     256c+16b.. of ear e => 16 register accumulators;
+//   * phase A handles 16 sources at a time: lane (j, e, c) runs the exact f32 cursor scan of
+//     source j / ear e / chunk c and leaves 16 checkpoints in LDS;
+//   * the source's sample window is fetched with bounds-checked buffer loads (hardware zero fill
+//     == frames.rs:105-123 out-of-range rule), one source ahead, and staged in LDS once;
+//   * workgroups are MIX_WG_WAVES independent waves (own LDS slice, wave-local ordering only);
+//     their accumulators are summed through LDS in fixed order before one partial tile is written.
+#ifndef ODDIO_MIX_WG_WAVES
+#define ODDIO_MIX_WG_WAVES 4
+#endif
+#ifndef ODDIO_MIX_WAVES
+#define ODDIO_MIX_WAVES 4
+#endif
+#ifndef ODDIO_MIX_BATCH
+#define ODDIO_MIX_BATCH 2
+#endif
+constexpr int MIX_WG_WAVES = ODDIO_MIX_WG_WAVES;       // waves per workgroup
+constexpr int MIX_WAVES_PER_SIMD = ODDIO_MIX_WAVES;    // register budget: 512 / this
+constexpr int MIX_BATCH = ODDIO_MIX_BATCH;             // frames whose LDS reads are in flight together
+constexpr int MIX_WAVES_PER_CU = 16;                   // default grid size (waves per CU)
+constexpr int MIX_GROUP = 16;                // sources per phase-A step (16 x 2 ears x 2 chunks = 64 lanes)
+constexpr int TILE_FRAMES = 512;             // frames per (wave, tile) pass
+constexpr int TILE_CHUNKS = TILE_FRAMES / 256;
+constexpr int WIN_CAP = 768;                 // samples staged per source and tile (ds <= ~1.43)
+constexpr int WIN_VECS = WIN_CAP / 256;      // float4 loads per lane covering WIN_CAP
+constexpr float PAD_EPS = 0.004f;            // |ds - 1| below this: lanes' runs sit 16 samples apart -> padded layout
 
 enum : int { PATH_SKIP = 0, PATH_LDS = 1, PATH_GENERIC = 2, PATH_SINE = 3, PATH_CONST = 4 };
 
-struct MixLds {
-    float ckpt[64 * CKPT_STRIDE];            // cursor checkpoints, [phaseA lane][16] (+1 pad)
-    int cinfo[64 * 4];                       // per phase-A lane: {wrel, frac/fast bits, fast, len}
-    int sinfo[MIX_GROUP * 4];                // per source: {ws, count, path, -}
-    float win[WIN_PAD];                      // padded sample window of the current source
-};
-constexpr size_t MIX_LDS_BYTES = sizeof(MixLds);
+// LDS map of one wave (bytes)
+//   WIN   the source's sample window, one copy.  General sources: plain (sample s at 4*s), pairs
+//         read with ds_read2_b32.  Sources whose resample ratio is within PAD_EPS of 1 (and the
+//         |ds-1| <= EPSILON fast path): one pad float per 16 samples (slot s + s/16; the pad repeats
+//         the next sample), otherwise the lanes' 16-frame runs, 16 samples apart, would all hit
+//         two banks.
+//   CKPT  64 phase-A lanes x 16 cursor checkpoints, xor-swizzled
+//   CINFO per phase-A lane {wrel, frac bits};  EPAR per (source, ear) {g0, dg, ds, fixed_gain}
+//   SINFO per source {ws, count, path, flags}
+constexpr int LDS_WIN = 0;
+constexpr int WIN_SLOTS = 1024;              // >= WIN_CAP*17/16 + 1; 4 KB so the region can also park 16 accumulators x 64 lanes
+constexpr int LDS_CKPT = ((WIN_SLOTS * 4 + 15) / 16) * 16;
+constexpr int LDS_CINFO = LDS_CKPT + 64 * 16 * 4;
+constexpr int LDS_EPAR = LDS_CINFO + 64 * 2 * 4;
+constexpr int LDS_SINFO = LDS_EPAR + MIX_GROUP * 2 * 16;
+constexpr int LDS_TOTAL = LDS_SINFO + MIX_GROUP * 4 * 4;
+constexpr int SFLAG_NEG = 1, SFLAG_FAST_L = 2, SFLAG_FAST_R = 4, SFLAG_PAD = 8;
+static_assert(LDS_TOTAL % 16 == 0, "per-wave LDS slices stay 16-byte aligned");
+static_assert(LDS_TOTAL <= 10240, "16 waves per CU need <= 10 KB of LDS each");
+static_assert(WIN_SLOTS >= WIN_CAP + WIN_CAP / 16 + 1, "padded window fits");
+static_assert(LDS_CKPT >= 16 * 64 * 4, "accumulator parking / cross-wave reduction use 4 KB at offset 0 and must not reach CKPT");
 
 __device__ __forceinline__ void wave_sync() {
-    // single-wave workgroups: LDS ops of one wave execute in order; this is a compiler fence plus
-    // the (free for one wave) barrier.
-    __syncthreads();
+    // Waves never share window/checkpoint data: the LDS pipeline executes one wave's DS operations
+    // in issue order, so a same-wave write -> read hand-off needs no s_barrier, only a compiler
+    // fence.
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
 __device__ __forceinline__ float rl_f(float v, int lane) {
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
 }
 __device__ __forceinline__ int rl_i(int v, int lane) { return __builtin_amdgcn_readlane(v, lane); }
+__device__ __forceinline__ const float* rl_ptr(const float* p, int lane) {
+    const uint64_t u = (uint64_t)p;
+    return (const float*)(((uint64_t)(uint32_t)rl_i((int)(u >> 32), lane) << 32) | (uint64_t)(uint32_t)rl_i((int)(u & 0xffffffffu), lane));
+}
+__device__ __forceinline__ double rl_d(double v, int lane) {
+    const long long b = __double_as_longlong(v);
+    return __longlong_as_double(((long long)rl_i((int)(b >> 32), lane) << 32) | (long long)(uint32_t)rl_i((int)(b & 0xffffffff), lane));
+}
 
-// One source, LDS path, both ears.  acc[2*i+e] += lerp * gain  (spatial.rs:458-462)
-template <bool FULL, bool HAS_FG>
-__device__ __forceinline__ void mix_source_lds(const MixLds& L, int j, int lane, float (&acc)[32], float fbase,
-                                               uint32_t frame0, uint32_t n_frames, float fixed_gain,
-                                               float g0L, float dgL, float dsL, float g0R, float dgR, float dsR) {
-    const int c = lane >> 4, b = lane & 15;
-    if (!FULL && frame0 >= n_frames) return;   // this lane's 16 frames lie past the end of `out`
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+// Coalesced 16 B/lane read of samples [ws, ws + 4*nvec) of a clip into registers through a buffer
+// descriptor clipped to [window, clip end): lanes outside read 0 with no memory traffic.
+// All descriptor inputs are wave-uniform scalars.
+__device__ __forceinline__ void window_load(u32x4 (&pre)[WIN_VECS], const float* clip, int clip_len4, int ws, int nvec, int lane) {
+    const int ws_pos = ws > 0 ? ws : 0;             // first in-clip sample of the window
+    const int neg4 = (ws < 0 ? ws : 0) * 4;         // byte offset of the window start relative to it (<= 0)
+    long long rec = (long long)(clip_len4 - ws_pos) * 4;          // bytes to the (padded) clip end
+    const long long wend = (long long)neg4 + (long long)nvec * 16;   // bytes to the window end
+    if (rec > wend) rec = wend;
+    if (rec < 0) rec = 0;
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(clip + ws_pos), 0, (int)rec, 0x00020000);
 #pragma unroll
-    for (int e = 0; e < 2; ++e) {
-        const float g0 = e ? g0R : g0L, dg = e ? dgR : dgL, ds = e ? dsR : dsL;
-        const int la = j * 8 + e * 4 + c;
-        const int wrel = L.cinfo[la * 4 + 0];
-        const float fracf = __int_as_float(L.cinfo[la * 4 + 1]);
-        const int fast = L.cinfo[la * 4 + 2];
-        if (fast) {
-            // frames.rs:180-187: constant fract, consecutive pairs
-            const int w0 = wrel + 16 * b;
-            int pos = w0 + (w0 >> 4);
-            float a = L.win[pos];
+    for (int k = 0; k < WIN_VECS; ++k) {
+        // negative offsets wrap to huge unsigned values: out of range -> 0
+        pre[k] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, neg4 + 16 * lane + 1024 * k, 0, 0);
+    }
+}
+// registers -> LDS.  Plain layout: one aligned 16-byte store per float4.
+__device__ __forceinline__ void window_store_plain(unsigned char* smem, const u32x4 (&pre)[WIN_VECS], int nvec, int lane) {
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const int w1 = w0 + i + 1;
-                const float bb = L.win[w1 + (w1 >> 4)];
-                float v = a + fracf * (bb - a);
-                if (HAS_FG) v = v * fixed_gain;
-                const float gain = g0 + (fbase + (float)i) * dg;
-                const float p = v * gain;
-                if (FULL || frame0 + (uint32_t)i < n_frames) acc[2 * i + e] = acc[2 * i + e] + p;
-                a = bb;
-            }
-        } else {
-            // frames.rs:189-196: x_{16b+i} = x_{16b} (+ ds) i times, exactly as the scan produced it
-            float x = L.ckpt[la * CKPT_STRIDE + b];
+    for (int k = 0; k < WIN_VECS; ++k) {
+        if (lane + 64 * k < nvec) *reinterpret_cast<u32x4*>(smem + LDS_WIN + 16 * lane + 1024 * k) = pre[k];
+    }
+}
+// Padded layout: slot(s) = s + s/16; the pad slot repeats the following sample, so that a pair
+// (w, w+1) is always two adjacent dwords.
+__device__ __forceinline__ void window_store_padded(unsigned char* smem, const u32x4 (&pre)[WIN_VECS], int nvec, int lane) {
+    unsigned int* win = reinterpret_cast<unsigned int*>(smem + LDS_WIN);
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const int tr = (int)x;
-                const float fr = x - (float)tr;
-                const int w = wrel + tr;
-                const int pos = w + (w >> 4);
-                const float a = L.win[pos];
-                const float bb = L.win[pos + 1];
-                float v = a + fr * (bb - a);
-                if (HAS_FG) v = v * fixed_gain;
-                const float gain = g0 + (fbase + (float)i) * dg;
-                const float p = v * gain;
-                if (FULL || frame0 + (uint32_t)i < n_frames) acc[2 * i + e] = acc[2 * i + e] + p;
-                x = x + ds;
-            }
+    for (int k = 0; k < WIN_VECS; ++k) {
+        const int v = lane + 64 * k;
+        if (v < nvec) {
+            const int li = 4 * v;
+            const int pos = li + (li >> 4);
+            win[pos + 0] = pre[k].x; win[pos + 1] = pre[k].y; win[pos + 2] = pre[k].z; win[pos + 3] = pre[k].w;
+            if ((li & 15) == 0 && li > 0) win[pos - 1] = pre[k].x;
         }
     }
 }
 
-// frames.rs:105-123 straight from global memory (sources whose window does not fit the LDS stage,
-// absurd cursors, |ds| huge ...).  Correct for every input, slow.
+// One source, staged-window path.  acc[i] += lerp * gain for this lane's ear (spatial.rs:458-462).
+// NONNEG: every cursor value of the source is >= 0, so fract(x) == x - trunc(x) (one v_fract_f32).
+// PAD: padded window layout (see above); also serves frames.rs:180-187's constant-fract path.
+template <bool FULL, bool HAS_FG, bool NONNEG, bool PAD>
+__device__ __forceinline__ void mix_source_lds(const unsigned char* smem, int la, int b, int fast, float (&acc)[16], const float (&fi)[16],
+                                               uint32_t frame0, uint32_t n_frames, float fixed_gain, float g0, float dg, float ds) {
+    if (!FULL && frame0 >= n_frames) return;   // this lane's 16 frames lie past the end of `out`
+    const int* cinfo = reinterpret_cast<const int*>(smem + LDS_CINFO);
+    const float* ckpt = reinterpret_cast<const float*>(smem + LDS_CKPT);
+    const float* win = reinterpret_cast<const float*>(smem + LDS_WIN);
+    const int wrel = cinfo[la * 2 + 0];
+    if (PAD && fast) {
+        // frames.rs:180-187 (|ds - 1| <= EPSILON): constant fract, consecutive pairs
+        const float fracf = __int_as_float(cinfo[la * 2 + 1]);
+        const int w0 = wrel + 16 * b;
+        float a = win[w0 + (w0 >> 4)];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int w1 = w0 + i + 1;
+            const float bb = win[w1 + (w1 >> 4)];
+            float v = a + fracf * (bb - a);
+            if (HAS_FG) v = v * fixed_gain;
+            const float p = v * (g0 + fi[i] * dg);
+            if (FULL || frame0 + (uint32_t)i < n_frames) acc[i] = acc[i] + p;
+            a = bb;
+        }
+        return;
+    }
+    // frames.rs:189-196: x_{16b+i} = x_{16b} (+ ds) i times, exactly as the scan produced it.
+    // Software pipelined by hand: a batch's LDS reads are all issued before the first lerp
+    // consumes one.
+    float x = ckpt[la * 16 + (b ^ (la & 15))];
+#pragma unroll
+    for (int i0 = 0; i0 < 16; i0 += MIX_BATCH) {
+        float a[MIX_BATCH], bb[MIX_BATCH], fr[MIX_BATCH];
+#pragma unroll
+        for (int k = 0; k < MIX_BATCH; ++k) {
+            const int tr = (int)x;                                        // v_cvt_i32_f32 (toward zero)
+            fr[k] = NONNEG ? __builtin_amdgcn_fractf(x) : x - (float)tr;  // frames.rs:192
+            int w = wrel + tr;
+            if (PAD) w = w + (w >> 4);
+            a[k] = win[w];                                                // one ds_read2_b32
+            bb[k] = win[w + 1];
+            x = x + ds;                                                   // frames.rs:194
+        }
+#pragma unroll
+        for (int k = 0; k < MIX_BATCH; ++k) {
+            const int i = i0 + k;
+            float v = a[k] + fr[k] * (bb[k] - a[k]);              // frame.rs:39-41 lerp, unfused
+            if (HAS_FG) v = v * fixed_gain;                       // gain.rs:32-37
+            const float p = v * (g0 + fi[i] * dg);                // spatial.rs:459-460
+            if (FULL || frame0 + (uint32_t)i < n_frames) acc[i] = acc[i] + p;
+        }
+    }
+}
+
+// frames.rs:105-123 straight from global memory
 __device__ __forceinline__ float clip_at(const float* clip, uint32_t len, long long i) {
     return (i >= 0 && i < (long long)len) ? clip[i] : 0.0f;
 }
 
-template <bool FULL>
-__device__ __forceinline__ void mix_source_generic(int lane, float (&acc)[32], float fbase, uint32_t frame0,
-                                                uint32_t n_frames, uint32_t tile, const float* clip, uint32_t clip_len,
-                                                uint32_t clip_rate, float fixed_gain, double t_earL, float dtL, float g0L,
-                                                float dgL, double t_earR, float dtR, float g0R, float dgR) {
-    const int c = lane >> 4, b = lane & 15;
-    const uint32_t c_abs = tile * 4u + (uint32_t)c;
+// ---- rare paths -------------------------------------------------------------------------------
+// Sources that do not take the staged-window path (windows larger than the LDS stage, backwards
+// or absurd cursors, Sine / Constant sources).  Kept out of line and working on accumulators
+// parked in LDS (slot i of lane l at acc_lds[i * 64 + l]) so that their register needs (sinf range
+// reduction, 64-bit indices) do not inflate the hot kernel's allocation.
+__device__ __noinline__ void mix_source_generic(float* acc_lds, int lane, float fbase, uint32_t frame0, uint32_t n_frames,
+                                                uint32_t c_abs, const float* clip, uint32_t clip_len, uint32_t clip_rate,
+                                                float fixed_gain, double t_ear, float dt, float g0, float dg) {
+    const int b = lane & 15;
+    double t_c = t_ear;
+    for (uint32_t cc = 0; cc < c_abs; ++cc) t_c = t_c + (double)dt * 256.0;
+    const double s0 = t_c * (double)clip_rate;
+    const float ds = dt * (float)clip_rate;
+    const long long base = f64_as_isize(s0);
+    const float frac0 = (float)(s0 - (double)base);
+    const bool fast = fabsf(ds - 1.0f) <= FLT_EPSILON;
+    float x = frac0;
+    if (!fast) for (int k = 0; k < 16 * b; ++k) x = x + ds;
 #pragma unroll 1
-    for (int e = 0; e < 2; ++e) {
-        const double t_ear = e ? t_earR : t_earL;
-        const float dt = e ? dtR : dtL, g0 = e ? g0R : g0L, dg = e ? dgR : dgL;
-        double t_c = t_ear;
-        for (uint32_t cc = 0; cc < c_abs; ++cc) t_c = t_c + (double)dt * 256.0;
-        const double s0 = t_c * (double)clip_rate;
-        const float ds = dt * (float)clip_rate;
-        const long long base = f64_as_isize(s0);
-        const float frac0 = (float)(s0 - (double)base);
-        const bool fast = fabsf(ds - 1.0f) <= FLT_EPSILON;
-        float x = frac0;
-        if (!fast) for (int k = 0; k < 16 * b; ++k) x = x + ds;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            long long idx; float fr;
-            if (fast) { idx = base + (long long)(16 * b + i); fr = frac0; }
-            else { const long long tr = (long long)x; idx = base + tr; fr = x - (float)tr; }
-            const float a = clip_at(clip, clip_len, idx), bb = clip_at(clip, clip_len, idx + 1);
-            float v = a + fr * (bb - a);
-            v = v * fixed_gain;
-            const float gain = g0 + (fbase + (float)i) * dg;
-            const float p = v * gain;
-            if (FULL || frame0 + (uint32_t)i < n_frames) acc[2 * i + e] = acc[2 * i + e] + p;
-            x = x + ds;
-        }
+    for (int i = 0; i < 16; ++i) {
+        long long idx; float fr;
+        if (fast) { idx = base + (long long)(16 * b + i); fr = frac0; }
+        else { const long long tr = (long long)x; idx = base + tr; fr = x - (float)tr; }
+        const float a = clip_at(clip, clip_len, idx), bb = clip_at(clip, clip_len, idx + 1);
+        float v = a + fr * (bb - a);
+        v = v * fixed_gain;
+        const float p = v * (g0 + (fbase + (float)i) * dg);
+        if (frame0 + (uint32_t)i < n_frames) acc_lds[i * 64 + lane] = acc_lds[i * 64 + lane] + p;
+        x = x + ds;
     }
 }
 
 // sine.rs:34-40 inside the spatial chunk loop; Constant (constant.rs:16-18)
-template <bool FULL, bool IS_SINE>
-__device__ __forceinline__ void mix_source_analytic(int lane, float (&acc)[32], float fbase, uint32_t frame0,
-                                                 uint32_t n_frames, uint32_t tile, float freq_or_value, float fixed_gain,
-                                                 float phL, float dtL, float g0L, float dgL, float phR, float dtR,
-                                                 float g0R, float dgR) {
-    const int c = lane >> 4, b = lane & 15;
-    const uint32_t c_abs = tile * 4u + (uint32_t)c;
+__device__ __noinline__ void mix_source_analytic(float* acc_lds, int lane, float fbase, uint32_t frame0, uint32_t n_frames,
+                                                 uint32_t c_abs, int is_sine, float freq_or_value, float fixed_gain, float ph,
+                                                 float dt, float g0, float dg) {
+    const int b = lane & 15;
+    if (is_sine) for (uint32_t cc = 0; cc < c_abs; ++cc) ph = fmodf(ph + (dt * 256.0f) * freq_or_value, ODDIO_TAU);
 #pragma unroll 1
-    for (int e = 0; e < 2; ++e) {
-        const float dt = e ? dtR : dtL, g0 = e ? g0R : g0L, dg = e ? dgR : dgL;
-        float ph = e ? phR : phL;
-        if (IS_SINE) for (uint32_t cc = 0; cc < c_abs; ++cc) ph = fmodf(ph + (dt * 256.0f) * freq_or_value, ODDIO_TAU);
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            float v;
-            if (IS_SINE) {
-                const float t = dt * (float)(16 * b + i);
-                v = sinf(t * freq_or_value + ph);
-            } else {
-                v = freq_or_value;
-            }
-            v = v * fixed_gain;
-            const float gain = g0 + (fbase + (float)i) * dg;
-            const float p = v * gain;
-            if (FULL || frame0 + (uint32_t)i < n_frames) acc[2 * i + e] = acc[2 * i + e] + p;
+    for (int i = 0; i < 16; ++i) {
+        float v;
+        if (is_sine) {
+            const float t = dt * (float)(16 * b + i);
+            v = sinf(t * freq_or_value + ph);
+        } else {
+            v = freq_or_value;
         }
+        v = v * fixed_gain;
+        const float p = v * (g0 + (fbase + (float)i) * dg);
+        if (frame0 + (uint32_t)i < n_frames) acc_lds[i * 64 + lane] = acc_lds[i * 64 + lane] + p;
     }
 }
 
-// grid = (n_waves, n_tiles); block = 64 (one wave).  Wave w walks groups [g_lo, g_hi) of 8 slots
-// in DESCENDING order (the reference's reverse set walk, spatial.rs:204) and leaves its partial
-// stereo tile in partials[(tile * n_waves + w) * 2048 + ...] (interleaved L,R).
+// grid = (n_workgroups, n_tiles); block = 64 * MIX_WG_WAVES.  Wave w walks groups [g_lo, g_hi) of
+// 16 slots in DESCENDING order (the reference's reverse set walk, spatial.rs:204).  A workgroup
+// leaves ONE partial tile: partials[(tile * n_wgs + wg) * 1024 + e * 512 + f] (planar L | R).
 template <bool FULL>
-__global__ __launch_bounds__(64) void spatial_mix(SceneParams P, const SrcStatic* __restrict__ st,
-                                                  const EarParams* __restrict__ ear, float* __restrict__ partials,
-                                                  uint32_t groups_per_wave, uint32_t n_groups) {
-    __shared__ MixLds L;
-    const int lane = threadIdx.x;
-    const uint32_t wave = blockIdx.x, tile = blockIdx.y;
+__global__ __launch_bounds__(64 * MIX_WG_WAVES, MIX_WAVES_PER_SIMD) void spatial_mix(SceneParams P, const SrcStatic* __restrict__ st,
+                                                                                     const EarParams* __restrict__ ear,
+                                                                                     float* __restrict__ partials,
+                                                                                     uint32_t groups_per_wave, uint32_t n_groups) {
+    __shared__ __attribute__((aligned(16))) unsigned char smem_all[LDS_TOTAL * MIX_WG_WAVES];
+    const int wv = threadIdx.x >> 6;
+    unsigned char* smem = smem_all + LDS_TOTAL * wv;
+    float* ckpt = reinterpret_cast<float*>(smem + LDS_CKPT);
+    int* cinfo = reinterpret_cast<int*>(smem + LDS_CINFO);
+    float4* epar = reinterpret_cast<float4*>(smem + LDS_EPAR);
+    int* sinfo = reinterpret_cast<int*>(smem + LDS_SINFO);
+    const int lane = threadIdx.x & 63;
+    const uint32_t wave = blockIdx.x * MIX_WG_WAVES + wv, tile = blockIdx.y;
     const uint32_t n_frames = P.n_frames;
-    float acc[32];
+    float acc[16], fi[16];
+    // phase-B role: ear e, chunk c (of the tile), block b -> 16 consecutive frames
+    const int eB = lane >> 5, cB = (lane >> 4) & 1, bB = lane & 15;
+    const uint32_t frame0 = tile * TILE_FRAMES + 16u * (uint32_t)(lane & 31);   // this lane's first output frame
+    const float fbase = (float)frame0;
 #pragma unroll
-    for (int k = 0; k < 32; ++k) acc[k] = 0.0f;
-    const uint32_t frame0 = tile * TILE_FRAMES + 16u * (uint32_t)lane;   // this lane's first output frame
-    const float fbase = (float)frame0;                                    // `i as f32` base (spatial.rs:459)
+    for (int k = 0; k < 16; ++k) { acc[k] = 0.0f; fi[k] = fbase + (float)k; }   // `i as f32` (spatial.rs:459)
+    const uint32_t cB_abs = tile * TILE_CHUNKS + (uint32_t)cB;
 
     const uint32_t g_lo = wave * groups_per_wave;
     uint32_t g_hi = g_lo + groups_per_wave;
     if (g_hi > n_groups) g_hi = n_groups;
 
-    // phase-A role of this lane
-    const int jA = lane >> 3, eA = (lane >> 2) & 1, cA = lane & 3;
-    const uint32_t cA_abs = tile * 4u + (uint32_t)cA;
-    const int lenA = (int)n_frames - (int)(cA_abs * 256u) < 0 ? 0 : ((int)n_frames - (int)(cA_abs * 256u) > 256 ? 256 : (int)n_frames - (int)(cA_abs * 256u));
+    // phase-A role: source j of the group, ear e, chunk c
+    const int jA = lane >> 2, eA = (lane >> 1) & 1, cA = lane & 1;
+    const uint32_t cA_abs = tile * TILE_CHUNKS + (uint32_t)cA;
+    const int remA = (int)n_frames - (int)(cA_abs * 256u);
+    const int lenA = remA < 0 ? 0 : (remA > 256 ? 256 : remA);
 
     for (uint32_t g = g_hi; g-- > g_lo;) {
         // ------------------------------ phase A ------------------------------
@@ -401,7 +497,8 @@ __global__ __launch_bounds__(64) void spatial_mix(SceneParams P, const SrcStatic
         if (validA) { ep = ear[2 * srcA + eA]; ss = st[srcA]; }
         const bool live = validA && !(ep.flags & EAR_SKIP);
         int lo = 0x7fffffff, hi = (int)0x80000000;
-        int generic = 0, fast = 0, wbase = 0;
+        int generic = 0, wbase = 0;
+        int fl = 0;                              // SFLAG_* contributed by this stream
         float frac0 = 0.0f, ds = 0.0f;
         if (live && ss.kind == KIND_FRAMES) {
             double t_c = ep.t_ear;
@@ -410,42 +507,50 @@ __global__ __launch_bounds__(64) void spatial_mix(SceneParams P, const SrcStatic
             ds = ep.dt * (float)ss.clip_rate;                                             // :178
             const long long base = f64_as_isize(s0);                                      // :179
             frac0 = (float)(s0 - (double)base);                                           // :181 / :189
-            fast = fabsf(ds - 1.0f) <= FLT_EPSILON;                                       // :180
-            if (!(fabs(s0) < 1.0e9) || !(fabsf(ds) < 65536.0f)) generic = 1;
+            const float dev = fabsf(ds - 1.0f);
+            if (dev <= FLT_EPSILON) fl |= eA ? SFLAG_FAST_R : SFLAG_FAST_L;               // :180
+            if (dev < PAD_EPS) fl |= SFLAG_PAD;
+            // the staged path needs a forward-running, sane cursor; everything else is exact but slow
+            if (!(fabs(s0) < 1.0e9) || !(ds > 0.0f) || !(ds < 4096.0f)) generic = 1;
+            if (frac0 < 0.0f) fl |= SFLAG_NEG;
             wbase = (int)base;
         }
-        // exact f32 cursor scan (frames.rs:189-196); checkpoints every 16 frames
+        const bool fastA = (fl & (SFLAG_FAST_L | SFLAG_FAST_R)) != 0;
+        // exact f32 cursor scan (frames.rs:189-196); checkpoints every 16 frames, xor-swizzled so
+        // that both this (lane-strided) write and phase B's read are bank-conflict free
         float x = frac0;
         {
-            float* ck = &L.ckpt[lane * CKPT_STRIDE];
+            float* ck = &ckpt[lane * 16];
+            const int sw = lane & 15;
 #pragma unroll 1
             for (int b = 0; b < 15; ++b) {
-                ck[b] = x;
+                ck[b ^ sw] = x;
 #pragma unroll
                 for (int i = 0; i < 16; ++i) x = x + ds;
             }
-            ck[15] = x;
+            ck[15 ^ sw] = x;
 #pragma unroll
             for (int i = 0; i < 15; ++i) x = x + ds;   // x == offset at frame 255 of the chunk
         }
         if (live && ss.kind == KIND_FRAMES && lenA > 0 && !generic) {
             int i0, i1;
-            if (fast) { i0 = wbase; i1 = wbase + 255; }
+            if (fastA) { i0 = wbase; i1 = wbase + 255; }
             else {
-                if (!(fabsf(x) < 8.0e6f)) generic = 1;
+                if (!(x < 8.0e6f)) generic = 1;
                 i0 = wbase + (int)frac0;
                 i1 = wbase + (int)x;
             }
             lo = i0 < i1 ? i0 : i1;
             hi = i0 < i1 ? i1 : i0;
         }
-        // per-source (8 lanes) reduction of window bounds
+        // per-source (4 lanes) reduction of window bounds and flags
 #pragma unroll
-        for (int m = 1; m < 8; m <<= 1) {
-            const int olo = __shfl_xor(lo, m), ohi = __shfl_xor(hi, m), og = __shfl_xor(generic, m);
+        for (int m = 1; m < 4; m <<= 1) {
+            const int olo = __shfl_xor(lo, m), ohi = __shfl_xor(hi, m), og = __shfl_xor(generic, m), of = __shfl_xor(fl, m);
             lo = olo < lo ? olo : lo;
             hi = ohi > hi ? ohi : hi;
             generic |= og;
+            fl |= of;
         }
         const int ws = lo & ~3;
         const int count = hi + 2 - ws;
@@ -457,80 +562,118 @@ __global__ __launch_bounds__(64) void spatial_mix(SceneParams P, const SrcStatic
             else if (lo > hi) path = PATH_SKIP;      // no frames in this tile
             else path = (count <= WIN_CAP) ? PATH_LDS : PATH_GENERIC;
         }
-        L.cinfo[lane * 4 + 0] = wbase - ws;
-        L.cinfo[lane * 4 + 1] = __float_as_int(frac0);
-        L.cinfo[lane * 4 + 2] = fast;
-        L.cinfo[lane * 4 + 3] = lenA;
-        if ((lane & 7) == 0) {
-            L.sinfo[jA * 4 + 0] = ws;
-            L.sinfo[jA * 4 + 1] = count;
-            L.sinfo[jA * 4 + 2] = path;
+        cinfo[lane * 2 + 0] = wbase - ws;
+        cinfo[lane * 2 + 1] = __float_as_int(frac0);
+        if (cA == 0) epar[jA * 2 + eA] = make_float4(ep.g0, ep.dg, ds, ss.fixed_gain);
+        if ((lane & 3) == 0) {
+            sinfo[jA * 4 + 0] = ws;
+            sinfo[jA * 4 + 1] = count;
+            sinfo[jA * 4 + 2] = path;
+            sinfo[jA * 4 + 3] = fl;
         }
         wave_sync();
 
         // ------------------------------ phase B ------------------------------
+        // bit 4*j of lds_mask: source j of the group takes the staged-window path
+        const unsigned long long lds_mask = __ballot(path == PATH_LDS && (lane & 3) == 0);
+        u32x4 pre[WIN_VECS];
+        {
+            const int jn = lds_mask ? (63 - __builtin_clzll(lds_mask)) >> 2 : -1;
+            if (jn >= 0) {
+                const int ws_n = __builtin_amdgcn_readfirstlane(sinfo[jn * 4 + 0]);
+                const int cnt_n = __builtin_amdgcn_readfirstlane(sinfo[jn * 4 + 1]);
+                window_load(pre, rl_ptr(ss.clip, jn * 4), (rl_i((int)ss.clip_len, jn * 4) + 3) & ~3, ws_n, (cnt_n + 3) >> 2, lane);
+            }
+        }
 #pragma unroll 1
         for (int j = MIX_GROUP - 1; j >= 0; --j) {
-            const int path_j = __builtin_amdgcn_readfirstlane(L.sinfo[j * 4 + 2]);
+            const int path_j = __builtin_amdgcn_readfirstlane(sinfo[j * 4 + 2]);
             if (path_j == PATH_SKIP) continue;
-            const int laL = j * 8, laR = j * 8 + 4;
-            const float g0L = rl_f(ep.g0, laL), dgL = rl_f(ep.dg, laL), dtL = rl_f(ep.dt, laL);
-            const float g0R = rl_f(ep.g0, laR), dgR = rl_f(ep.dg, laR), dtR = rl_f(ep.dt, laR);
-            const float fg = rl_f(ss.fixed_gain, laL);
+            const float4 pe = epar[j * 2 + eB];           // this lane's ear: {g0, dg, ds, fixed_gain}
+            const int la = j * 4 + eB * 2 + cB;           // (source, ear, chunk) stream of this lane
             if (path_j == PATH_LDS) {
-                const int ws_j = __builtin_amdgcn_readfirstlane(L.sinfo[j * 4 + 0]);
-                const int count_j = __builtin_amdgcn_readfirstlane(L.sinfo[j * 4 + 1]);
-                const uint64_t cp = ((uint64_t)(uint32_t)rl_i((int)((uint64_t)ss.clip >> 32), laL) << 32) |
-                                    (uint64_t)(uint32_t)rl_i((int)((uint64_t)ss.clip & 0xffffffffu), laL);
-                const float* clip = (const float*)cp;
-                const int clip_len4 = (int)((rl_i((int)ss.clip_len, laL) + 3) & ~3);
-                const int nvec = (count_j + 3) >> 2;
-                wave_sync();   // previous source's readers are done with L.win
-                for (int v = lane; v < nvec; v += 64) {
-                    const int idx = ws_j + 4 * v;
-                    float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
-                    if (idx >= 0 && idx < clip_len4) val = *reinterpret_cast<const float4*>(clip + idx);
-                    const int li = 4 * v;
-                    const int pos = li + (li >> 4);
-                    L.win[pos + 0] = val.x; L.win[pos + 1] = val.y; L.win[pos + 2] = val.z; L.win[pos + 3] = val.w;
-                    if ((li & 15) == 0 && li > 0) L.win[pos - 1] = val.x;   // duplicate across the pad
+                const int count_j = __builtin_amdgcn_readfirstlane(sinfo[j * 4 + 1]);
+                const int flags_j = __builtin_amdgcn_readfirstlane(sinfo[j * 4 + 3]);
+                const bool pad_j = (flags_j & SFLAG_PAD) != 0;
+                wave_sync();   // previous source's readers are done with the window
+                if (pad_j) window_store_padded(smem, pre, (count_j + 3) >> 2, lane);
+                else window_store_plain(smem, pre, (count_j + 3) >> 2, lane);
+                wave_sync();
+                {   // prefetch the next staged source of this group; lands while we compute
+                    const unsigned long long below = lds_mask & ((1ull << (4 * j)) - 1ull);
+                    if (below) {
+                        const int jn = (63 - __builtin_clzll(below)) >> 2;
+                        const int ws_n = __builtin_amdgcn_readfirstlane(sinfo[jn * 4 + 0]);
+                        const int cnt_n = __builtin_amdgcn_readfirstlane(sinfo[jn * 4 + 1]);
+                        window_load(pre, rl_ptr(ss.clip, jn * 4), (rl_i((int)ss.clip_len, jn * 4) + 3) & ~3, ws_n, (cnt_n + 3) >> 2, lane);
+                    }
+                }
+                const int fast_e = eB ? (flags_j & SFLAG_FAST_R) : (flags_j & SFLAG_FAST_L);
+                const bool plain_math = pe.w == 1.0f && !(flags_j & SFLAG_NEG);   // wave-uniform: fixed_gain is per source
+                if (pad_j) {
+                    mix_source_lds<FULL, true, false, true>(smem, la, bB, fast_e, acc, fi, frame0, n_frames, pe.w, pe.x, pe.y, pe.z);
+                } else if (__builtin_amdgcn_readfirstlane((int)plain_math)) {
+                    mix_source_lds<FULL, false, true, false>(smem, la, bB, 0, acc, fi, frame0, n_frames, pe.w, pe.x, pe.y, pe.z);
+                } else {
+                    mix_source_lds<FULL, true, false, false>(smem, la, bB, 0, acc, fi, frame0, n_frames, pe.w, pe.x, pe.y, pe.z);
+                }
+            } else {
+                // rare path: park the accumulators in LDS, run out of line, fetch them back
+                float* park = reinterpret_cast<float*>(smem);
+                const int laL = j * 4, laR = j * 4 + 2;   // phase-A lanes holding this source's ears
+                const float dt = eB ? rl_f(ep.dt, laR) : rl_f(ep.dt, laL);
+                wave_sync();
+#pragma unroll
+                for (int k = 0; k < 16; ++k) park[k * 64 + lane] = acc[k];
+                wave_sync();
+                if (path_j == PATH_GENERIC) {
+                    const double t_ear = eB ? rl_d(ep.t_ear, laR) : rl_d(ep.t_ear, laL);
+                    mix_source_generic(park, lane, fbase, frame0, n_frames, cB_abs, rl_ptr(ss.clip, laL), (uint32_t)rl_i((int)ss.clip_len, laL),
+                                       (uint32_t)rl_i((int)ss.clip_rate, laL), pe.w, t_ear, dt, pe.x, pe.y);
+                } else {
+                    const float ph = eB ? rl_f(ep.phase_ear, laR) : rl_f(ep.phase_ear, laL);
+                    mix_source_analytic(park, lane, fbase, frame0, n_frames, cB_abs, path_j == PATH_SINE ? 1 : 0, rl_f(ss.freq_or_value, laL), pe.w,
+                                        ph, dt, pe.x, pe.y);
                 }
                 wave_sync();
-                const float dsL = rl_f(ds, laL), dsR = rl_f(ds, laR);
-                if (fg != 1.0f)
-                    mix_source_lds<FULL, true>(L, j, lane, acc, fbase, frame0, n_frames, fg, g0L, dgL, dsL, g0R, dgR, dsR);
-                else
-                    mix_source_lds<FULL, false>(L, j, lane, acc, fbase, frame0, n_frames, fg, g0L, dgL, dsL, g0R, dgR, dsR);
-            } else if (path_j == PATH_GENERIC) {
-                const uint64_t cp = ((uint64_t)(uint32_t)rl_i((int)((uint64_t)ss.clip >> 32), laL) << 32) |
-                                    (uint64_t)(uint32_t)rl_i((int)((uint64_t)ss.clip & 0xffffffffu), laL);
-                const uint32_t clen = (uint32_t)rl_i((int)ss.clip_len, laL), crate = (uint32_t)rl_i((int)ss.clip_rate, laL);
-                const long long tLb = __double_as_longlong(ep.t_ear);
-                const double tL = __longlong_as_double(((long long)rl_i((int)(tLb >> 32), laL) << 32) | (long long)(uint32_t)rl_i((int)(tLb & 0xffffffff), laL));
-                const double tR = __longlong_as_double(((long long)rl_i((int)(tLb >> 32), laR) << 32) | (long long)(uint32_t)rl_i((int)(tLb & 0xffffffff), laR));
-                mix_source_generic<FULL>(lane, acc, fbase, frame0, n_frames, tile, (const float*)cp, clen, crate, fg,
-                                         tL, dtL, g0L, dgL, tR, dtR, g0R, dgR);
-            } else {
-                const float fv = rl_f(ss.freq_or_value, laL);
-                const float phL = rl_f(ep.phase_ear, laL), phR = rl_f(ep.phase_ear, laR);
-                if (path_j == PATH_SINE)
-                    mix_source_analytic<FULL, true>(lane, acc, fbase, frame0, n_frames, tile, fv, fg, phL, dtL, g0L, dgL, phR, dtR, g0R, dgR);
-                else
-                    mix_source_analytic<FULL, false>(lane, acc, fbase, frame0, n_frames, tile, fv, fg, phL, dtL, g0L, dgL, phR, dtR, g0R, dgR);
+#pragma unroll
+                for (int k = 0; k < 16; ++k) acc[k] = park[k * 64 + lane];
             }
         }
         wave_sync();   // before the next group's phase A overwrites ckpt/cinfo
     }
 
-    // this lane's 16 frames x 2 ears are 32 consecutive floats of the interleaved partial tile
-    float4* dst = reinterpret_cast<float4*>(partials + ((size_t)tile * gridDim.x + wave) * (2 * TILE_FRAMES) + 32 * lane);
+    // ---- cross-wave reduction through LDS, fixed order (wave 0 + wave 1 + ...), then one store ----
+    // partial tile is planar: [ear][512 frames]; this lane owns frames 16*(lane&31).. of ear lane>>5
+    float* dst = partials + ((size_t)tile * gridDim.x + blockIdx.x) * (2 * TILE_FRAMES) + (size_t)eB * TILE_FRAMES + 16 * (lane & 31);
+    if (MIX_WG_WAVES == 1) {
 #pragma unroll
-    for (int q = 0; q < 8; ++q) dst[q] = make_float4(acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]);
+        for (int q = 0; q < 4; ++q) reinterpret_cast<float4*>(dst)[q] = make_float4(acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]);
+        return;
+    }
+    __syncthreads();   // every wave is done with its slice
+    if (wv != 0) {
+        float* mine = reinterpret_cast<float*>(smem);
+#pragma unroll
+        for (int k = 0; k < 16; ++k) mine[k * 64 + lane] = acc[k];
+    }
+    __syncthreads();
+    if (wv == 0) {
+#pragma unroll 1
+        for (int w = 1; w < MIX_WG_WAVES; ++w) {
+            const float* other = reinterpret_cast<const float*>(smem_all + LDS_TOTAL * w);
+#pragma unroll
+            for (int k = 0; k < 16; ++k) acc[k] = acc[k] + other[k * 64 + lane];
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) reinterpret_cast<float4*>(dst)[q] = make_float4(acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
-// reduce: out[f][e] = sum over waves (fixed order) ; then Reinhard / Tanh
-// grid = (ceil(2*n_frames / 64)), block = 1024 = 64 outputs x 16 segments
+// reduce: out[f][e] = sum over workgroup partials (fixed order) ; then Reinhard / Tanh
+// partials are planar tiles [tile][wg][e][512]; out is interleaved stereo.
+// grid = (ceil(n_frames / 32)), block = 1024: thread = (segment s of 16, ear e, frame-in-32)
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ float postfx_apply(float x, int postfx) {
     if (postfx == 1) return x / (1.0f + fabsf(x));   // reinhard.rs:32
@@ -538,18 +681,20 @@ __device__ __forceinline__ float postfx_apply(float x, int postfx) {
     return x;
 }
 
+constexpr int RED_SEGS = 16;
+
 __global__ __launch_bounds__(1024) void reduce_partials(const float* __restrict__ partials, float* __restrict__ out,
-                                                        uint32_t n_waves, uint32_t n_frames, int postfx) {
-    __shared__ float red[16][64];
+                                                        uint32_t n_wgs, uint32_t n_frames, int postfx) {
+    __shared__ float red[RED_SEGS][64];
     const uint32_t ox = threadIdx.x & 63, seg = threadIdx.x >> 6;
-    const uint32_t o = blockIdx.x * 64 + ox;          // flat interleaved output index
-    const uint32_t n_out = 2 * n_frames;
-    const uint32_t tile = o / (2 * TILE_FRAMES), within = o % (2 * TILE_FRAMES);
+    const uint32_t e = ox >> 5;
+    const uint32_t f = blockIdx.x * 32 + (ox & 31);      // output frame
+    const uint32_t tile = f / TILE_FRAMES, fin = f % TILE_FRAMES;
     float s = 0.0f;
-    if (o < n_out) {
-        const float* p = partials + (size_t)tile * n_waves * (2 * TILE_FRAMES) + within;
+    if (f < n_frames) {
+        const float* p = partials + (size_t)tile * n_wgs * (2 * TILE_FRAMES) + (size_t)e * TILE_FRAMES + fin;
         bool first = true;
-        for (uint32_t w = seg; w < n_waves; w += 16) {
+        for (uint32_t w = seg; w < n_wgs; w += RED_SEGS) {
             const float v = p[(size_t)w * (2 * TILE_FRAMES)];
             s = first ? v : s + v;
             first = false;
@@ -557,12 +702,12 @@ __global__ __launch_bounds__(1024) void reduce_partials(const float* __restrict_
     }
     red[seg][ox] = s;
     __syncthreads();
-    if (seg == 0 && o < n_out) {
-        // fixed-order combine; segments beyond n_waves hold exact zeros
+    if (seg == 0 && f < n_frames) {
+        // fixed-order combine; segments beyond n_wgs hold exact zeros and are skipped
         float t = red[0][ox];
-        const uint32_t nseg = n_waves < 16 ? n_waves : 16;
+        const uint32_t nseg = n_wgs < RED_SEGS ? n_wgs : RED_SEGS;
         for (uint32_t k = 1; k < nseg; ++k) t = t + red[k][ox];
-        out[o] = postfx_apply(t, postfx);
+        out[2 * f + e] = postfx_apply(t, postfx);
     }
 }
 

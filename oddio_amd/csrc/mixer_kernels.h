@@ -40,13 +40,16 @@ __global__ __launch_bounds__(256) void mixer_prepass(uint32_t n_sources, uint32_
 }
 
 constexpr int MIXER_GROUP = 64;
+constexpr int MIXER_TILE = 1024;               // one tile == one Mixer staging chunk (mixer.rs:77)
+constexpr int MIXER_WIN_CAP = 1536;           // padded single-copy window (one pad float per 16 samples)
+constexpr int MIXER_WIN_PAD = MIXER_WIN_CAP + MIXER_WIN_CAP / 16 + 16;
 constexpr int MIXER_CKPT_STRIDE = 65;
 
 struct MixerLds {
     float ckpt[64 * MIXER_CKPT_STRIDE];   // [phase-A lane = source][64 checkpoints]
     int cinfo[64 * 4];                    // per source: {wrel, frac bits, fast, path}
     int sinfo[64 * 2];                    // per source: {ws, count}
-    float win[WIN_PAD];
+    float win[MIXER_WIN_PAD];
 };
 
 template <bool FULL>
@@ -59,11 +62,11 @@ __global__ __launch_bounds__(64) void mixer_mix(uint32_t n_sources, uint32_t n_f
     float acc[16];
 #pragma unroll
     for (int k = 0; k < 16; ++k) acc[k] = 0.0f;
-    const uint32_t frame0 = tile * TILE_FRAMES + 16u * (uint32_t)lane;
+    const uint32_t frame0 = tile * MIXER_TILE + 16u * (uint32_t)lane;
     const uint32_t g_lo = wave * groups_per_wave;
     uint32_t g_hi = g_lo + groups_per_wave;
     if (g_hi > n_groups) g_hi = n_groups;
-    const int len_tile = (int)n_frames - (int)(tile * TILE_FRAMES) > TILE_FRAMES ? TILE_FRAMES : (int)n_frames - (int)(tile * TILE_FRAMES);
+    const int len_tile = (int)n_frames - (int)(tile * MIXER_TILE) > MIXER_TILE ? MIXER_TILE : (int)n_frames - (int)(tile * MIXER_TILE);
 
     for (uint32_t g = g_hi; g-- > g_lo;) {
         // ---- phase A: one lane per source ----
@@ -117,7 +120,7 @@ __global__ __launch_bounds__(64) void mixer_mix(uint32_t n_sources, uint32_t n_f
                 const int lo = i0 < i1 ? i0 : i1, hi = i0 < i1 ? i1 : i0;
                 ws = lo & ~3;
                 count = hi + 2 - ws;
-                path = (generic || count > WIN_CAP) ? PATH_GENERIC : PATH_LDS;
+                path = (generic || count > MIXER_WIN_CAP) ? PATH_GENERIC : PATH_LDS;
             }
         }
         L.cinfo[lane * 4 + 0] = wbase - ws;
@@ -239,9 +242,37 @@ __global__ __launch_bounds__(64) void mixer_mix(uint32_t n_sources, uint32_t n_f
     }
     (void)len_tile;
     // MonoToStereo: duplicate (signal.rs:73-80); Mixer adds per channel (mixer.rs:114-116)
-    float4* dst = reinterpret_cast<float4*>(partials + ((size_t)tile * gridDim.x + wave) * (2 * TILE_FRAMES) + 32 * lane);
+    float4* dst = reinterpret_cast<float4*>(partials + ((size_t)tile * gridDim.x + wave) * (2 * MIXER_TILE) + 32 * lane);
 #pragma unroll
     for (int q = 0; q < 8; ++q) dst[q] = make_float4(acc[2 * q], acc[2 * q], acc[2 * q + 1], acc[2 * q + 1]);
+}
+
+// out[o] = sum over waves (fixed order) of interleaved partial tiles, then Reinhard / Tanh
+__global__ __launch_bounds__(1024) void mixer_reduce(const float* __restrict__ partials, float* __restrict__ out,
+                                                     uint32_t n_waves, uint32_t n_frames, int postfx) {
+    __shared__ float red[16][64];
+    const uint32_t ox = threadIdx.x & 63, seg = threadIdx.x >> 6;
+    const uint32_t o = blockIdx.x * 64 + ox;
+    const uint32_t n_out = 2 * n_frames;
+    const uint32_t tile = o / (2 * MIXER_TILE), within = o % (2 * MIXER_TILE);
+    float s = 0.0f;
+    if (o < n_out) {
+        const float* p = partials + (size_t)tile * n_waves * (2 * MIXER_TILE) + within;
+        bool first = true;
+        for (uint32_t w = seg; w < n_waves; w += 16) {
+            const float v = p[(size_t)w * (2 * MIXER_TILE)];
+            s = first ? v : s + v;
+            first = false;
+        }
+    }
+    red[seg][ox] = s;
+    __syncthreads();
+    if (seg == 0 && o < n_out) {
+        float t = red[0][ox];
+        const uint32_t nseg = n_waves < 16 ? n_waves : 16;
+        for (uint32_t k = 1; k < nseg; ++k) t = t + red[k][ox];
+        out[o] = postfx_apply(t, postfx);
+    }
 }
 
 struct MixerMove { uint32_t dst, src; };

@@ -10,6 +10,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -247,19 +248,23 @@ extern "C" int oddio_hip_scene_create(int device, uint32_t max_sources, uint32_t
     s->device = device; s->max_sources = max_sources; s->max_frames = max_frames;
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) != hipSuccess) { delete s; return fail(ODDIO_HIP_ENODEV, "hipGetDeviceProperties failed"); }
-    s->waves_cap = (uint32_t)prop.multiProcessorCount * 8u;
-    if (s->waves_cap == 0) s->waves_cap = 2048;
+    {   // mix-kernel waves per CU (one wave = one 64-thread workgroup); tunable for experiments
+        uint32_t per_cu = MIX_WAVES_PER_CU;
+        if (const char* e = getenv("ODDIO_HIP_WAVES_PER_CU")) { int v = atoi(e); if (v > 0 && v <= 64) per_cu = (uint32_t)v; }
+        s->waves_cap = (uint32_t)prop.multiProcessorCount * per_cu;
+        if (s->waves_cap == 0) s->waves_cap = 2048;
+    }
     s->tiles_max = (max_frames + TILE_FRAMES - 1) / TILE_FRAMES;
     const size_t cap = max_sources;
     const uint32_t groups = (max_sources + MIX_GROUP - 1) / MIX_GROUP;
-    const uint32_t waves = std::min(groups, s->waves_cap);
+    const uint32_t wgs_max = (std::min(groups, s->waves_cap) + MIX_WG_WAVES - 1) / MIX_WG_WAVES + 1;
 #define SC_TRY(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { int rc = fail(_e == hipErrorOutOfMemory ? ODDIO_HIP_ENOMEM : (int)_e, "%s: %s", #expr, hipGetErrorString(_e)); scene_free(s); return rc; } } while (0)
     SC_TRY(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
     SC_TRY(hipMalloc(&s->d_static, cap * sizeof(SrcStatic)));
     SC_TRY(hipMalloc(&s->d_dyn, cap * sizeof(SrcDyn)));
     SC_TRY(hipMalloc(&s->d_pend, cap * sizeof(SrcPending)));
     SC_TRY(hipMalloc(&s->d_ear, cap * 2 * sizeof(EarParams)));
-    SC_TRY(hipMalloc(&s->d_partials, (size_t)s->tiles_max * waves * 2 * TILE_FRAMES * sizeof(float)));
+    SC_TRY(hipMalloc(&s->d_partials, (size_t)s->tiles_max * wgs_max * 2 * TILE_FRAMES * sizeof(float)));
     SC_TRY(hipMalloc(&s->d_out, (size_t)s->tiles_max * 2 * TILE_FRAMES * sizeof(float)));
     SC_TRY(hipMalloc(&s->d_motion, cap * sizeof(MotionUpdate)));
     SC_TRY(hipMalloc(&s->d_moves, cap * sizeof(SlotMove)));
@@ -657,26 +662,27 @@ static int scene_sample_impl(oddio_hip_scene* s, float interval, float* host_out
         HIP_TRY(hipGetLastError());
     }
     if (prof) HIP_TRY(hipEventRecord(pev[1], s->stream));
-    uint32_t n_waves = 0;
+    uint32_t n_wgs = 0;
     const uint32_t n_tiles = ((uint32_t)n_frames + TILE_FRAMES - 1) / TILE_FRAMES;
     if (n_frames > 0 && s->len > 0) {
         const uint32_t n_groups = (s->len + MIX_GROUP - 1) / MIX_GROUP;
         uint32_t waves = s->mode == ODDIO_HIP_MODE_ORDERED ? 1u : std::min(n_groups, s->waves_cap);
         const uint32_t gpw = (n_groups + waves - 1) / waves;
         waves = (n_groups + gpw - 1) / gpw;
-        n_waves = waves;
+        // whole workgroups of MIX_WG_WAVES independent waves (trailing waves get an empty range)
+        n_wgs = (waves + MIX_WG_WAVES - 1) / MIX_WG_WAVES;
         const bool full = (n_frames % TILE_FRAMES) == 0;
         if (full)
-            hipLaunchKernelGGL(spatial_mix<true>, dim3(waves, n_tiles), dim3(64), 0, s->stream, P, s->d_static, s->d_ear, s->d_partials, gpw, n_groups);
+            hipLaunchKernelGGL(spatial_mix<true>, dim3(n_wgs, n_tiles), dim3(64 * MIX_WG_WAVES), 0, s->stream, P, s->d_static, s->d_ear, s->d_partials, gpw, n_groups);
         else
-            hipLaunchKernelGGL(spatial_mix<false>, dim3(waves, n_tiles), dim3(64), 0, s->stream, P, s->d_static, s->d_ear, s->d_partials, gpw, n_groups);
+            hipLaunchKernelGGL(spatial_mix<false>, dim3(n_wgs, n_tiles), dim3(64 * MIX_WG_WAVES), 0, s->stream, P, s->d_static, s->d_ear, s->d_partials, gpw, n_groups);
         HIP_TRY(hipGetLastError());
     }
     if (prof) HIP_TRY(hipEventRecord(pev[2], s->stream));
     if (n_frames > 0) {
         const uint32_t n_out = 2u * (uint32_t)n_frames;
-        if (n_waves > 0) {
-            hipLaunchKernelGGL(reduce_partials, dim3((n_out + 63) / 64), dim3(1024), 0, s->stream, s->d_partials, out_dev, n_waves,
+        if (n_wgs > 0) {
+            hipLaunchKernelGGL(reduce_partials, dim3(((uint32_t)n_frames + 31) / 32), dim3(1024), 0, s->stream, s->d_partials, out_dev, n_wgs,
                                (uint32_t)n_frames, s->postfx);
         } else {
             hipLaunchKernelGGL(zero_kernel, dim3((n_out + 255) / 256), dim3(256), 0, s->stream, out_dev, n_out);   // spatial.rs:389-391
@@ -756,6 +762,23 @@ extern "C" int oddio_hip_source_playback_position(oddio_hip_scene* s, uint32_t i
     double sp = d.t * rate;
     sp = sp != sp ? 0.0 : std::trunc(sp);
     *seconds = sp / rate;
+    return 0;
+}
+
+// Debug: what the runtime thinks about the mix kernel's residency (blocks of 64 threads per CU).
+extern "C" int oddio_hip_debug_mix_occupancy(int device, int* blocks_per_cu, int* num_cus, int* vgprs, int* lds_bytes) {
+    DeviceGuard g(device);
+    if (!g.ok) return fail(ODDIO_HIP_ENODEV, "hipSetDevice(%d) failed", device);
+    int nb = 0;
+    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, spatial_mix<true>, 64 * MIX_WG_WAVES, 0));
+    hipFuncAttributes fa;
+    HIP_TRY(hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(spatial_mix<true>)));
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device));
+    if (blocks_per_cu) *blocks_per_cu = nb;
+    if (num_cus) *num_cus = prop.multiProcessorCount;
+    if (vgprs) *vgprs = fa.numRegs;
+    if (lds_bytes) *lds_bytes = (int)fa.sharedSizeBytes;
     return 0;
 }
 
