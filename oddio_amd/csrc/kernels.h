@@ -10,7 +10,7 @@
 //                                         (spatial.rs:191-265, :445-469 scalar part, :501-549)
 //   spatial_mix       1 wave  / 8 sources per step; the per-sample loop
 //                                         (spatial.rs:456-463 + frames.rs:176-201 + sine.rs:34-40)
-//   reduce_partials   fixed-order sum of the per-wave stereo partials + Reinhard/Tanh epilogue
+//   reduce_stage1/2   fixed-order sum of the workgroup partial tiles + Reinhard/Tanh epilogue
 //                                         (reinhard.rs:32, tanh.rs:26)
 //
 // Mix kernel work decomposition (why it is not "one lane = one output frame"):
@@ -310,7 +310,11 @@ __device__ __forceinline__ void window_load(u32x4 (&pre)[WIN_VECS], const float*
 #pragma unroll
     for (int k = 0; k < WIN_VECS; ++k) {
         // negative offsets wrap to huge unsigned values: out of range -> 0
+#if defined(ODDIO_EXP) && ODDIO_EXP == 3
+        pre[k] = u32x4{(unsigned)lane, 0u, 1u, 2u};             // EXPERIMENT: no window loads (wrong data)
+#else
         pre[k] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, neg4 + 16 * lane + 1024 * k, 0, 0);
+#endif
     }
 }
 // registers -> LDS.  Plain layout: one aligned 16-byte store per float4.
@@ -377,8 +381,15 @@ __device__ __forceinline__ void mix_source_lds(const unsigned char* smem, int la
             fr[k] = NONNEG ? __builtin_amdgcn_fractf(x) : x - (float)tr;  // frames.rs:192
             int w = wrel + tr;
             if (PAD) w = w + (w >> 4);
+#if defined(ODDIO_EXP) && ODDIO_EXP == 1
+            w = (w & 1) + 2 * (b + 16 * (la & 3)) + 128 * k;    // EXPERIMENT: conflict-free addresses (wrong data)
+#endif
+#if defined(ODDIO_EXP) && ODDIO_EXP == 2
+            a[k] = x; bb[k] = fr[k];                            // EXPERIMENT: no LDS reads (wrong data)
+#else
             a[k] = win[w];                                                // one ds_read2_b32
             bb[k] = win[w + 1];
+#endif
             x = x + ds;                                                   // frames.rs:194
         }
 #pragma unroll
@@ -681,20 +692,27 @@ __device__ __forceinline__ float postfx_apply(float x, int postfx) {
     return x;
 }
 
-constexpr int RED_SEGS = 16;
+constexpr int RED_SPLIT = 16;   // stage-1 slices of the workgroup-partial list
+constexpr int RED_SEGS = 4;     // strided segments inside one stage-1 block
 
-__global__ __launch_bounds__(1024) void reduce_partials(const float* __restrict__ partials, float* __restrict__ out,
-                                                        uint32_t n_wgs, uint32_t n_frames, int postfx) {
+// stage 1: grid = (ceil(n_frames / 32), RED_SPLIT), block = 256 = 64 outputs x RED_SEGS.
+// slice k sums workgroup partials [k*per, (k+1)*per) -> stage1[k][2*f + e]
+__global__ __launch_bounds__(256) void reduce_stage1(const float* __restrict__ partials, float* __restrict__ stage1,
+                                                     uint32_t n_wgs, uint32_t n_frames) {
     __shared__ float red[RED_SEGS][64];
     const uint32_t ox = threadIdx.x & 63, seg = threadIdx.x >> 6;
     const uint32_t e = ox >> 5;
     const uint32_t f = blockIdx.x * 32 + (ox & 31);      // output frame
     const uint32_t tile = f / TILE_FRAMES, fin = f % TILE_FRAMES;
+    const uint32_t per = (n_wgs + RED_SPLIT - 1) / RED_SPLIT;
+    const uint32_t w0 = blockIdx.y * per;
+    uint32_t w1 = w0 + per;
+    if (w1 > n_wgs) w1 = n_wgs;
     float s = 0.0f;
     if (f < n_frames) {
         const float* p = partials + (size_t)tile * n_wgs * (2 * TILE_FRAMES) + (size_t)e * TILE_FRAMES + fin;
         bool first = true;
-        for (uint32_t w = seg; w < n_wgs; w += RED_SEGS) {
+        for (uint32_t w = w0 + seg; w < w1; w += RED_SEGS) {
             const float v = p[(size_t)w * (2 * TILE_FRAMES)];
             s = first ? v : s + v;
             first = false;
@@ -703,12 +721,25 @@ __global__ __launch_bounds__(1024) void reduce_partials(const float* __restrict_
     red[seg][ox] = s;
     __syncthreads();
     if (seg == 0 && f < n_frames) {
-        // fixed-order combine; segments beyond n_wgs hold exact zeros and are skipped
         float t = red[0][ox];
-        const uint32_t nseg = n_wgs < RED_SEGS ? n_wgs : RED_SEGS;
+        const uint32_t have = w1 > w0 ? w1 - w0 : 0;
+        const uint32_t nseg = have < RED_SEGS ? have : RED_SEGS;
         for (uint32_t k = 1; k < nseg; ++k) t = t + red[k][ox];
-        out[2 * f + e] = postfx_apply(t, postfx);
+        stage1[(size_t)blockIdx.y * (2 * n_frames) + 2 * f + e] = have ? t : 0.0f;
     }
+}
+
+// stage 2: out[o] = stage1[0][o] + stage1[1][o] + ... (fixed order), then Reinhard / Tanh
+__global__ __launch_bounds__(256) void reduce_stage2(const float* __restrict__ stage1, float* __restrict__ out,
+                                                     uint32_t n_wgs, uint32_t n_frames, int postfx) {
+    const uint32_t o = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t n_out = 2 * n_frames;
+    if (o >= n_out) return;
+    const uint32_t per = (n_wgs + RED_SPLIT - 1) / RED_SPLIT;
+    const uint32_t used = (n_wgs + per - 1) / per;        // slices that saw at least one workgroup
+    float t = stage1[o];
+    for (uint32_t k = 1; k < used; ++k) t = t + stage1[(size_t)k * n_out + o];
+    out[o] = postfx_apply(t, postfx);
 }
 
 __global__ void postfx_kernel(float* __restrict__ buf, uint32_t n, int postfx) {

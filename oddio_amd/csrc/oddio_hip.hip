@@ -186,6 +186,7 @@ struct oddio_hip_scene {
     uint32_t* d_stopped[RING] = {nullptr, nullptr};
     float* d_partials = nullptr;
     float* d_out = nullptr;
+    float* d_stage1 = nullptr;
     MotionUpdate* d_motion = nullptr;
     SlotMove* d_moves = nullptr;
     // pinned staging
@@ -222,7 +223,7 @@ static int scene_free(oddio_hip_scene* s) {
     for (auto& h : s->handles) if (h.frames) { oddio_hip_frames_release(h.frames); h.frames = nullptr; }
     for (auto& p : s->pending_plays) (void)p;
     (void)hipFree(s->d_static); (void)hipFree(s->d_dyn); (void)hipFree(s->d_pend); (void)hipFree(s->d_ear);
-    (void)hipFree(s->d_partials); (void)hipFree(s->d_out); (void)hipFree(s->d_motion); (void)hipFree(s->d_moves);
+    (void)hipFree(s->d_partials); (void)hipFree(s->d_out); (void)hipFree(s->d_stage1); (void)hipFree(s->d_motion); (void)hipFree(s->d_moves);
     for (int r = 0; r < RING; ++r) {
         (void)hipFree(s->d_stopped[r]);
         if (s->h_stopped[r]) (void)hipHostFree(s->h_stopped[r]);
@@ -266,6 +267,7 @@ extern "C" int oddio_hip_scene_create(int device, uint32_t max_sources, uint32_t
     SC_TRY(hipMalloc(&s->d_ear, cap * 2 * sizeof(EarParams)));
     SC_TRY(hipMalloc(&s->d_partials, (size_t)s->tiles_max * wgs_max * 2 * TILE_FRAMES * sizeof(float)));
     SC_TRY(hipMalloc(&s->d_out, (size_t)s->tiles_max * 2 * TILE_FRAMES * sizeof(float)));
+    SC_TRY(hipMalloc(&s->d_stage1, (size_t)RED_SPLIT * s->tiles_max * 2 * TILE_FRAMES * sizeof(float)));
     SC_TRY(hipMalloc(&s->d_motion, cap * sizeof(MotionUpdate)));
     SC_TRY(hipMalloc(&s->d_moves, cap * sizeof(SlotMove)));
     SC_TRY(hipHostMalloc(&s->h_out, (size_t)2 * max_frames * sizeof(float), hipHostMallocDefault));
@@ -682,7 +684,9 @@ static int scene_sample_impl(oddio_hip_scene* s, float interval, float* host_out
     if (n_frames > 0) {
         const uint32_t n_out = 2u * (uint32_t)n_frames;
         if (n_wgs > 0) {
-            hipLaunchKernelGGL(reduce_partials, dim3(((uint32_t)n_frames + 31) / 32), dim3(1024), 0, s->stream, s->d_partials, out_dev, n_wgs,
+            hipLaunchKernelGGL(reduce_stage1, dim3(((uint32_t)n_frames + 31) / 32, RED_SPLIT), dim3(256), 0, s->stream, s->d_partials, s->d_stage1,
+                               n_wgs, (uint32_t)n_frames);
+            hipLaunchKernelGGL(reduce_stage2, dim3((n_out + 255) / 256), dim3(256), 0, s->stream, s->d_stage1, out_dev, n_wgs,
                                (uint32_t)n_frames, s->postfx);
         } else {
             hipLaunchKernelGGL(zero_kernel, dim3((n_out + 255) / 256), dim3(256), 0, s->stream, out_dev, n_out);   // spatial.rs:389-391
