@@ -112,6 +112,10 @@ def main():
     ap.add_argument("--sources", type=int, default=262144, help="sources per GPU (config 3: 262144; config 2: 4096)")
     ap.add_argument("--clip-len", type=int, default=65536)
     ap.add_argument("--seed", type=int, default=2024)
+    ap.add_argument("--mode", choices=["scenes", "sharded"], default="scenes",
+                    help="N>1: 'scenes' = one independent scene per GPU (configs[3] pattern, no collective); "
+                         "'sharded' = ONE scene of N*sources split into contiguous index shards with an RCCL sum-reduce "
+                         "of the 8 KiB stereo buffer per callback (configs[4] pattern)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=12.0)
     args = ap.parse_args()
@@ -147,6 +151,13 @@ def main():
 
     step_no = 0
 
+    sharded = args.mode == "sharded" and dist is not None
+    if sharded:
+        # one logical scene: this rank's scene IS its contiguous shard (seed + rank streams); the
+        # partial stereo buffers are summed over RCCL on the same stream as the kernels
+        from oddio_amd import sharding
+        scene.set_stream(torch.cuda.current_stream(device).cuda_stream)
+
     def one_step():
         nonlocal step_no
         if step_no and step_no % span == 0:
@@ -154,6 +165,8 @@ def main():
         if step_no and step_no % reset_every == 0:
             control.set_motion_batch(g["ids"], g["spec"]["position"], g["spec"]["velocity"], True)
         scene.sample_device(interval, out.data_ptr(), N_FRAMES)
+        if sharded:
+            sharding.reduce_stereo(out, dist, dst=0)    # 2048 floats, sum, to rank 0
         step_no += 1
 
     for _ in range(args.warmup):
@@ -211,9 +224,10 @@ def main():
             "config": {
                 "workload": (f"BASELINE configs[2]: SpatialScene, {S} moving FramesSignal sources (own {L}-sample clip each), "
                              f"Doppler + propagation delay, 48 kHz stereo, {N_FRAMES}-frame callbacks"
-                             + ("" if world == 1 else f"; {world} independent scenes, one per GPU (configs[3] pattern)")),
+                             + ("" if world == 1 else (f"; ONE scene of {world * S} sources in {world} index shards + RCCL reduce (configs[4] pattern)" if sharded
+                                                      else f"; {world} independent scenes, one per GPU (configs[3] pattern)"))),
                 "sources_per_gpu": S, "frames_per_callback": N_FRAMES, "sample_rate": RATE, "clip_len": L,
-                "parallelism": "scene-parallel" if world > 1 else "single-gpu",
+                "parallelism": ("single-gpu" if world == 1 else ("source-sharded scene + RCCL stereo-buffer reduce" if sharded else "scene-parallel")),
             },
             "max_realtime_sources": value / RATE,
             "realtime_factor_per_gpu": (N_FRAMES / RATE) / (elapsed / args.steps),

@@ -143,6 +143,9 @@ int oddio_hip_scene_sample_device(oddio_hip_scene* scene, float interval, float*
 int oddio_hip_postfx_device(int device, int postfx, float* dev_buf, size_t n_frames, void* hip_stream);
 /* Block until everything enqueued on the scene's stream has finished. */
 int oddio_hip_scene_synchronize(oddio_hip_scene* scene);
+/* Make the scene enqueue on a caller-owned hipStream_t (e.g. the stream a framework's collectives
+ * run on) instead of its private stream. */
+int oddio_hip_scene_set_stream(oddio_hip_scene* scene, void* hip_stream);
 /* The scene's hipStream_t (for callers that order their own work after sample_device). */
 int oddio_hip_scene_stream(oddio_hip_scene* scene, void** hip_stream);
 /* Seek::seek applied to every live source (src/signal.rs:48-51): t += seconds. */

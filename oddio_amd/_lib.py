@@ -81,6 +81,7 @@ def lib():
         "oddio_hip_postfx_device": (i32, [i32, i32, vp, sz, vp]),
         "oddio_hip_scene_synchronize": (i32, [vp]),
         "oddio_hip_scene_stream": (i32, [vp, vpp]),
+        "oddio_hip_scene_set_stream": (i32, [vp, vp]),
         "oddio_hip_scene_seek_all": (i32, [vp, f32]),
         "oddio_hip_scene_set_profiling": (i32, [vp, i32]),
         "oddio_hip_scene_last_kernel_ms": (i32, [vp, fp]),

@@ -185,6 +185,9 @@ class _SceneSignal(Signal):
         _lib.check(_lib.lib().oddio_hip_scene_stream(self._h, C.byref(p)))
         return p.value or 0
 
+    def set_stream(self, hip_stream: int):
+        _lib.check(_lib.lib().oddio_hip_scene_set_stream(self._h, C.c_void_p(hip_stream)))
+
     def seek_all(self, seconds):
         _lib.check(_lib.lib().oddio_hip_scene_seek_all(self._h, np.float32(seconds)))
 

@@ -177,6 +177,7 @@ constexpr int RING = 2;
 struct oddio_hip_scene {
     int device = 0;
     hipStream_t stream = nullptr;
+    bool owns_stream = true;
     uint32_t max_sources = 0, max_frames = 0, waves_cap = 0, tiles_max = 0;
     // device arrays
     SrcStatic* d_static = nullptr;
@@ -231,7 +232,7 @@ static int scene_free(oddio_hip_scene* s) {
     }
     if (s->h_out) (void)hipHostFree(s->h_out);
     for (auto& e : s->ev_prof) if (e) (void)hipEventDestroy(e);
-    if (s->stream) (void)hipStreamDestroy(s->stream);
+    if (s->stream && s->owns_stream) (void)hipStreamDestroy(s->stream);
     delete s;
     return 0;
 }
@@ -486,6 +487,15 @@ extern "C" int oddio_hip_scene_synchronize(oddio_hip_scene* s) {
     if (!s) return fail(ODDIO_HIP_EINVAL, "NULL scene");
     DeviceGuard g(s->device);
     HIP_TRY(hipStreamSynchronize(s->stream));
+    return 0;
+}
+extern "C" int oddio_hip_scene_set_stream(oddio_hip_scene* s, void* stream) {
+    if (!s) return fail(ODDIO_HIP_EINVAL, "NULL scene");
+    DeviceGuard g(s->device);
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    if (s->owns_stream && s->stream) (void)hipStreamDestroy(s->stream);
+    s->stream = (hipStream_t)stream;   // NULL selects the legacy default stream
+    s->owns_stream = false;
     return 0;
 }
 extern "C" int oddio_hip_scene_stream(oddio_hip_scene* s, void** stream) {

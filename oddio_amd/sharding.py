@@ -1,0 +1,95 @@
+"""Multi-GPU for the hot path: one process per GPU over torch.distributed (backend "nccl" == RCCL
+over xGMI on MI355X; "gloo" in the CPU tests).
+
+The path shards naturally: sources are independent until the final
+per-frame sum (src/spatial.rs:460), independent scenes share nothing.
+
+  * scene-parallel (BASELINE configs[3]): every rank owns whole scenes -> no communication at all;
+    nothing here is needed except `shard_range` to split a list of scenes.
+  * one huge scene (BASELINE configs[4]): contiguous source-index shards (keeps the reference's
+    reverse walk order inside a shard); every rank renders a partial 2*N-float stereo buffer; ONE
+    sum-reduce of that 8 KiB buffer per callback (latency bound, ring vs tree is irrelevant at
+    this size); the post-mix soft clip (Reinhard/Tanh wraps the *scene*, src/reinhard.rs:7-10)
+    runs after the reduce.  The summation order differs from the single sequential f32 sum of the
+    reference, so the result is within the tolerance policy of SURVEY.md H2, not bit-identical.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+
+def shard_range(n_items: int, world_size: int, rank: int) -> tuple[int, int]:
+    """Contiguous, balanced [lo, hi) slice of `n_items` for `rank` (first n % world ranks get one more)."""
+    if not (0 <= rank < world_size):
+        raise ValueError("rank out of range")
+    base, extra = divmod(n_items, world_size)
+    lo = rank * base + min(rank, extra)
+    hi = lo + base + (1 if rank < extra else 0)
+    return lo, hi
+
+
+def reduce_stereo(partial, dist=None, group=None, dst: int | None = 0):
+    """Sum the ranks' partial stereo buffers (torch tensor, [n_frames, 2] f32, on the backend's
+    device).  dst=None -> all_reduce (every rank gets the mix); otherwise reduce to `dst`."""
+    if dist is None:
+        import torch.distributed as dist
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return partial
+    if dst is None:
+        dist.all_reduce(partial, op=dist.ReduceOp.SUM, group=group)
+    else:
+        dist.reduce(partial, dst=dst, op=dist.ReduceOp.SUM, group=group)
+    return partial
+
+
+def apply_postfx_numpy(x: np.ndarray, postfx: int) -> np.ndarray:
+    """Host-side Reinhard (exact IEEE ops, src/reinhard.rs:32) for CPU-side checks of a reduced buffer."""
+    if postfx == 1:
+        x = x.astype(np.float32)
+        return (x / (np.float32(1.0) + np.abs(x))).astype(np.float32)
+    if postfx == 0:
+        return x
+    raise ValueError("only Reinhard has an exact host form here")
+
+
+class ShardedSpatialScene:
+    """One logical SpatialScene whose sources are split into contiguous index shards, one per rank.
+
+    `play_frames_batch` is called with the FULL source list on every rank; each rank keeps only
+    its shard.  `sample_device` renders the shard on the HIP path into a torch tensor, reduces it
+    over RCCL on the same stream, then applies the scene-level post filter."""
+
+    def __init__(self, device: int, max_sources_total: int, max_frames: int, postfx: int = 0, dst: int | None = 0):
+        import torch
+        import torch.distributed as dist
+
+        import oddio_amd as oa
+        self.torch, self.dist = torch, dist
+        self.rank = dist.get_rank() if dist.is_initialized() else 0
+        self.world = dist.get_world_size() if dist.is_initialized() else 1
+        self.device = device
+        self.postfx = postfx
+        self.dst = dst
+        lo, hi = shard_range(max_sources_total, self.world, self.rank)
+        self.control, self.scene = oa.SpatialScene(device=device, max_sources=max(hi - lo, 1), max_frames=max_frames)
+        # collectives and kernels on one stream: the reduce is ordered after the mix without host syncs
+        self.scene.set_stream(torch.cuda.current_stream(device).cuda_stream)
+        self.out = torch.zeros((max_frames, 2), dtype=torch.float32, device=torch.device("cuda", device))
+
+    def play_frames_batch(self, frames_list, start_seconds, positions, velocities, radii):
+        lo, hi = shard_range(len(frames_list), self.world, self.rank)
+        self.shard = (lo, hi)
+        if hi > lo:
+            return self.control.play_frames_batch(frames_list[lo:hi], np.asarray(start_seconds)[lo:hi], np.asarray(positions)[lo:hi],
+                                                  np.asarray(velocities)[lo:hi], np.asarray(radii)[lo:hi])
+        return []
+
+    def sample_device(self, interval, n_frames: int):
+        from . import _lib
+        out = self.out[:n_frames]
+        self.scene.sample_device(interval, out.data_ptr(), n_frames)
+        reduce_stereo(out, self.dist, dst=self.dst)
+        if self.postfx and (self.dst is None or self.rank == self.dst):
+            stream = self.torch.cuda.current_stream(self.device).cuda_stream
+            _lib.check(_lib.lib().oddio_hip_postfx_device(self.device, self.postfx, out.data_ptr(), n_frames, stream))
+        return out
