@@ -49,6 +49,13 @@ def lib():
         raise ImportError(
             f"{SO_PATH} is missing: the HIP extension has not been built "
             "(run `python -c 'import __graft_entry__ as g; g.build()'`). There is no CPU fallback.")
+    import sys
+    if "torch" in sys.modules:
+        # when PyTorch shares the process, let it bring up its HIP runtime first so that both bind
+        # the same libamdhip64 (the reverse order leaves torch without a device)
+        torch = sys.modules["torch"]
+        if torch.cuda.is_available():
+            torch.cuda.init()
     L = C.CDLL(SO_PATH)
     vp, f32, f64, u32, sz, i32 = C.c_void_p, C.c_float, C.c_double, C.c_uint32, C.c_size_t, C.c_int
     fp, u32p, vpp = C.POINTER(C.c_float), C.POINTER(C.c_uint32), C.POINTER(C.c_void_p)

@@ -246,7 +246,10 @@ constexpr int TILE_FRAMES = 512;             // frames per (wave, tile) pass
 constexpr int TILE_CHUNKS = TILE_FRAMES / 256;
 constexpr int WIN_CAP = 768;                 // samples staged per source and tile (ds <= ~1.43)
 constexpr int WIN_VECS = WIN_CAP / 256;      // float4 loads per lane covering WIN_CAP
-constexpr float PAD_EPS = 0.004f;            // |ds - 1| below this: lanes' runs sit 16 samples apart -> padded layout
+#ifndef ODDIO_PAD_EPS
+#define ODDIO_PAD_EPS 0.004f
+#endif
+constexpr float PAD_EPS = ODDIO_PAD_EPS;           // |ds - 1| below this: lanes' runs sit 16 samples apart -> padded layout
 
 enum : int { PATH_SKIP = 0, PATH_LDS = 1, PATH_GENERIC = 2, PATH_SINE = 3, PATH_CONST = 4 };
 

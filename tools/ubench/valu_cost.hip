@@ -3,7 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <vector>
-#define N_ITER 256
+#define N_ITER 20000
 #define REP 32
 template <int OP>
 __global__ void k(float* out, long long* cyc, float a, float b) {
@@ -56,8 +56,13 @@ template <int OP> void run(const char* name, int per_iter_instrs, int threads) {
     hipMalloc(&out, 4096 * sizeof(float)); hipMalloc(&cyc, 8);
     k<OP><<<1, threads>>>(out, cyc, 1.0f, 1.0001f);
     hipDeviceSynchronize();
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    hipEventRecord(e0);
     k<OP><<<1, threads>>>(out, cyc, 1.0f, 1.0001f);
+    hipEventRecord(e1); hipEventSynchronize(e1);
+    float ms = 0; hipEventElapsedTime(&ms, e0, e1);
     long long c; hipMemcpy(&c, cyc, 8, hipMemcpyDeviceToHost);
+    if (OP == 1 && threads == 1024) printf("   [calibration] %lld ticks in %.4f ms (incl. launch) -> >= %.1f MHz tick\n", c, ms, c / (ms * 1e3));
     double per = (double)c / (N_ITER * REP * per_iter_instrs);
     printf("%-44s threads=%4d  cycles/instr(per wave)=%.2f  -> per-instr SIMD occupancy=%.2f (with %d waves/SIMD)\n", name, threads, per, per / (threads / 256.0 > 1 ? threads / 256.0 : 1), threads / 256 > 1 ? threads / 256 : 1);
     hipFree(out); hipFree(cyc);
