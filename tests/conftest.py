@@ -8,12 +8,22 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 
-def pytest_configure(config):
-    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
-
-
 def _gpu_present() -> bool:
     return os.path.exists("/dev/kfd")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    if _gpu_present():
+        # Some GPU tests use PyTorch as an HBM allocator next to libodd_hip.so.  PyTorch must bring
+        # up its HIP runtime BEFORE our library is loaded (otherwise torch finds no device), so do
+        # it once, up front.
+        try:
+            import torch
+            if torch.cuda.is_available():
+                torch.cuda.init()
+        except Exception:
+            pass
 
 
 def pytest_collection_modifyitems(config, items):
