@@ -324,7 +324,11 @@ __device__ __forceinline__ void window_load(u32x4 (&pre)[WIN_VECS], const float*
 __device__ __forceinline__ void window_store_plain(unsigned char* smem, const u32x4 (&pre)[WIN_VECS], int nvec, int lane) {
 #pragma unroll
     for (int k = 0; k < WIN_VECS; ++k) {
+#if defined(ODDIO_EXP) && (ODDIO_EXP == 4 || ODDIO_EXP == 6)
+        if (lane + 64 * k < nvec && pre[k].x == 0x12345u) *reinterpret_cast<u32x4*>(smem + LDS_WIN + 16 * lane + 1024 * k) = pre[k];   // EXPERIMENT: (almost) no LDS stores
+#else
         if (lane + 64 * k < nvec) *reinterpret_cast<u32x4*>(smem + LDS_WIN + 16 * lane + 1024 * k) = pre[k];
+#endif
     }
 }
 // Padded layout: slot(s) = s + s/16; the pad slot repeats the following sample, so that a pair
@@ -387,7 +391,7 @@ __device__ __forceinline__ void mix_source_lds(const unsigned char* smem, int la
 #if defined(ODDIO_EXP) && ODDIO_EXP == 1
             w = (w & 1) + 2 * (b + 16 * (la & 3)) + 128 * k;    // EXPERIMENT: conflict-free addresses (wrong data)
 #endif
-#if defined(ODDIO_EXP) && ODDIO_EXP == 2
+#if defined(ODDIO_EXP) && (ODDIO_EXP == 2 || ODDIO_EXP == 6)
             a[k] = x; bb[k] = fr[k];                            // EXPERIMENT: no LDS reads (wrong data)
 #else
             a[k] = win[w];                                                // one ds_read2_b32
@@ -536,6 +540,9 @@ __global__ __launch_bounds__(64 * MIX_WG_WAVES, MIX_WAVES_PER_SIMD) void spatial
         {
             float* ck = &ckpt[lane * 16];
             const int sw = lane & 15;
+#if defined(ODDIO_EXP) && ODDIO_EXP == 5
+            if (ds == 123.0f)   // EXPERIMENT: no cursor scan (wrong data)
+#endif
 #pragma unroll 1
             for (int b = 0; b < 15; ++b) {
                 ck[b ^ sw] = x;
