@@ -103,6 +103,32 @@ int oddio_hip_scene_play_frames_batch(oddio_hip_scene* scene, size_t n,
                                       const float* positions, const float* velocities,
                                       const float* radii, uint32_t* ids);
 
+/* ---- buffered sources: SpatialSceneControl::play_buffered (src/spatial.rs:314-340) ----
+ * For signals that are not `Seek`.  The inner signal is a leaf (ODDIO_HIP_LEAF_*: FramesSignal /
+ * Sine / Constant, arguments as in the play_* calls above) wrapped in up to 4 filters, innermost
+ * first: FixedGain(db) (src/gain.rs:9-51), Gain (src/gain.rs:58-127, param = initial amplitude
+ * ratio, normally 1) and Speed (src/speed.rs, param = initial factor, normally 1).  The scene owns a
+ * `Ring` (src/ring.rs) of ceil((max_distance / 343 + buffer_duration) * rate) + 1 samples per source
+ * in HBM, allocated here (control thread) and sampled at `rate`. */
+enum { ODDIO_HIP_LEAF_FRAMES = 0, ODDIO_HIP_LEAF_SINE = 1, ODDIO_HIP_LEAF_CONSTANT = 2 };
+enum { ODDIO_HIP_FILTER_FIXED_GAIN = 1, ODDIO_HIP_FILTER_GAIN = 2, ODDIO_HIP_FILTER_SPEED = 3 };
+typedef struct oddio_hip_filter { int kind; float param; } oddio_hip_filter;
+int oddio_hip_scene_reserve_buffered(oddio_hip_scene* scene, uint32_t max_buffered);
+int oddio_hip_scene_play_buffered(oddio_hip_scene* scene, int leaf_kind, oddio_hip_frames* frames,
+                                  double start_seconds, float phase, float frequency_hz_or_value,
+                                  const oddio_hip_filter* filters, int n_filters,
+                                  const float position[3], const float velocity[3], float radius,
+                                  float max_distance, uint32_t rate, float buffer_duration,
+                                  uint32_t* source_id);
+/* GainControl::set_amplitude_ratio / set_gain (src/gain.rs:141-160), SpeedControl::set_speed
+ * (src/speed.rs:52-54) of filter `filter_index` (position in the `filters` array) of a buffered
+ * source; like the reference's relaxed atomics they take effect at the next sample call. */
+int oddio_hip_source_set_gain(oddio_hip_scene* scene, uint32_t source_id, int filter_index, float amplitude_ratio);
+int oddio_hip_source_set_gain_db(oddio_hip_scene* scene, uint32_t source_id, int filter_index, float db);
+int oddio_hip_source_set_speed(oddio_hip_scene* scene, uint32_t source_id, int filter_index, float factor);
+/* `scene.recv_buffered.len()` after the last sample call */
+int oddio_hip_scene_len_buffered(oddio_hip_scene* scene, size_t* len);
+
 /* Spatial::set_motion (src/spatial.rs:137-149) */
 int oddio_hip_source_set_motion(oddio_hip_scene* scene, uint32_t source_id, const float position[3],
                                 const float velocity[3], int discontinuity);

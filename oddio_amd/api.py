@@ -101,9 +101,113 @@ class Constant(Signal):
 
 class FixedGain(Signal):
     def __init__(self, inner: Signal, db: float):
-        if not isinstance(inner, (FramesSignal, Sine)):
-            raise TypeError("FixedGain is supported around FramesSignal / Sine")
         self.inner, self.db = inner, np.float32(db)
+        self.seekable = inner.seekable
+
+
+class GainControl:
+    """src/gain.rs:129-161.  Bound to its source once the signal has been played."""
+
+    def __init__(self):
+        self._target = None      # (scene or None, source id, filter index)
+        self._ratio = np.float32(1.0)
+
+    def _bind(self, scene, sid, index):
+        self._target = (scene, sid, index)
+
+    def set_amplitude_ratio(self, factor):
+        self._ratio = np.float32(factor)
+        if self._target is not None:
+            scene, sid, index = self._target
+            _lib.check(_lib.lib().oddio_hip_source_set_gain(scene._h, sid, index, np.float32(factor)))
+
+    def set_gain(self, db):
+        self.set_amplitude_ratio(np.float32(_powf10(db)))
+
+    def amplitude_ratio(self):
+        return float(self._ratio)
+
+
+class SpeedControl:
+    """src/speed.rs:42-55"""
+
+    def __init__(self):
+        self._target = None
+        self._speed = np.float32(1.0)
+
+    def _bind(self, scene, sid, index):
+        self._target = (scene, sid, index)
+
+    def set_speed(self, factor):
+        self._speed = np.float32(factor)
+        if self._target is not None:
+            scene, sid, index = self._target
+            _lib.check(_lib.lib().oddio_hip_source_set_speed(scene._h, sid, index, np.float32(factor)))
+
+    def speed(self):
+        return float(self._speed)
+
+
+def _powf10(db):
+    """10.0f32.powf(db / 20.0) through libm's powf, as Rust's std does (src/gain.rs:143)."""
+    import ctypes.util
+    libm = C.CDLL(ctypes.util.find_library("m") or "libm.so.6")
+    libm.powf.restype = C.c_float
+    libm.powf.argtypes = [C.c_float, C.c_float]
+    return libm.powf(10.0, float(np.float32(db) / np.float32(20.0)))
+
+
+class Gain(Signal):
+    """Gain::new(signal) -> (GainControl, Gain)  (src/gain.rs:66-74).  Not `Seek`: play_buffered only."""
+    seekable = False
+
+    def __init__(self, inner: Signal):
+        self.inner = inner
+        self.control = GainControl()
+
+    @classmethod
+    def new(cls, inner):
+        g = cls(inner)
+        return g.control, g
+
+
+class Speed(Signal):
+    """Speed::new(signal) -> (SpeedControl, Speed)  (src/speed.rs:16-24).  Not `Seek`: play_buffered only."""
+    seekable = False
+
+    def __init__(self, inner: Signal):
+        self.inner = inner
+        self.control = SpeedControl()
+
+    @classmethod
+    def new(cls, inner):
+        sp = cls(inner)
+        return sp.control, sp
+
+
+FILTER_FIXED_GAIN, FILTER_GAIN, FILTER_SPEED = 1, 2, 3
+
+
+class _Filter(C.Structure):
+    _fields_ = [("kind", C.c_int), ("param", C.c_float)]
+
+
+def _unwrap_chain(signal):
+    """-> (leaf, [(kind, param, control or None)] innermost first)"""
+    chain = []
+    while isinstance(signal, (FixedGain, Gain, Speed)):
+        if isinstance(signal, FixedGain):
+            chain.append((FILTER_FIXED_GAIN, float(signal.db), None))
+        elif isinstance(signal, Gain):
+            chain.append((FILTER_GAIN, float(signal.control._ratio), signal.control))
+        else:
+            chain.append((FILTER_SPEED, float(signal.control._speed), signal.control))
+        signal = signal.inner
+    if not isinstance(signal, (FramesSignal, Sine, Constant)):
+        raise TypeError(f"{type(signal).__name__} is not implemented on the device path")
+    if len(chain) > 4:
+        raise TypeError("at most 4 filters around a buffered source")
+    return signal, chain[::-1]
 
 
 class MonoToStereo(Signal):
@@ -121,6 +225,9 @@ def _unwrap(signal):
     if isinstance(signal, FixedGain):
         db = float(signal.db)
         signal = signal.inner
+    if isinstance(signal, (Gain, Speed)) or (isinstance(signal, FixedGain)):
+        raise TypeError("Gain / Speed are not Seek (src/gain.rs:53-57, src/speed.rs): use play_buffered; "
+                        "nested FixedGain needs play_buffered too")
     if not isinstance(signal, (FramesSignal, Sine, Constant)):
         raise TypeError(f"{type(signal).__name__} is not implemented on the device path "
                         "(supported: FramesSignal, Sine, Constant, FixedGain around them)")
@@ -220,6 +327,11 @@ class _SceneSignal(Signal):
         _lib.check(_lib.lib().oddio_hip_scene_len(self._h, C.byref(n)))
         return n.value
 
+    def len_buffered(self):
+        n = C.c_size_t()
+        _lib.check(_lib.lib().oddio_hip_scene_len_buffered(self._h, C.byref(n)))
+        return n.value
+
     def close(self):
         if self._h:
             _lib.lib().oddio_hip_scene_destroy(self._h)
@@ -252,6 +364,32 @@ class SpatialSceneControl:
             _lib.check(L.oddio_hip_scene_play_sine(s._h, leaf.phase, leaf.frequency_hz, db, _fp(pos), _fp(vel), np.float32(options.radius), C.byref(sid)))
         else:
             _lib.check(L.oddio_hip_scene_play_constant(s._h, leaf.value, _fp(pos), _fp(vel), np.float32(options.radius), C.byref(sid)))
+        return Spatial(s, sid.value)
+
+    def play_buffered(self, signal: Signal, options: SpatialOptions, max_distance: float, rate: int, buffer_duration: float) -> Spatial:
+        """SpatialSceneControl::play_buffered (src/spatial.rs:314-340)."""
+        if signal.channels != 1:
+            raise TypeError("signals in a spatial scene must be single-channel")
+        leaf, chain = _unwrap_chain(signal)
+        L, s = _lib.lib(), self._scene
+        sid = C.c_uint32()
+        pos, vel = _vec3(options.position), _vec3(options.velocity)
+        filt = (_Filter * max(len(chain), 1))()
+        for i, (kind, param, _) in enumerate(chain):
+            filt[i].kind, filt[i].param = kind, param
+        if isinstance(leaf, FramesSignal):
+            s._keep.append(leaf.frames)
+            args = (0, leaf.frames._h, leaf.start_seconds, 0.0, 0.0)
+        elif isinstance(leaf, Sine):
+            args = (1, None, 0.0, float(leaf.phase), float(leaf.frequency_hz))
+        else:
+            args = (2, None, 0.0, 0.0, float(leaf.value))
+        _lib.check(L.oddio_hip_scene_play_buffered(s._h, args[0], args[1], args[2], args[3], args[4], C.cast(filt, C.c_void_p), len(chain),
+                                                   _fp(pos), _fp(vel), np.float32(options.radius), np.float32(max_distance), int(rate),
+                                                   np.float32(buffer_duration), C.byref(sid)))
+        for i, (_, _, control) in enumerate(chain):
+            if control is not None:
+                control._bind(s, sid.value, i)
         return Spatial(s, sid.value)
 
     def play_frames_batch(self, frames_list, start_seconds, positions, velocities, radii, fixed_gain_db=None):

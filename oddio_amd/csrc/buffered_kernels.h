@@ -1,0 +1,279 @@
+// buffered_kernels.h -- the buffered variant of the spatial path:
+// `SpatialSceneControl::play_buffered` (src/spatial.rs:314-340), `Ring` (src/ring.rs:4-80) and the
+// filters that are not `Seek` and therefore only enter a scene this way: `Gain` (+ `Smoothed`,
+// src/gain.rs:58-127, src/smooth.rs) and `Speed` (src/speed.rs:26-40), besides `FixedGain`.
+//
+// Correctness first, not tuned: ONE THREAD PER BUFFERED SOURCE replays the reference's sequential
+// loops (ring write through the filter chain, then per ear / per 256-frame chunk ring reads with
+// the f32 cursor and its wrap rule) and writes the source's contribution to its own [N][2] slab;
+// `buffered_reduce` then adds the slabs in the reference's reverse-slot order, so the result is
+// bit-identical to the reference's `o[ear] += s * gain` sequence for FramesSignal/Constant leaves.
+// Thousands of buffered sources still run concurrently (one per lane); the latency of one source
+// (~50 k dependent instructions) is the cost.
+#pragma once
+#include "kernels.h"
+
+namespace oddio_hip {
+
+enum : uint32_t { WRAP_FIXED_GAIN = 1, WRAP_GAIN = 2, WRAP_SPEED = 3 };
+constexpr int MAX_WRAP = 4;
+
+struct alignas(16) BufStatic {
+    const float* clip;      // leaf FramesSignal
+    uint32_t clip_len;
+    uint32_t clip_rate;
+    float freq_or_value;    // leaf Sine (rad/s) / Constant
+    uint32_t kind;          // KIND_*
+    float* ring;            // Ring::buffer (ring.rs:5), device memory owned by the scene
+    uint32_t ring_len;
+    uint32_t rate;          // SpatialSignalBuffered::rate (spatial.rs:19)
+    float max_delay;        // :20
+    float radius;
+    uint32_t n_wrap;        // filters, innermost first
+    uint32_t wrap_kind[MAX_WRAP];
+    float wrap_param[MAX_WRAP];   // FixedGain: linear gain
+    uint32_t pad[3];
+};
+static_assert(sizeof(BufStatic) == 96, "BufStatic layout");
+
+struct alignas(16) BufDyn {
+    SrcDyn common;          // clock / phase, Motion, State, finished_for, flags, id
+    float ring_write;       // Ring::write (ring.rs:6)
+    uint32_t pad0[3];
+    float shared[MAX_WRAP]; // Gain: atomically shared target (gain.rs:59) / Speed: factor (speed.rs:9)
+    float sm_prev[MAX_WRAP];     // Smoothed<f32> of each Gain (smooth.rs:26-30)
+    float sm_next[MAX_WRAP];
+    float sm_progress[MAX_WRAP];
+};
+static_assert(sizeof(BufDyn) == 64 + 16 + 64, "BufDyn layout");
+
+struct ControlUpdate { uint32_t slot; uint32_t index; float value; uint32_t pad; };
+
+__device__ __forceinline__ size_t f32_as_usize(float x) {   // Rust `f32 as usize`
+    if (!(x > 0.0f)) return 0;
+    if (x >= 1.8446744e19f) return ~(size_t)0;
+    return (size_t)x;
+}
+__device__ __forceinline__ float f32_rem_euclid(float a, float b) {   // core f32::rem_euclid
+    const float r = fmodf(a, b);
+    return r < 0.0f ? r + fabsf(b) : r;
+}
+
+// ---- the inner signal: leaf + filter chain, Signal::sample(interval, out[0..n]) -----------------
+__device__ void leaf_sample(const BufStatic& s, SrcDyn& d, float interval, float* out, uint32_t n) {
+    if (s.kind == KIND_FRAMES) {   // frames.rs:176-201
+        const double s0 = d.t * (double)s.clip_rate;
+        const float ds = interval * (float)s.clip_rate;
+        const long long base = f64_as_isize(s0);
+        if (fabsf(ds - 1.0f) <= FLT_EPSILON) {
+            const float fract = (float)(s0 - (double)base);
+            for (uint32_t i = 0; i < n; ++i) {
+                const float a = clip_at(s.clip, s.clip_len, base + (long long)i), b = clip_at(s.clip, s.clip_len, base + (long long)i + 1);
+                out[i] = a + fract * (b - a);
+            }
+        } else {
+            float offset = (float)(s0 - (double)base);
+            for (uint32_t i = 0; i < n; ++i) {
+                const long long tr = (long long)offset;
+                const float fract = offset - (float)tr;
+                const float a = clip_at(s.clip, s.clip_len, base + tr), b = clip_at(s.clip, s.clip_len, base + tr + 1);
+                out[i] = a + fract * (b - a);
+                offset = offset + ds;
+            }
+        }
+        d.t = d.t + (double)interval * (double)n;
+    } else if (s.kind == KIND_SINE) {   // sine.rs:34-40
+        for (uint32_t i = 0; i < n; ++i) {
+            const float t = interval * (float)i;
+            out[i] = sinf(t * s.freq_or_value + d.phase);
+        }
+        d.phase = fmodf(d.phase + (interval * (float)n) * s.freq_or_value, ODDIO_TAU);
+    } else {   // constant.rs:16-18
+        for (uint32_t i = 0; i < n; ++i) out[i] = s.freq_or_value;
+    }
+}
+
+__device__ void inner_sample(const BufStatic& s, BufDyn& d, float interval, float* out, uint32_t n) {
+    // interval as each filter level sees it (outermost first); Speed rescales it on the way in
+    float level_interval[MAX_WRAP];
+    float cur = interval;
+    for (int w = (int)s.n_wrap - 1; w >= 0; --w) {
+        level_interval[w] = cur;
+        if (s.wrap_kind[w] == WRAP_SPEED) cur = cur * d.shared[w];   // speed.rs:32-35
+    }
+    leaf_sample(s, d.common, cur, out, n);
+    for (uint32_t w = 0; w < s.n_wrap; ++w) {
+        if (s.wrap_kind[w] == WRAP_FIXED_GAIN) {                      // gain.rs:32-37
+            const float g = s.wrap_param[w];
+            for (uint32_t i = 0; i < n; ++i) out[i] = out[i] * g;
+        } else if (s.wrap_kind[w] == WRAP_GAIN) {                     // gain.rs:103-122
+            const float shared = d.shared[w];
+            if (d.sm_next[w] != shared) {                             // Smoothed::set, smooth.rs:57-64
+                d.sm_prev[w] = d.sm_prev[w] + d.sm_progress[w] * (d.sm_next[w] - d.sm_prev[w]);
+                d.sm_next[w] = shared;
+                d.sm_progress[w] = 0.0f;
+            }
+            if (d.sm_progress[w] == 1.0f) {
+                const float g = d.sm_prev[w] + d.sm_progress[w] * (d.sm_next[w] - d.sm_prev[w]);
+                if (g != 1.0f) for (uint32_t i = 0; i < n; ++i) out[i] = out[i] * g;
+            } else {
+                const float step = level_interval[w] / 0.1f;          // SMOOTHING_PERIOD, gain.rs:163
+                for (uint32_t i = 0; i < n; ++i) {
+                    const float g = d.sm_prev[w] + d.sm_progress[w] * (d.sm_next[w] - d.sm_prev[w]);
+                    out[i] = out[i] * g;
+                    d.sm_progress[w] = fminf(d.sm_progress[w] + step, 1.0f);   // Smoothed::advance, smooth.rs:47-49
+                }
+            }
+        }
+    }
+}
+
+// One thread per buffered slot: walk_set (spatial.rs:191-265) + the buffered mix closure
+// (spatial.rs:402-431).  contrib is [slot][n_frames][2]; skip[slot] != 0 means "not mixed".
+__global__ __launch_bounds__(64) void buffered_sources(SceneParams P, uint32_t n_buffered, const BufStatic* __restrict__ st,
+                                                       BufDyn* __restrict__ dyn, SrcPending* __restrict__ pend,
+                                                       float* __restrict__ contrib, uint32_t* __restrict__ skip,
+                                                       uint32_t* __restrict__ stopped_hdr, uint32_t stopped_cap) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_buffered) return;
+    BufDyn d = dyn[i];
+    const BufStatic s = st[i];
+    SrcDyn& c = d.common;
+    if (c.flags & DYN_STOPPED) { skip[i] = 1; return; }
+    const float elapsed = P.elapsed;
+    const uint32_t n = P.n_frames;
+    const float nf = (float)n;
+    V3 tpos = {c.tgt_pos[0], c.tgt_pos[1], c.tgt_pos[2]};
+    V3 tvel = {c.tgt_vel[0], c.tgt_vel[1], c.tgt_vel[2]};
+    V3 ppos = {c.prev_pos[0], c.prev_pos[1], c.prev_pos[2]};
+    const SrcPending pm = pend[i];
+    if (pm.flags & PEND_FRESH) {   // spatial.rs:216-226
+        V3 npos = {pm.pos[0], pm.pos[1], pm.pos[2]};
+        V3 nvel = {pm.vel[0], pm.vel[1], pm.vel[2]};
+        ppos = (pm.flags & PEND_DISCONTINUITY) ? npos : smoothed_position(ppos, c.state_dt, 0.0f, tpos, tvel);
+        tpos = npos; tvel = nvel;
+        c.state_dt = 0.0f;
+        pend[i].flags = 0;
+    }
+    const Quat prev_rot = {P.prev_rot[0], P.prev_rot[1], P.prev_rot[2], P.prev_rot[3]};
+    const Quat rot = {P.rot[0], P.rot[1], P.rot[2], P.rot[3]};
+    const V3 p0 = quat_rotate(prev_rot, smoothed_position(ppos, c.state_dt, 0.0f, tpos, tvel));
+    const V3 p1 = quat_rotate(rot, smoothed_position(ppos, c.state_dt, elapsed, tpos, tvel));
+    c.state_dt = c.state_dt + elapsed;
+    c.tgt_pos[0] = tpos.x; c.tgt_pos[1] = tpos.y; c.tgt_pos[2] = tpos.z;
+    c.tgt_vel[0] = tvel.x; c.tgt_vel[1] = tvel.y; c.tgt_vel[2] = tvel.z;
+    c.prev_pos[0] = ppos.x; c.prev_pos[1] = ppos.y; c.prev_pos[2] = ppos.z;
+    // spatial.rs:243-261
+    const float distance = v3_norm(p0);
+    if (c.flags & DYN_HAS_FINISHED_FOR) {
+        if (c.finished_for > distance / ODDIO_SPEED_OF_SOUND) c.flags |= DYN_STOPPED;
+        else c.finished_for = c.finished_for + elapsed;
+    } else {
+        bool fin = false;
+        if (s.kind == KIND_FRAMES) fin = c.t >= (double)(s.clip_len - 1u) / (double)s.clip_rate;   // is_finished passes through the filters
+        if (fin) { c.flags |= DYN_HAS_FINISHED_FOR; c.finished_for = elapsed; }
+    }
+    if (c.flags & DYN_STOPPED) {
+        const uint32_t k = atomicAdd(&stopped_hdr[0], 1u);
+        if (k < stopped_cap) stopped_hdr[1 + k] = c.id;
+        skip[i] = 1;
+        dyn[i] = d;
+        return;
+    }
+    skip[i] = 0;
+    float* ring = s.ring;
+    const uint32_t len = s.ring_len;
+    {   // Ring::write (ring.rs:18-41): extend the delay queue with new data
+        const float end = fmodf(d.ring_write + elapsed * (float)s.rate, (float)len);
+        const size_t start_idx = f32_as_usize(ceilf(d.ring_write));
+        const size_t end_idx = f32_as_usize(ceilf(end));
+        const float interval = 1.0f / (float)s.rate;
+        if (end_idx > start_idx) {
+            inner_sample(s, d, interval, ring + start_idx, (uint32_t)(end_idx - start_idx));
+        } else {
+            inner_sample(s, d, interval, ring + start_idx, (uint32_t)(len - start_idx));
+            inner_sample(s, d, interval, ring, (uint32_t)end_idx);
+        }
+        d.ring_write = end;
+    }
+    __threadfence_block();
+    float* my = contrib + (size_t)i * 2 * n;
+    float buf[32];
+    for (int e = 0; e < 2; ++e) {   // spatial.rs:409-430
+        float off0, g0, off1, g1;
+        ear_state(p0, e, s.radius, off0, g0);
+        ear_state(p1, e, s.radius, off1, g1);
+        const float prev_offset = fmaxf(off0 - elapsed, -s.max_delay);
+        const float next_offset = fmaxf(off1, -s.max_delay);
+        const float dt = (next_offset - prev_offset) / nf;
+        const float d_gain = (g1 - g0) / nf;
+        uint32_t idx = 0;
+        for (uint32_t done = 0; done < n; done += 256u) {
+            const uint32_t clen = (n - done) < 256u ? (n - done) : 256u;
+            const float t = prev_offset + (float)idx * dt;
+            // the 256-frame chunk restarts the cursor (ring.rs:57); inside it, consume in pieces of 32
+            float offset = f32_rem_euclid(d.ring_write + t * (float)s.rate, (float)len);
+            const float ds = dt * (float)s.rate;
+            for (uint32_t k0 = 0; k0 < clen; k0 += 32u) {
+                const uint32_t m = (clen - k0) < 32u ? (clen - k0) : 32u;
+                for (uint32_t k = 0; k < m; ++k) {   // ring.rs:59-78
+                    size_t x = (size_t)offset;
+                    const float fract = offset - (float)x;
+                    float a, b;
+                    if (x < (size_t)len - 1) { a = ring[x]; b = ring[x + 1]; }
+                    else if (x < (size_t)len) { a = ring[x]; b = ring[0]; }
+                    else {
+                        x = x % len;
+                        offset = (float)x + fract;
+                        if (x < (size_t)len - 1) { a = ring[x]; b = ring[x + 1]; }
+                        else { a = ring[x]; b = ring[0]; }
+                    }
+                    buf[k] = a + fract * (b - a);
+                    offset = offset + ds;
+                }
+                for (uint32_t k = 0; k < m; ++k) {
+                    const float gain = g0 + (float)idx * d_gain;   // spatial.rs:426
+                    my[2 * (done + k0 + k) + e] = buf[k] * gain;
+                    idx += 1;
+                }
+            }
+        }
+    }
+    dyn[i] = d;
+}
+
+// out_b[o] = ((0 + contrib[last]) + ... + contrib[0]) : the reference's reverse walk (spatial.rs:204)
+__global__ void buffered_reduce(const float* __restrict__ contrib, const uint32_t* __restrict__ skip, uint32_t n_buffered,
+                                uint32_t n_frames, float* __restrict__ out_b) {
+    const uint32_t o = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t n_out = 2 * n_frames;
+    if (o >= n_out) return;
+    float s = 0.0f;
+    for (uint32_t i = n_buffered; i-- > 0;) {
+        if (skip[i]) continue;
+        s = s + contrib[(size_t)i * n_out + o];
+    }
+    out_b[o] = s;
+}
+
+// one thread, send order: a later value for the same (slot, filter) wins, like the relaxed atomic stores
+__global__ void apply_control_updates_serial(const ControlUpdate* __restrict__ up, uint32_t n, BufDyn* __restrict__ dyn) {
+    for (uint32_t i = 0; i < n; ++i) dyn[up[i].slot].shared[up[i].index & (MAX_WRAP - 1)] = up[i].value;
+}
+
+struct BufMove { uint32_t dst, src; };
+__global__ void apply_buf_moves(const BufMove* __restrict__ mv, uint32_t n, BufStatic* st, BufDyn* dyn, SrcPending* pend) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    st[mv[i].dst] = st[mv[i].src];
+    dyn[mv[i].dst] = dyn[mv[i].src];
+    pend[mv[i].dst] = pend[mv[i].src];
+}
+
+// out[o] = postfx(in[o])  (scenes that hold only buffered sources)
+__global__ void copy_postfx_kernel(const float* __restrict__ in, float* __restrict__ out, uint32_t n, int postfx) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = postfx_apply(in[i], postfx);
+}
+
+}  // namespace oddio_hip

@@ -474,7 +474,7 @@ __device__ __noinline__ void mix_source_analytic(float* acc_lds, int lane, float
 template <bool FULL>
 __global__ __launch_bounds__(64 * MIX_WG_WAVES, MIX_WAVES_PER_SIMD) void spatial_mix(SceneParams P, const SrcStatic* __restrict__ st,
                                                                                      const EarParams* __restrict__ ear,
-                                                                                     float* __restrict__ partials,
+                                                                                     float* __restrict__ partials, const float* __restrict__ init,
                                                                                      uint32_t groups_per_wave, uint32_t n_groups) {
     __shared__ __attribute__((aligned(16))) unsigned char smem_all[LDS_TOTAL * MIX_WG_WAVES];
     const int wv = threadIdx.x >> 6;
@@ -493,6 +493,13 @@ __global__ __launch_bounds__(64 * MIX_WG_WAVES, MIX_WAVES_PER_SIMD) void spatial
     const float fbase = (float)frame0;
 #pragma unroll
     for (int k = 0; k < 16; ++k) { acc[k] = 0.0f; fi[k] = fbase + (float)k; }   // `i as f32` (spatial.rs:459)
+    if (init != nullptr && wave == 0) {
+        // the buffered set is walked before the seekable one (spatial.rs:395-438): its sum is the
+        // value the first source of this walk is added to
+#pragma unroll
+        for (int k = 0; k < 16; ++k)
+            if (frame0 + (uint32_t)k < n_frames) acc[k] = init[2 * (frame0 + (uint32_t)k) + eB];
+    }
     const uint32_t cB_abs = tile * TILE_CHUNKS + (uint32_t)cB;
 
     const uint32_t g_lo = wave * groups_per_wave;

@@ -20,6 +20,7 @@
 #include "../../include/oddio_hip.h"
 #include "kernels.h"
 #include "mixer_kernels.h"
+#include "buffered_kernels.h"
 
 using namespace oddio_hip;
 
@@ -162,12 +163,16 @@ struct HandleRec {
     bool queued = false;           // play() called, not yet update()d
     bool finished = false;         // Spatial::is_finished
     bool released = false;         // handle dropped by the user
+    bool buffered = false;         // lives in the buffered set (play_buffered)
+    float* ring = nullptr;         // device Ring of a buffered source
     uint64_t motion_epoch = 0;     // dedupe stamp for set_motion
     oddio_hip_frames* frames = nullptr;
 };
 
 struct PendingPlay { uint32_t id; SrcStatic st; SrcDyn dyn; };
 struct PendingMotion { uint32_t id; float pos[3]; float vel[3]; uint32_t disc; };
+struct PendingPlayB { uint32_t id; BufStatic st; BufDyn dyn; };
+struct PendingControl { uint32_t id; uint32_t index; float value; };
 
 constexpr uint32_t STOPPED_CAP = 4096;   // ids returned inline with each callback; more => second fetch
 constexpr int RING = 2;
@@ -188,6 +193,21 @@ struct oddio_hip_scene {
     float* d_partials = nullptr;
     float* d_out = nullptr;
     float* d_stage1 = nullptr;
+    // buffered set (play_buffered): allocated on first use by the control thread
+    uint32_t max_buffered = 0, len_b = 0;
+    BufStatic* d_bstatic = nullptr;
+    BufDyn* d_bdyn = nullptr;
+    SrcPending* d_bpend = nullptr;
+    float* d_contrib = nullptr;
+    uint32_t* d_bskip = nullptr;
+    float* d_outb = nullptr;
+    BufMove* d_bmoves = nullptr;
+    ControlUpdate* d_ctrl = nullptr;
+    std::vector<uint32_t> id_of_slot_b;
+    std::vector<PendingPlayB> pending_plays_b;
+    std::vector<PendingControl> pending_controls;
+    size_t live_count_b = 0;
+    std::vector<float*> ring_garbage;      // rings of removed sources, freed off the audio thread
     MotionUpdate* d_motion = nullptr;
     SlotMove* d_moves = nullptr;
     // pinned staging
@@ -224,7 +244,11 @@ static int scene_free(oddio_hip_scene* s) {
     for (auto& h : s->handles) if (h.frames) { oddio_hip_frames_release(h.frames); h.frames = nullptr; }
     for (auto& p : s->pending_plays) (void)p;
     (void)hipFree(s->d_static); (void)hipFree(s->d_dyn); (void)hipFree(s->d_pend); (void)hipFree(s->d_ear);
-    (void)hipFree(s->d_partials); (void)hipFree(s->d_out); (void)hipFree(s->d_stage1); (void)hipFree(s->d_motion); (void)hipFree(s->d_moves);
+    (void)hipFree(s->d_partials); (void)hipFree(s->d_out); (void)hipFree(s->d_stage1);
+    (void)hipFree(s->d_bstatic); (void)hipFree(s->d_bdyn); (void)hipFree(s->d_bpend); (void)hipFree(s->d_contrib); (void)hipFree(s->d_bskip);
+    (void)hipFree(s->d_outb); (void)hipFree(s->d_bmoves); (void)hipFree(s->d_ctrl);
+    for (auto& h : s->handles) if (h.ring) { (void)hipFree(h.ring); h.ring = nullptr; }
+    for (float* r : s->ring_garbage) (void)hipFree(r); (void)hipFree(s->d_motion); (void)hipFree(s->d_moves);
     for (int r = 0; r < RING; ++r) {
         (void)hipFree(s->d_stopped[r]);
         if (s->h_stopped[r]) (void)hipHostFree(s->h_stopped[r]);
@@ -451,6 +475,11 @@ extern "C" int oddio_hip_scene_len(oddio_hip_scene* s, size_t* len) {
     *len = s->len;
     return 0;
 }
+extern "C" int oddio_hip_scene_len_buffered(oddio_hip_scene* s, size_t* len) {
+    if (!s || !len) return fail(ODDIO_HIP_EINVAL, "NULL argument");
+    *len = s->len_b;
+    return 0;
+}
 extern "C" int oddio_hip_scene_set_profiling(oddio_hip_scene* s, int enable) {
     if (!s) return fail(ODDIO_HIP_EINVAL, "NULL scene");
     DeviceGuard g(s->device);
@@ -504,59 +533,191 @@ extern "C" int oddio_hip_scene_stream(oddio_hip_scene* s, void** stream) {
     return 0;
 }
 
+// ---- buffered sources (play_buffered, spatial.rs:314-340) -------------------------------------
+static int ensure_buffered_locked(oddio_hip_scene* s, uint32_t want) {
+    if (s->d_bstatic) return want <= s->max_buffered ? 0 : fail(ODDIO_HIP_ENOMEM, "buffered capacity is %u (call oddio_hip_scene_reserve_buffered first)", s->max_buffered);
+    const uint32_t cap = std::min<uint32_t>(std::max<uint32_t>(want, 256u), s->max_sources);
+    DeviceGuard g(s->device);
+    const size_t n_out = (size_t)2 * s->max_frames;
+#define BF_TRY(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) return fail(_e == hipErrorOutOfMemory ? ODDIO_HIP_ENOMEM : (int)_e, "%s: %s", #expr, hipGetErrorString(_e)); } while (0)
+    BF_TRY(hipMalloc(&s->d_bstatic, cap * sizeof(BufStatic)));
+    BF_TRY(hipMalloc(&s->d_bdyn, cap * sizeof(BufDyn)));
+    BF_TRY(hipMalloc(&s->d_bpend, cap * sizeof(SrcPending)));
+    BF_TRY(hipMalloc(&s->d_contrib, cap * n_out * sizeof(float)));
+    BF_TRY(hipMalloc(&s->d_bskip, cap * sizeof(uint32_t)));
+    BF_TRY(hipMalloc(&s->d_outb, n_out * sizeof(float)));
+    BF_TRY(hipMalloc(&s->d_bmoves, cap * sizeof(BufMove)));
+    BF_TRY(hipMalloc(&s->d_ctrl, 4096 * sizeof(ControlUpdate)));
+    BF_TRY(hipMemset(s->d_bpend, 0, cap * sizeof(SrcPending)));
+#undef BF_TRY
+    s->id_of_slot_b.resize(cap);
+    s->max_buffered = cap;
+    return 0;
+}
+
+extern "C" int oddio_hip_scene_reserve_buffered(oddio_hip_scene* s, uint32_t max_buffered) {
+    if (!s || max_buffered == 0) return fail(ODDIO_HIP_EINVAL, "bad argument");
+    std::lock_guard<std::mutex> lk(s->mu);
+    if (s->d_bstatic) return max_buffered <= s->max_buffered ? 0 : fail(ODDIO_HIP_ESTATE, "buffered capacity already fixed at %u", s->max_buffered);
+    return ensure_buffered_locked(s, max_buffered);
+}
+
+extern "C" int oddio_hip_scene_play_buffered(oddio_hip_scene* s, int leaf_kind, oddio_hip_frames* frames, double start_seconds, float phase,
+                                             float freq_hz_or_value, const oddio_hip_filter* filters, int n_filters,
+                                             const float position[3], const float velocity[3], float radius, float max_distance,
+                                             uint32_t rate, float buffer_duration, uint32_t* source_id) {
+    if (!s || !position || !velocity) return fail(ODDIO_HIP_EINVAL, "NULL argument");
+    if (n_filters < 0 || n_filters > MAX_WRAP || (n_filters && !filters)) return fail(ODDIO_HIP_EINVAL, "0..%d filters", MAX_WRAP);
+    if (rate == 0) return fail(ODDIO_HIP_EINVAL, "rate must be > 0");
+    BufStatic st = {};
+    BufDyn d = {};
+    if (leaf_kind == (int)KIND_FRAMES) {
+        if (!frames) return fail(ODDIO_HIP_EINVAL, "frames is NULL");
+        if (frames->device != s->device) return fail(ODDIO_HIP_EINVAL, "frames live on another device");
+        st.clip = frames->dev; st.clip_len = (uint32_t)frames->len; st.clip_rate = frames->rate;
+        d.common.t = start_seconds;
+    } else if (leaf_kind == (int)KIND_SINE) {
+        st.freq_or_value = freq_hz_or_value * ODDIO_TAU;   // sine.rs:21
+        d.common.phase = phase;
+        frames = nullptr;
+    } else if (leaf_kind == (int)KIND_CONSTANT) {
+        st.freq_or_value = freq_hz_or_value;
+        frames = nullptr;
+    } else {
+        return fail(ODDIO_HIP_EINVAL, "unknown leaf kind %d", leaf_kind);
+    }
+    st.kind = (uint32_t)leaf_kind;
+    st.n_wrap = (uint32_t)n_filters;
+    for (int w = 0; w < n_filters; ++w) {
+        st.wrap_kind[w] = (uint32_t)filters[w].kind;
+        d.shared[w] = 1.0f; d.sm_prev[w] = 1.0f; d.sm_next[w] = 1.0f; d.sm_progress[w] = 1.0f;
+        switch (filters[w].kind) {
+        case ODDIO_HIP_FILTER_FIXED_GAIN: st.wrap_param[w] = powf(10.0f, filters[w].param / 20.0f); break;                 // gain.rs:20
+        case ODDIO_HIP_FILTER_GAIN: d.shared[w] = filters[w].param; d.sm_prev[w] = d.sm_next[w] = filters[w].param; break;    // Gain::set_amplitude_ratio, gain.rs:90-93
+        case ODDIO_HIP_FILTER_SPEED: d.shared[w] = filters[w].param; break;                                                    // speed.rs:18
+        default: return fail(ODDIO_HIP_EINVAL, "unknown filter kind %d", filters[w].kind);
+        }
+    }
+    // SpatialSignalBuffered::new (spatial.rs:31-56)
+    const float max_delay = max_distance / ODDIO_SPEED_OF_SOUND + buffer_duration;
+    const float cap_f = ceilf(max_delay * (float)rate);
+    if (!(cap_f >= 0.0f) || cap_f > 2.0e8f) return fail(ODDIO_HIP_EINVAL, "ring of %g samples is out of range", (double)cap_f);
+    const uint32_t ring_len = (uint32_t)cap_f + 1u;
+    st.ring_len = ring_len; st.rate = rate; st.max_delay = max_delay; st.radius = radius;
+    {   // queue.delay(rate, min(|position| / c, max_delay))  (ring.rs:45-47)
+        float n2 = 0.0f;
+        n2 = n2 + position[0] * position[0]; n2 = n2 + position[1] * position[1]; n2 = n2 + position[2] * position[2];
+        const float dist = sqrtf(n2);
+        const float dt = fminf(dist / ODDIO_SPEED_OF_SOUND, max_delay);
+        d.ring_write = fmodf(0.0f + (float)rate * dt, (float)ring_len);
+    }
+    for (int k = 0; k < 3; ++k) { d.common.tgt_pos[k] = position[k]; d.common.tgt_vel[k] = velocity[k]; d.common.prev_pos[k] = position[k]; }
+    std::lock_guard<std::mutex> lk(s->mu);
+    int rc = ensure_buffered_locked(s, (uint32_t)s->live_count_b + 1);
+    if (rc) return rc;
+    if (s->live_count_b >= s->max_buffered) return fail(ODDIO_HIP_ENOMEM, "buffered set is full (%u)", s->max_buffered);
+    {   // control thread: allocate the ring (zeroed, Ring::new ring.rs:10-15) and free rings of removed sources
+        DeviceGuard g(s->device);
+        for (float* r : s->ring_garbage) (void)hipFree(r);
+        s->ring_garbage.clear();
+        hipError_t e = hipMalloc(&st.ring, (size_t)ring_len * sizeof(float));
+        if (e != hipSuccess) return fail(ODDIO_HIP_ENOMEM, "hipMalloc(ring of %u floats): %s", ring_len, hipGetErrorString(e));
+        e = hipMemset(st.ring, 0, (size_t)ring_len * sizeof(float));
+        if (e != hipSuccess) { (void)hipFree(st.ring); return fail((int)e, "hipMemset(ring): %s", hipGetErrorString(e)); }
+    }
+    s->live_count_b++;
+    const uint32_t id = alloc_id_locked(s);
+    d.common.id = id;
+    HandleRec& h = s->handles[id];
+    h.queued = true; h.buffered = true; h.frames = frames; h.ring = st.ring;
+    if (frames) oddio_hip_frames_retain(frames);
+    s->pending_plays_b.push_back({id, st, d});
+    if (source_id) *source_id = id;
+    return 0;
+}
+
+static int push_control(oddio_hip_scene* s, uint32_t id, int filter_index, float value) {
+    if (!s) return fail(ODDIO_HIP_EINVAL, "NULL scene");
+    if (filter_index < 0 || filter_index >= MAX_WRAP) return fail(ODDIO_HIP_EINVAL, "bad filter index");
+    std::lock_guard<std::mutex> lk(s->mu);
+    if (id >= s->handles.size() || s->handles[id].released || !s->handles[id].buffered) return fail(ODDIO_HIP_ESTATE, "source %u is not a buffered source", id);
+    s->pending_controls.push_back({id, (uint32_t)filter_index, value});
+    return 0;
+}
+extern "C" int oddio_hip_source_set_gain(oddio_hip_scene* s, uint32_t id, int filter_index, float amplitude_ratio) {
+    return push_control(s, id, filter_index, amplitude_ratio);                              // gain.rs:158-160
+}
+extern "C" int oddio_hip_source_set_gain_db(oddio_hip_scene* s, uint32_t id, int filter_index, float db) {
+    return push_control(s, id, filter_index, powf(10.0f, db / 20.0f));                       // gain.rs:141-143
+}
+extern "C" int oddio_hip_source_set_speed(oddio_hip_scene* s, uint32_t id, int filter_index, float factor) {
+    return push_control(s, id, filter_index, factor);                                       // speed.rs:52-54
+}
+
 // ---- the audio-thread side ------------------------------------------------------------------
 
 // Applies one harvested list of stopped ids: Set::remove == Vec::swap_remove in the walk's
 // descending slot order (spatial.rs:204,258-261; set.rs:183-188).
 static int apply_stopped(oddio_hip_scene* s, std::vector<uint32_t>& ids) {
     if (ids.empty()) return 0;
-    std::vector<uint32_t> slots;
+    std::vector<uint32_t> slots_of[2];   // [0] seekable set, [1] buffered set
     {
         std::lock_guard<std::mutex> lk(s->mu);
         for (uint32_t id : ids) {
             if (id >= s->handles.size()) continue;
             HandleRec& h = s->handles[id];
             if (!h.in_set) continue;
-            slots.push_back(h.slot);
+            slots_of[h.buffered ? 1 : 0].push_back(h.slot);
         }
     }
-    std::sort(slots.begin(), slots.end(), std::greater<uint32_t>());
-    // simulate the swap_removes on the id map, tracking where each surviving element started
-    std::unordered_map<uint32_t, uint32_t> origin;   // current slot -> original slot of its (moved) occupant
-    uint32_t len = s->len;
-    std::vector<uint32_t> removed_ids;
-    for (uint32_t slot : slots) {
-        removed_ids.push_back(s->id_of_slot[slot]);
-        const uint32_t last = len - 1;
-        if (slot != last) {
-            auto it = origin.find(last);
-            origin[slot] = it == origin.end() ? last : it->second;
-            s->id_of_slot[slot] = s->id_of_slot[last];
+    for (int set = 0; set < 2; ++set) {
+        std::vector<uint32_t>& slots = slots_of[set];
+        if (slots.empty()) continue;
+        std::vector<uint32_t>& id_of_slot = set ? s->id_of_slot_b : s->id_of_slot;
+        std::sort(slots.begin(), slots.end(), std::greater<uint32_t>());
+        // simulate the swap_removes on the id map, tracking where each surviving element started
+        std::unordered_map<uint32_t, uint32_t> origin;   // current slot -> original slot of its (moved) occupant
+        uint32_t len = set ? s->len_b : s->len;
+        std::vector<uint32_t> removed_ids;
+        for (uint32_t slot : slots) {
+            removed_ids.push_back(id_of_slot[slot]);
+            const uint32_t last = len - 1;
+            if (slot != last) {
+                auto it = origin.find(last);
+                origin[slot] = it == origin.end() ? last : it->second;
+                id_of_slot[slot] = id_of_slot[last];
+            }
+            origin.erase(last);
+            len--;
         }
-        origin.erase(last);
-        len--;
-    }
-    std::vector<SlotMove> moves;
-    for (auto& kv : origin) if (kv.first < len) moves.push_back({kv.first, kv.second});
-    {
-        std::lock_guard<std::mutex> lk(s->mu);
-        for (uint32_t id : removed_ids) {
-            HandleRec& h = s->handles[id];
-            h.in_set = false; h.finished = true; h.slot = 0xffffffffu;
-            s->live_count--;
-            if (h.frames) { oddio_hip_frames_release(h.frames); h.frames = nullptr; }
-            if (h.released) s->free_ids.push_back(id);
+        std::vector<SlotMove> moves;
+        for (auto& kv : origin) if (kv.first < len) moves.push_back({kv.first, kv.second});
+        {
+            std::lock_guard<std::mutex> lk(s->mu);
+            for (uint32_t id : removed_ids) {
+                HandleRec& h = s->handles[id];
+                h.in_set = false; h.finished = true; h.slot = 0xffffffffu;
+                if (set) s->live_count_b--; else s->live_count--;
+                if (h.frames) { oddio_hip_frames_release(h.frames); h.frames = nullptr; }
+                if (h.ring) { s->ring_garbage.push_back(h.ring); h.ring = nullptr; }   // freed by the control thread / destroy
+                if (h.released) s->free_ids.push_back(id);
+            }
+            for (const SlotMove& m : moves) s->handles[id_of_slot[m.dst]].slot = m.dst;
         }
-        for (const SlotMove& m : moves) s->handles[s->id_of_slot[m.dst]].slot = m.dst;
-    }
-    s->len = len;
-    if (!moves.empty()) {
-        // sources move from original (surviving) slots into stopped slots: reads and writes are disjoint
-        HIP_TRY(hipMemcpyAsync(s->d_moves, moves.data(), moves.size() * sizeof(SlotMove), hipMemcpyHostToDevice, s->stream));
-        HIP_TRY(hipStreamSynchronize(s->stream));   // `moves` is pageable host memory
-        const uint32_t n = (uint32_t)moves.size();
-        hipLaunchKernelGGL(apply_slot_moves, dim3((n + 255) / 256), dim3(256), 0, s->stream, s->d_moves, n, s->d_static, s->d_dyn, s->d_pend);
-        HIP_TRY(hipGetLastError());
+        if (set) s->len_b = len; else s->len = len;
+        if (!moves.empty()) {
+            // sources move from original (surviving) slots into stopped slots: reads and writes are disjoint
+            static_assert(sizeof(SlotMove) == sizeof(BufMove), "move records share a staging buffer layout");
+            void* d_mv = set ? (void*)s->d_bmoves : (void*)s->d_moves;
+            HIP_TRY(hipMemcpyAsync(d_mv, moves.data(), moves.size() * sizeof(SlotMove), hipMemcpyHostToDevice, s->stream));
+            HIP_TRY(hipStreamSynchronize(s->stream));   // `moves` is pageable host memory
+            const uint32_t n = (uint32_t)moves.size();
+            if (set)
+                hipLaunchKernelGGL(apply_buf_moves, dim3((n + 255) / 256), dim3(256), 0, s->stream, s->d_bmoves, n, s->d_bstatic, s->d_bdyn, s->d_bpend);
+            else
+                hipLaunchKernelGGL(apply_slot_moves, dim3((n + 255) / 256), dim3(256), 0, s->stream, s->d_moves, n, s->d_static, s->d_dyn, s->d_pend);
+            HIP_TRY(hipGetLastError());
+        }
     }
     return 0;
 }
@@ -576,6 +737,11 @@ static int harvest_ring(oddio_hip_scene* s, int r) {
         std::vector<SrcDyn> dyn(s->ring_nsrc[r]);
         HIP_TRY(hipMemcpy(dyn.data(), s->d_dyn, dyn.size() * sizeof(SrcDyn), hipMemcpyDeviceToHost));
         for (const SrcDyn& d : dyn) if (d.flags & DYN_STOPPED) ids.push_back(d.id);
+        if (s->len_b) {
+            std::vector<BufDyn> bd(s->len_b);
+            HIP_TRY(hipMemcpy(bd.data(), s->d_bdyn, bd.size() * sizeof(BufDyn), hipMemcpyDeviceToHost));
+            for (const BufDyn& d : bd) if (d.common.flags & DYN_STOPPED) ids.push_back(d.common.id);
+        }
     }
     return apply_stopped(s, ids);
 }
@@ -593,12 +759,16 @@ static int scene_sample_impl(oddio_hip_scene* s, float interval, float* host_out
 
     // ---- set.update(): drain control messages (set.rs:141-168) ----
     std::vector<PendingPlay> plays;
+    std::vector<PendingPlayB> plays_b;
+    std::vector<PendingControl> controls;
     std::vector<PendingMotion> motions;
     bool rot_fresh;
     float rot_new[4];
     {
         std::lock_guard<std::mutex> lk(s->mu);
         plays.swap(s->pending_plays);
+        plays_b.swap(s->pending_plays_b);
+        controls.swap(s->pending_controls);
         motions.swap(s->pending_motion);
         rot_fresh = s->rot_fresh;
         s->rot_fresh = false;
@@ -626,9 +796,50 @@ static int scene_sample_impl(oddio_hip_scene* s, float interval, float* host_out
         HIP_TRY(hipStreamSynchronize(s->stream));   // hs/hd are pageable and go out of scope
         s->len = first + (uint32_t)k;
     }
+    if (!plays_b.empty()) {   // buffered set: set.update() pushes in send order too
+        const uint32_t first = s->len_b;
+        const size_t k = plays_b.size();
+        std::vector<BufStatic> hs(k);
+        std::vector<BufDyn> hd(k);
+        {
+            std::lock_guard<std::mutex> lk(s->mu);
+            for (size_t i = 0; i < k; ++i) {
+                hs[i] = plays_b[i].st; hd[i] = plays_b[i].dyn;
+                const uint32_t slot = first + (uint32_t)i;
+                s->id_of_slot_b[slot] = plays_b[i].id;
+                HandleRec& h = s->handles[plays_b[i].id];
+                h.slot = slot; h.in_set = true; h.queued = false;
+            }
+        }
+        HIP_TRY(hipMemcpyAsync(s->d_bstatic + first, hs.data(), k * sizeof(BufStatic), hipMemcpyHostToDevice, s->stream));
+        HIP_TRY(hipMemcpyAsync(s->d_bdyn + first, hd.data(), k * sizeof(BufDyn), hipMemcpyHostToDevice, s->stream));
+        HIP_TRY(hipMemsetAsync(s->d_bpend + first, 0, k * sizeof(SrcPending), s->stream));
+        HIP_TRY(hipStreamSynchronize(s->stream));
+        s->len_b = first + (uint32_t)k;
+    }
+    if (!controls.empty()) {   // GainControl / SpeedControl: relaxed "latest value" stores (gain.rs:158-160, speed.rs:52-54)
+        std::vector<ControlUpdate> ups;
+        {
+            std::lock_guard<std::mutex> lk(s->mu);
+            for (const PendingControl& c : controls) {
+                const HandleRec& h = s->handles[c.id];
+                if (!h.in_set || !h.buffered) continue;
+                ups.push_back({h.slot, c.index, c.value, 0u});
+            }
+        }
+        if (!ups.empty()) {
+            HIP_TRY(hipMemcpyAsync(s->d_ctrl, ups.data(), ups.size() * sizeof(ControlUpdate), hipMemcpyHostToDevice, s->stream));
+            HIP_TRY(hipStreamSynchronize(s->stream));
+            const uint32_t n = (uint32_t)ups.size();
+            // updates of one callback are applied in send order by a single thread block per 256; a later
+            // value for the same (slot, index) must win -> serialise them
+            hipLaunchKernelGGL(apply_control_updates_serial, dim3(1), dim3(1), 0, s->stream, s->d_ctrl, n, s->d_bdyn);
+            HIP_TRY(hipGetLastError());
+        }
+    }
     if (!motions.empty()) {
         // swap.rs semantics: only the latest value per source survives until refresh()
-        std::vector<MotionUpdate> ups;
+        std::vector<MotionUpdate> ups, ups_b;
         {
             std::lock_guard<std::mutex> lk(s->mu);
             s->motion_epoch++;
@@ -641,8 +852,16 @@ static int scene_sample_impl(oddio_hip_scene* s, float interval, float* host_out
                 u.slot = h.slot;
                 for (int c = 0; c < 3; ++c) { u.pos[c] = motions[i].pos[c]; u.vel[c] = motions[i].vel[c]; }
                 u.discontinuity = motions[i].disc;
-                ups.push_back(u);
+                (h.buffered ? ups_b : ups).push_back(u);
             }
+        }
+        if (!ups_b.empty()) {
+            // d_motion is sized for max_sources >= max_buffered; reuse it before the seekable batch
+            HIP_TRY(hipMemcpyAsync(s->d_motion, ups_b.data(), ups_b.size() * sizeof(MotionUpdate), hipMemcpyHostToDevice, s->stream));
+            HIP_TRY(hipStreamSynchronize(s->stream));
+            const uint32_t n = (uint32_t)ups_b.size();
+            hipLaunchKernelGGL(apply_motion_updates, dim3((n + 255) / 256), dim3(256), 0, s->stream, s->d_motion, n, s->d_bpend);
+            HIP_TRY(hipGetLastError());
         }
         if (!ups.empty()) {
             HIP_TRY(hipMemcpyAsync(s->d_motion, ups.data(), ups.size() * sizeof(MotionUpdate), hipMemcpyHostToDevice, s->stream));
@@ -673,6 +892,19 @@ static int scene_sample_impl(oddio_hip_scene* s, float interval, float* host_out
                            s->d_ear, s->d_stopped[r], STOPPED_CAP);
         HIP_TRY(hipGetLastError());
     }
+    const float* init = nullptr;
+    if (s->len_b > 0) {
+        hipLaunchKernelGGL(buffered_sources, dim3((s->len_b + 63) / 64), dim3(64), 0, s->stream, P, s->len_b, s->d_bstatic, s->d_bdyn, s->d_bpend,
+                           s->d_contrib, s->d_bskip, s->d_stopped[r], STOPPED_CAP);
+        HIP_TRY(hipGetLastError());
+        if (n_frames > 0) {
+            const uint32_t n_out = 2u * (uint32_t)n_frames;
+            hipLaunchKernelGGL(buffered_reduce, dim3((n_out + 255) / 256), dim3(256), 0, s->stream, s->d_contrib, s->d_bskip, s->len_b,
+                               (uint32_t)n_frames, s->d_outb);
+            HIP_TRY(hipGetLastError());
+            init = s->d_outb;
+        }
+    }
     if (prof) HIP_TRY(hipEventRecord(pev[1], s->stream));
     uint32_t n_wgs = 0;
     const uint32_t n_tiles = ((uint32_t)n_frames + TILE_FRAMES - 1) / TILE_FRAMES;
@@ -685,9 +917,9 @@ static int scene_sample_impl(oddio_hip_scene* s, float interval, float* host_out
         n_wgs = (waves + MIX_WG_WAVES - 1) / MIX_WG_WAVES;
         const bool full = (n_frames % TILE_FRAMES) == 0;
         if (full)
-            hipLaunchKernelGGL(spatial_mix<true>, dim3(n_wgs, n_tiles), dim3(64 * MIX_WG_WAVES), 0, s->stream, P, s->d_static, s->d_ear, s->d_partials, gpw, n_groups);
+            hipLaunchKernelGGL(spatial_mix<true>, dim3(n_wgs, n_tiles), dim3(64 * MIX_WG_WAVES), 0, s->stream, P, s->d_static, s->d_ear, s->d_partials, init, gpw, n_groups);
         else
-            hipLaunchKernelGGL(spatial_mix<false>, dim3(n_wgs, n_tiles), dim3(64 * MIX_WG_WAVES), 0, s->stream, P, s->d_static, s->d_ear, s->d_partials, gpw, n_groups);
+            hipLaunchKernelGGL(spatial_mix<false>, dim3(n_wgs, n_tiles), dim3(64 * MIX_WG_WAVES), 0, s->stream, P, s->d_static, s->d_ear, s->d_partials, init, gpw, n_groups);
         HIP_TRY(hipGetLastError());
     }
     if (prof) HIP_TRY(hipEventRecord(pev[2], s->stream));
@@ -698,6 +930,8 @@ static int scene_sample_impl(oddio_hip_scene* s, float interval, float* host_out
                                n_wgs, (uint32_t)n_frames);
             hipLaunchKernelGGL(reduce_stage2, dim3((n_out + 255) / 256), dim3(256), 0, s->stream, s->d_stage1, out_dev, n_wgs,
                                (uint32_t)n_frames, s->postfx);
+        } else if (init) {
+            hipLaunchKernelGGL(copy_postfx_kernel, dim3((n_out + 255) / 256), dim3(256), 0, s->stream, init, out_dev, n_out, s->postfx);
         } else {
             hipLaunchKernelGGL(zero_kernel, dim3((n_out + 255) / 256), dim3(256), 0, s->stream, out_dev, n_out);   // spatial.rs:389-391
         }

@@ -1,0 +1,135 @@
+"""play_buffered on the HIP path vs the CPU oracle (src/spatial.rs:314-340,395-433; src/ring.rs;
+src/gain.rs; src/speed.rs).  GPU only.  FramesSignal/Constant leaves: bit-exact (the buffered
+kernel replays the reference's sequential loops and its reduce walks slots in reverse order);
+Sine leaves: 1e-5 relative (device sinf)."""
+import numpy as np
+import pytest
+
+from oddio_amd import synth
+from oracle import oracle_c as oc
+
+pytestmark = pytest.mark.gpu
+
+INTERVAL = np.float32(1.0) / np.float32(48000)
+
+
+def pair():
+    import oddio_amd as oa
+    control, scene = oa.SpatialScene(max_sources=64, max_frames=2048)
+    scene.set_mode(oa.MODE_ORDERED)
+    return oa, control, scene, oc.SpatialScene()
+
+
+def opts(mod, p, v, r=0.1):
+    return mod.SpatialOptions(np.asarray(p, np.float32), np.asarray(v, np.float32), r)
+
+
+def test_buffered_frames_plain_and_len():
+    oa, control, scene, ref = pair()
+    for i in range(5):
+        clip = synth.noise_clip(3, i, 30000)
+        p, v = [4.0 + 3 * i, 1.0, -2.0 - i], [3.0, -1.0 * i, 2.0]
+        control.play_buffered(oa.FramesSignal(oa.Frames.from_slice(48000, clip), 0.0), opts(oa, p, v), 200.0, 48000, 0.1)
+        ref.play_buffered(oc.FramesSignal(oc.Frames(48000, clip), 0.0), opts(oc, p, v), 200.0, 48000, 0.1)
+    for cb in range(6):
+        n = (1024, 1024, 700, 1024, 256, 2048)[cb]
+        a, b = ref.sample_n(INTERVAL, n), scene.sample_n(INTERVAL, n)
+        assert np.abs(a).max() > 0 or cb == 0
+        np.testing.assert_array_equal(b, a)
+        assert scene.len_buffered() == ref.len_buffered() and len(scene) == 0
+    scene.close()
+
+
+def test_buffered_gain_speed_fixedgain_chain():
+    oa, control, scene, ref = pair()
+    clip = synth.noise_clip(8, 0, 60000)
+    # Speed<Gain<FixedGain<FramesSignal>>> and Gain<Speed<Sine>>, Gain<Constant>
+    gc_h, g_h = oa.Gain.new(oa.FixedGain(oa.FramesSignal(oa.Frames.from_slice(44100, clip), 0.0), -3.0))
+    sc_h, s_h = oa.Speed.new(g_h)
+    og = oc.Gain(oc.FixedGain(oc.FramesSignal(oc.Frames(44100, clip), 0.0), -3.0))
+    os_ = oc.Speed(og)
+    p, v = [5.0, 0.5, -3.0], [-6.0, 0.0, 1.0]
+    control.play_buffered(s_h, opts(oa, p, v), 150.0, 48000, 0.1)
+    ref.play_buffered(os_, opts(oc, p, v), 150.0, 48000, 0.1)
+    gc2_h, g2_h = oa.Gain.new(oa.Constant(0.5))
+    og2 = oc.Gain(oc.Constant(0.5))
+    control.play_buffered(g2_h, opts(oa, [1.0, 2.0, 2.0], [0.0, 0.0, 0.0]), 50.0, 48000, 0.1)
+    ref.play_buffered(og2, opts(oc, [1.0, 2.0, 2.0], [0.0, 0.0, 0.0]), 50.0, 48000, 0.1)
+    for cb in range(8):
+        if cb == 1:
+            gc_h.set_amplitude_ratio(0.25); og.set_amplitude_ratio(0.25)       # 0.1 s ramp spans several callbacks
+            gc2_h.set_gain(-12.0); og2.set_gain(-12.0)
+        if cb == 2:
+            sc_h.set_speed(1.5); os_.set_speed(1.5)
+        if cb == 3:
+            gc_h.set_amplitude_ratio(2.0); og.set_amplitude_ratio(2.0)         # retarget mid-ramp (smooth.rs:14-17)
+        if cb == 5:
+            sc_h.set_speed(0.5); os_.set_speed(0.5)
+        a, b = ref.sample_n(INTERVAL, 1024), scene.sample_n(INTERVAL, 1024)
+        np.testing.assert_array_equal(b, a)
+    scene.close()
+
+
+def test_buffered_sine_tolerance():
+    oa, control, scene, ref = pair()
+    gc_h, g_h = oa.Gain.new(oa.Sine(0.3, 440.0))
+    og = oc.Gain(oc.Sine(0.3, 440.0))
+    control.play_buffered(g_h, opts(oa, [10.0, 0.0, -4.0], [-20.0, 0.0, 0.0]), 100.0, 48000, 0.1)
+    ref.play_buffered(og, opts(oc, [10.0, 0.0, -4.0], [-20.0, 0.0, 0.0]), 100.0, 48000, 0.1)
+    for cb in range(4):
+        if cb == 2:
+            gc_h.set_amplitude_ratio(0.1); og.set_amplitude_ratio(0.1)
+        a, b = ref.sample_n(INTERVAL, 1024), scene.sample_n(INTERVAL, 1024)
+        assert np.abs(b - a).max() <= 1e-5 * max(np.abs(a).max(), 1e-30)
+    scene.close()
+
+
+def test_buffered_and_seek_sets_together_with_motion_and_removal():
+    oa, control, scene, ref = pair()
+    hb, rb = [], []
+    for i in range(4):   # buffered: short clips that finish and are removed after their delay
+        clip = synth.noise_clip(11, i, 3000 + 2500 * i)
+        p, v = [3.0 + 2 * i, -1.0, 2.0], [1.0, 0.5 * i, -2.0]
+        hb.append(control.play_buffered(oa.FramesSignal(oa.Frames.from_slice(48000, clip), 0.0), opts(oa, p, v), 120.0, 48000, 0.1))
+        rb.append(ref.play_buffered(oc.FramesSignal(oc.Frames(48000, clip), 0.0), opts(oc, p, v), 120.0, 48000, 0.1))
+    hs, rs = [], []
+    for i in range(5):   # seekable set in the same scene
+        clip = synth.noise_clip(12, i, 26000)
+        p, v = [-4.0 - i, 2.0, 1.0 + i], [5.0, -3.0, 0.5 * i]
+        hs.append(control.play(oa.FramesSignal(oa.Frames.from_slice(48000, clip), 0.05), opts(oa, p, v)))
+        rs.append(ref.play(oc.FramesSignal(oc.Frames(48000, clip), 0.05), opts(oc, p, v)))
+    for cb in range(14):
+        if cb == 2:
+            for h, r in ((hb[1], rb[1]), (hs[3], rs[3])):
+                h.set_motion(np.float32([2.0, 2.0, 2.0]), np.float32([0.0, 1.0, 0.0]), cb % 2 == 0)
+                r.set_motion(np.float32([2.0, 2.0, 2.0]), np.float32([0.0, 1.0, 0.0]), cb % 2 == 0)
+        if cb == 4:
+            q = np.float32([np.cos(0.4), 0.0, np.sin(0.4), 0.0])
+            control.set_listener_rotation(q)
+            ref.set_listener_rotation(q)
+        a, b = ref.sample_n(INTERVAL, 1024), scene.sample_n(INTERVAL, 1024)
+        np.testing.assert_array_equal(b, a)
+        assert (scene.len_buffered(), len(scene)) == (ref.len_buffered(), len(ref))
+        assert [h.is_finished() for h in hb + hs] == [r.is_finished() for r in rb + rs]
+    assert scene.len_buffered() == 0
+    scene.close()
+
+
+def test_buffered_fast_mode_tolerance():
+    import oddio_amd as oa
+    control, scene = oa.SpatialScene(max_sources=256, max_frames=1024)
+    ref = oc.SpatialScene()
+    sc = synth.make_scene(21, 96, cube=20.0)
+    for i in range(96):
+        clip = synth.noise_clip(21, i, 20000)
+        o_h, o_r = opts(oa, sc["position"][i], sc["velocity"][i]), opts(oc, sc["position"][i], sc["velocity"][i])
+        if i % 2:
+            control.play_buffered(oa.FramesSignal(oa.Frames.from_slice(48000, clip), 0.0), o_h, 100.0, 48000, 0.1)
+            ref.play_buffered(oc.FramesSignal(oc.Frames(48000, clip), 0.0), o_r, 100.0, 48000, 0.1)
+        else:
+            control.play(oa.FramesSignal(oa.Frames.from_slice(48000, clip), 0.1), o_h)
+            ref.play(oc.FramesSignal(oc.Frames(48000, clip), 0.1), o_r)
+    for cb in range(3):
+        a, b = ref.sample_n(INTERVAL, 1024), scene.sample_n(INTERVAL, 1024)
+        assert np.abs(b - a).max() <= 1e-5 * np.abs(a).max()
+    scene.close()
