@@ -66,6 +66,9 @@ int oddio_hip_device_count(int* count);
  * rejected (the reference panics on them in get_pair, src/frames.rs:111). */
 int oddio_hip_frames_from_slice(int device, uint32_t rate, const float* samples, size_t len,
                                 oddio_hip_frames** out);
+/* Frames<[f32; 2]> (interleaved stereo, e.g. examples/wav.rs:45-70); playable in a Mixer only. */
+int oddio_hip_frames_from_slice_stereo(int device, uint32_t rate, const float* interleaved,
+                                       size_t n_frames, oddio_hip_frames** out);
 /* Same, but `dev_samples` is already a device pointer on `device`.  copy != 0: D2D copy;
  * copy == 0: borrow (caller keeps the memory alive; `len` must be a multiple of 4 floats and the
  * pointer 16-byte aligned). */
@@ -110,7 +113,8 @@ int oddio_hip_scene_play_frames_batch(oddio_hip_scene* scene, size_t n,
  * ratio, normally 1) and Speed (src/speed.rs, param = initial factor, normally 1).  The scene owns a
  * `Ring` (src/ring.rs) of ceil((max_distance / 343 + buffer_duration) * rate) + 1 samples per source
  * in HBM, allocated here (control thread) and sampled at `rate`. */
-enum { ODDIO_HIP_LEAF_FRAMES = 0, ODDIO_HIP_LEAF_SINE = 1, ODDIO_HIP_LEAF_CONSTANT = 2 };
+enum { ODDIO_HIP_LEAF_FRAMES = 0, ODDIO_HIP_LEAF_SINE = 1, ODDIO_HIP_LEAF_CONSTANT = 2,
+       ODDIO_HIP_LEAF_CYCLE = 3 /* Cycle::new(frames), src/cycle.rs (buffered sources and Mixer chains) */ };
 enum { ODDIO_HIP_FILTER_FIXED_GAIN = 1, ODDIO_HIP_FILTER_GAIN = 2, ODDIO_HIP_FILTER_SPEED = 3 };
 typedef struct oddio_hip_filter { int kind; float param; } oddio_hip_filter;
 int oddio_hip_scene_reserve_buffered(oddio_hip_scene* scene, uint32_t max_buffered);
@@ -204,6 +208,18 @@ int oddio_hip_mixer_play_sine(oddio_hip_mixer* mixer, float phase, float frequen
 int oddio_hip_mixer_play_frames(oddio_hip_mixer* mixer, oddio_hip_frames* frames,
                                 double start_seconds, float fixed_gain_db, uint32_t* source_id);
 int oddio_hip_mixer_play_constant(oddio_hip_mixer* mixer, float value, uint32_t* source_id);
+/* MixerControl::play of any supported signal: leaf (ODDIO_HIP_LEAF_*, arguments as above; mono
+ * leaves are implicitly MonoToStereo'd, stereo clips play as is) inside up to 4 filters, innermost
+ * first (FixedGain / Gain / Speed; see oddio_hip_filter).  A mixer that has ever been given a Gain,
+ * Speed, Cycle, a stereo clip or more than one filter renders through the general (one thread per
+ * source) path from then on and holds at most 1024 sources. */
+int oddio_hip_mixer_play_chain(oddio_hip_mixer* mixer, int leaf_kind, oddio_hip_frames* frames,
+                               double start_seconds, float phase, float frequency_hz_or_value,
+                               const oddio_hip_filter* filters, int n_filters, uint32_t* source_id);
+/* GainControl / SpeedControl of filter `filter_index` of a mixer source */
+int oddio_hip_mixer_set_gain(oddio_hip_mixer* mixer, uint32_t source_id, int filter_index, float amplitude_ratio);
+int oddio_hip_mixer_set_gain_db(oddio_hip_mixer* mixer, uint32_t source_id, int filter_index, float db);
+int oddio_hip_mixer_set_speed(oddio_hip_mixer* mixer, uint32_t source_id, int filter_index, float factor);
 /* Mixed::stop / Mixed::is_stopped (src/mixer.rs:34-43) */
 int oddio_hip_mixer_stop(oddio_hip_mixer* mixer, uint32_t source_id);
 int oddio_hip_mixer_is_stopped(oddio_hip_mixer* mixer, uint32_t source_id, int* stopped);

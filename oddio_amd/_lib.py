@@ -64,6 +64,7 @@ def lib():
         "oddio_hip_last_error": (C.c_char_p, []),
         "oddio_hip_device_count": (i32, [C.POINTER(i32)]),
         "oddio_hip_frames_from_slice": (i32, [i32, u32, fp, sz, vpp]),
+        "oddio_hip_frames_from_slice_stereo": (i32, [i32, u32, fp, sz, vpp]),
         "oddio_hip_frames_from_device": (i32, [i32, u32, vp, sz, i32, vpp]),
         "oddio_hip_frames_retain": (i32, [vp]),
         "oddio_hip_frames_release": (i32, [vp]),
@@ -106,6 +107,10 @@ def lib():
         "oddio_hip_mixer_play_sine": (i32, [vp, f32, f32, f32, u32p]),
         "oddio_hip_mixer_play_frames": (i32, [vp, vp, f64, f32, u32p]),
         "oddio_hip_mixer_play_constant": (i32, [vp, f32, u32p]),
+        "oddio_hip_mixer_play_chain": (i32, [vp, i32, vp, f64, f32, f32, vp, i32, u32p]),
+        "oddio_hip_mixer_set_gain": (i32, [vp, u32, i32, f32]),
+        "oddio_hip_mixer_set_gain_db": (i32, [vp, u32, i32, f32]),
+        "oddio_hip_mixer_set_speed": (i32, [vp, u32, i32, f32]),
         "oddio_hip_mixer_stop": (i32, [vp, u32]),
         "oddio_hip_mixer_is_stopped": (i32, [vp, u32, C.POINTER(i32)]),
         "oddio_hip_mixer_len": (i32, [vp, C.POINTER(sz)]),

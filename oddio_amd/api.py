@@ -42,15 +42,22 @@ def _vec3(v):
 class Frames:
     """oddio::Frames<f32> held in HBM (src/frames.rs:19-47).  Reference counted like the Arc."""
 
+    channels = 1
+
     def __init__(self, handle, rate, length, device, keepalive=None):
         self._h, self.rate, self.len, self.device, self._keepalive = handle, rate, length, device, keepalive
 
     @classmethod
     def from_slice(cls, rate: int, samples, device: int = 0) -> "Frames":
         a = np.ascontiguousarray(np.asarray(samples, dtype=np.float32))
-        if a.ndim != 1:
-            raise TypeError("spatial scenes and MonoToStereo take mono clips (Frame = Sample, src/spatial.rs:291)")
         h = C.c_void_p()
+        if a.ndim == 2 and a.shape[1] == 2:      # Frames<[f32; 2]>: playable in a Mixer only
+            _lib.check(_lib.lib().oddio_hip_frames_from_slice_stereo(device, int(rate), _fp(a), a.shape[0], C.byref(h)))
+            f = cls(h, int(rate), a.shape[0], device)
+            f.channels = 2
+            return f
+        if a.ndim != 1:
+            raise TypeError("clips are mono [n] or interleaved stereo [n, 2]")
         _lib.check(_lib.lib().oddio_hip_frames_from_slice(device, int(rate), _fp(a), a.shape[0], C.byref(h)))
         return cls(h, int(rate), a.shape[0], device)
 
@@ -83,10 +90,20 @@ class Signal:
 class FramesSignal(Signal):
     def __init__(self, frames: Frames, start_seconds: float = 0.0):
         self.frames, self.start_seconds = frames, float(start_seconds)
+        self.channels = frames.channels
 
     @classmethod
     def new(cls, frames, start_seconds):
         return cls(frames, start_seconds)
+
+
+class Cycle(Signal):
+    """Cycle::new(frames) (src/cycle.rs:17-23): loops a clip end to end.  Device support: buffered
+    spatial sources and Mixer chains (the general, one-thread-per-source paths)."""
+
+    def __init__(self, frames: Frames):
+        self.frames = frames
+        self.channels = frames.channels
 
 
 class Sine(Signal):
@@ -118,8 +135,9 @@ class GainControl:
     def set_amplitude_ratio(self, factor):
         self._ratio = np.float32(factor)
         if self._target is not None:
-            scene, sid, index = self._target
-            _lib.check(_lib.lib().oddio_hip_source_set_gain(scene._h, sid, index, np.float32(factor)))
+            owner, sid, index = self._target
+            fn = _lib.lib().oddio_hip_mixer_set_gain if isinstance(owner, _MixerSignal) else _lib.lib().oddio_hip_source_set_gain
+            _lib.check(fn(owner._h, sid, index, np.float32(factor)))
 
     def set_gain(self, db):
         self.set_amplitude_ratio(np.float32(_powf10(db)))
@@ -141,8 +159,9 @@ class SpeedControl:
     def set_speed(self, factor):
         self._speed = np.float32(factor)
         if self._target is not None:
-            scene, sid, index = self._target
-            _lib.check(_lib.lib().oddio_hip_source_set_speed(scene._h, sid, index, np.float32(factor)))
+            owner, sid, index = self._target
+            fn = _lib.lib().oddio_hip_mixer_set_speed if isinstance(owner, _MixerSignal) else _lib.lib().oddio_hip_source_set_speed
+            _lib.check(fn(owner._h, sid, index, np.float32(factor)))
 
     def speed(self):
         return float(self._speed)
@@ -188,6 +207,19 @@ class Speed(Signal):
 FILTER_FIXED_GAIN, FILTER_GAIN, FILTER_SPEED = 1, 2, 3
 
 
+def _leaf_args(leaf, keep):
+    """-> (leaf_kind, frames handle, start_seconds, phase, frequency_hz_or_value)"""
+    if isinstance(leaf, FramesSignal):
+        keep.append(leaf.frames)
+        return (0, leaf.frames._h, leaf.start_seconds, 0.0, 0.0)
+    if isinstance(leaf, Cycle):
+        keep.append(leaf.frames)
+        return (3, leaf.frames._h, 0.0, 0.0, 0.0)
+    if isinstance(leaf, Sine):
+        return (1, None, 0.0, float(leaf.phase), float(leaf.frequency_hz))
+    return (2, None, 0.0, 0.0, float(leaf.value))
+
+
 class _Filter(C.Structure):
     _fields_ = [("kind", C.c_int), ("param", C.c_float)]
 
@@ -203,7 +235,7 @@ def _unwrap_chain(signal):
         else:
             chain.append((FILTER_SPEED, float(signal.control._speed), signal.control))
         signal = signal.inner
-    if not isinstance(signal, (FramesSignal, Sine, Constant)):
+    if not isinstance(signal, (FramesSignal, Sine, Constant, Cycle)):
         raise TypeError(f"{type(signal).__name__} is not implemented on the device path")
     if len(chain) > 4:
         raise TypeError("at most 4 filters around a buffered source")
@@ -377,13 +409,7 @@ class SpatialSceneControl:
         filt = (_Filter * max(len(chain), 1))()
         for i, (kind, param, _) in enumerate(chain):
             filt[i].kind, filt[i].param = kind, param
-        if isinstance(leaf, FramesSignal):
-            s._keep.append(leaf.frames)
-            args = (0, leaf.frames._h, leaf.start_seconds, 0.0, 0.0)
-        elif isinstance(leaf, Sine):
-            args = (1, None, 0.0, float(leaf.phase), float(leaf.frequency_hz))
-        else:
-            args = (2, None, 0.0, 0.0, float(leaf.value))
+        args = _leaf_args(leaf, s._keep)
         _lib.check(L.oddio_hip_scene_play_buffered(s._h, args[0], args[1], args[2], args[3], args[4], C.cast(filt, C.c_void_p), len(chain),
                                                    _fp(pos), _fp(vel), np.float32(options.radius), np.float32(max_distance), int(rate),
                                                    np.float32(buffer_duration), C.byref(sid)))
@@ -525,18 +551,39 @@ class MixerControl:
         self._m = mixer
 
     def play(self, signal: Signal) -> Mixed:
-        if not isinstance(signal, MonoToStereo):
-            raise TypeError("the device Mixer is Mixer<[f32;2]>: play MonoToStereo::new(mono signal)")
-        leaf, db = _unwrap(signal.inner)
+        """MixerControl::play for Mixer<[f32;2]>: any nest of FixedGain / Gain / Speed / MonoToStereo
+        around FramesSignal (mono or stereo clip), Cycle, Sine or Constant whose output is stereo."""
+        chain, stereo_seen, sig = [], False, signal
+        while isinstance(sig, (FixedGain, Gain, Speed, MonoToStereo)):
+            if isinstance(sig, MonoToStereo):
+                if stereo_seen:
+                    raise TypeError("MonoToStereo appears twice")
+                stereo_seen = True
+            elif isinstance(sig, FixedGain):
+                chain.append((FILTER_FIXED_GAIN, float(sig.db), None))
+            elif isinstance(sig, Gain):
+                chain.append((FILTER_GAIN, float(sig.control._ratio), sig.control))
+            else:
+                chain.append((FILTER_SPEED, float(sig.control._speed), sig.control))
+            sig = sig.inner
+        if not isinstance(sig, (FramesSignal, Sine, Constant, Cycle)):
+            raise TypeError(f"{type(sig).__name__} is not implemented on the device path")
+        leaf_channels = getattr(sig, "channels", 1)
+        if (leaf_channels == 1) != stereo_seen:
+            raise TypeError("the device Mixer is Mixer<[f32;2]>: mono signals need MonoToStereo::new, stereo clips must not have it")
+        chain = chain[::-1]
+        if len(chain) > 4:
+            raise TypeError("at most 4 filters")
         L, m = _lib.lib(), self._m
         sid = C.c_uint32()
-        if isinstance(leaf, FramesSignal):
-            m._keep.append(leaf.frames)
-            _lib.check(L.oddio_hip_mixer_play_frames(m._h, leaf.frames._h, leaf.start_seconds, db, C.byref(sid)))
-        elif isinstance(leaf, Sine):
-            _lib.check(L.oddio_hip_mixer_play_sine(m._h, leaf.phase, leaf.frequency_hz, db, C.byref(sid)))
-        else:
-            _lib.check(L.oddio_hip_mixer_play_constant(m._h, leaf.value, C.byref(sid)))
+        filt = (_Filter * max(len(chain), 1))()
+        for i, (kind, param, _) in enumerate(chain):
+            filt[i].kind, filt[i].param = kind, param
+        args = _leaf_args(sig, m._keep)
+        _lib.check(L.oddio_hip_mixer_play_chain(m._h, args[0], args[1], args[2], args[3], args[4], C.cast(filt, C.c_void_p), len(chain), C.byref(sid)))
+        for i, (_, _, control) in enumerate(chain):
+            if control is not None:
+                control._bind(m, sid.value, i)
         return Mixed(m, sid.value)
 
 

@@ -32,7 +32,8 @@ struct alignas(16) BufStatic {
     uint32_t n_wrap;        // filters, innermost first
     uint32_t wrap_kind[MAX_WRAP];
     float wrap_param[MAX_WRAP];   // FixedGain: linear gain
-    uint32_t pad[3];
+    uint32_t channels;      // 1 (mono) or 2 (interleaved stereo clip; Mixer general path only)
+    uint32_t pad[2];
 };
 static_assert(sizeof(BufStatic) == 96, "BufStatic layout");
 
@@ -60,28 +61,62 @@ __device__ __forceinline__ float f32_rem_euclid(float a, float b) {   // core f3
 }
 
 // ---- the inner signal: leaf + filter chain, Signal::sample(interval, out[0..n]) -----------------
+// `out` holds n frames of C = s.channels interleaved floats.
+__device__ __forceinline__ float clip_ch(const float* clip, uint32_t len, uint32_t C, uint32_t ch, long long i) {
+    return (i >= 0 && i < (long long)len) ? clip[(size_t)i * C + ch] : 0.0f;   // frames.rs:105-123
+}
+
 __device__ void leaf_sample(const BufStatic& s, SrcDyn& d, float interval, float* out, uint32_t n) {
+    const uint32_t C = s.channels ? s.channels : 1u;
     if (s.kind == KIND_FRAMES) {   // frames.rs:176-201
         const double s0 = d.t * (double)s.clip_rate;
         const float ds = interval * (float)s.clip_rate;
         const long long base = f64_as_isize(s0);
         if (fabsf(ds - 1.0f) <= FLT_EPSILON) {
             const float fract = (float)(s0 - (double)base);
-            for (uint32_t i = 0; i < n; ++i) {
-                const float a = clip_at(s.clip, s.clip_len, base + (long long)i), b = clip_at(s.clip, s.clip_len, base + (long long)i + 1);
-                out[i] = a + fract * (b - a);
-            }
+            for (uint32_t i = 0; i < n; ++i)
+                for (uint32_t ch = 0; ch < C; ++ch) {
+                    const float a = clip_ch(s.clip, s.clip_len, C, ch, base + (long long)i), b = clip_ch(s.clip, s.clip_len, C, ch, base + (long long)i + 1);
+                    out[i * C + ch] = a + fract * (b - a);
+                }
         } else {
             float offset = (float)(s0 - (double)base);
             for (uint32_t i = 0; i < n; ++i) {
                 const long long tr = (long long)offset;
                 const float fract = offset - (float)tr;
-                const float a = clip_at(s.clip, s.clip_len, base + tr), b = clip_at(s.clip, s.clip_len, base + tr + 1);
-                out[i] = a + fract * (b - a);
+                for (uint32_t ch = 0; ch < C; ++ch) {
+                    const float a = clip_ch(s.clip, s.clip_len, C, ch, base + tr), b = clip_ch(s.clip, s.clip_len, C, ch, base + tr + 1);
+                    out[i * C + ch] = a + fract * (b - a);
+                }
                 offset = offset + ds;
             }
         }
         d.t = d.t + (double)interval * (double)n;
+    } else if (s.kind == KIND_CYCLE) {   // cycle.rs:26-53 ; d.t is the cursor in samples
+        const size_t len = s.clip_len;
+        const float ds = interval * (float)s.clip_rate;
+        size_t base = (size_t)f64_as_isize(d.t);
+        float offset = (float)(d.t - (double)base);
+        for (uint32_t i = 0; i < n; ++i) {
+            const size_t trunc = (size_t)offset;
+            const float fract = offset - (float)trunc;
+            const size_t x = base + trunc;
+            size_t ia, ib;
+            if (x < len - 1) { ia = x; ib = x + 1; }
+            else if (x < len) { ia = x; ib = 0; }
+            else {
+                base = 0;
+                offset = (float)(x % len) + fract;
+                const size_t x2 = (size_t)offset;
+                if (x2 < len - 1) { ia = x2; ib = x2 + 1; } else { ia = x2; ib = 0; }
+            }
+            for (uint32_t ch = 0; ch < C; ++ch) {
+                const float a = s.clip[ia * C + ch], b = s.clip[ib * C + ch];
+                out[i * C + ch] = a + fract * (b - a);
+            }
+            offset = offset + ds;
+        }
+        d.t = (double)base + (double)offset;
     } else if (s.kind == KIND_SINE) {   // sine.rs:34-40
         for (uint32_t i = 0; i < n; ++i) {
             const float t = interval * (float)i;
@@ -89,12 +124,13 @@ __device__ void leaf_sample(const BufStatic& s, SrcDyn& d, float interval, float
         }
         d.phase = fmodf(d.phase + (interval * (float)n) * s.freq_or_value, ODDIO_TAU);
     } else {   // constant.rs:16-18
-        for (uint32_t i = 0; i < n; ++i) out[i] = s.freq_or_value;
+        for (uint32_t i = 0; i < n * C; ++i) out[i] = s.freq_or_value;
     }
 }
 
 __device__ void inner_sample(const BufStatic& s, BufDyn& d, float interval, float* out, uint32_t n) {
     // interval as each filter level sees it (outermost first); Speed rescales it on the way in
+    const uint32_t C = s.channels ? s.channels : 1u;
     float level_interval[MAX_WRAP];
     float cur = interval;
     for (int w = (int)s.n_wrap - 1; w >= 0; --w) {
@@ -105,7 +141,7 @@ __device__ void inner_sample(const BufStatic& s, BufDyn& d, float interval, floa
     for (uint32_t w = 0; w < s.n_wrap; ++w) {
         if (s.wrap_kind[w] == WRAP_FIXED_GAIN) {                      // gain.rs:32-37
             const float g = s.wrap_param[w];
-            for (uint32_t i = 0; i < n; ++i) out[i] = out[i] * g;
+            for (uint32_t i = 0; i < n * C; ++i) out[i] = out[i] * g;
         } else if (s.wrap_kind[w] == WRAP_GAIN) {                     // gain.rs:103-122
             const float shared = d.shared[w];
             if (d.sm_next[w] != shared) {                             // Smoothed::set, smooth.rs:57-64
@@ -115,12 +151,12 @@ __device__ void inner_sample(const BufStatic& s, BufDyn& d, float interval, floa
             }
             if (d.sm_progress[w] == 1.0f) {
                 const float g = d.sm_prev[w] + d.sm_progress[w] * (d.sm_next[w] - d.sm_prev[w]);
-                if (g != 1.0f) for (uint32_t i = 0; i < n; ++i) out[i] = out[i] * g;
+                if (g != 1.0f) for (uint32_t i = 0; i < n * C; ++i) out[i] = out[i] * g;
             } else {
                 const float step = level_interval[w] / 0.1f;          // SMOOTHING_PERIOD, gain.rs:163
                 for (uint32_t i = 0; i < n; ++i) {
                     const float g = d.sm_prev[w] + d.sm_progress[w] * (d.sm_next[w] - d.sm_prev[w]);
-                    out[i] = out[i] * g;
+                    for (uint32_t ch = 0; ch < C; ++ch) out[i * C + ch] = out[i * C + ch] * g;
                     d.sm_progress[w] = fminf(d.sm_progress[w] + step, 1.0f);   // Smoothed::advance, smooth.rs:47-49
                 }
             }

@@ -11,7 +11,7 @@
 
 namespace oddio_hip {
 
-enum : uint32_t { KIND_FRAMES = 0, KIND_SINE = 1, KIND_CONSTANT = 2 };
+enum : uint32_t { KIND_FRAMES = 0, KIND_SINE = 1, KIND_CONSTANT = 2, KIND_CYCLE = 3 };   // CYCLE: general (thread-per-source) paths only
 enum : uint32_t { DYN_HAS_FINISHED_FOR = 1u, DYN_STOPPED = 2u };
 enum : uint32_t { PEND_FRESH = 1u, PEND_DISCONTINUITY = 2u };
 enum : uint32_t { EAR_SKIP = 1u };

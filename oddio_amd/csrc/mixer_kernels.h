@@ -3,6 +3,7 @@
 // Mixer's 1024-frame staging chunk (mixer.rs:77) as the unit: one tile == one chunk.
 #pragma once
 #include "kernels.h"
+#include "buffered_kernels.h"
 
 namespace oddio_hip {
 
@@ -273,6 +274,81 @@ __global__ __launch_bounds__(1024) void mixer_reduce(const float* __restrict__ p
         for (uint32_t k = 1; k < nseg; ++k) t = t + red[k][ox];
         out[o] = postfx_apply(t, postfx);
     }
+}
+
+// ---- general path: any leaf (FramesSignal mono/stereo, Sine, Constant, Cycle) inside any chain of
+// FixedGain / Gain / Speed filters.  One thread per source replays Mixer::sample's per-source work
+// (mixer.rs:100-117) through the filter chain into the source's own slab; mixer_general_reduce then
+// adds the slabs in reverse slot order (bit-identical sum order).  Correctness first, not tuned.
+__global__ __launch_bounds__(64) void mixer_general_sources(uint32_t n_sources, uint32_t n_frames, float interval,
+                                                            const BufStatic* __restrict__ st, BufDyn* __restrict__ dyn,
+                                                            float* __restrict__ slabs, uint32_t* __restrict__ skip,
+                                                            uint32_t* __restrict__ stopped_hdr, uint32_t stopped_cap) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_sources) return;
+    BufDyn d = dyn[i];
+    const BufStatic s = st[i];
+    if (d.common.flags & MIXDYN_STOPPED) { skip[i] = 1; return; }
+    bool fin = (d.common.flags & MIXDYN_STOP_REQUESTED) != 0;                                                   // mixer.rs:102
+    if (s.kind == KIND_FRAMES) fin = fin || d.common.t >= (double)(s.clip_len - 1u) / (double)s.clip_rate;      // frames.rs:204-206
+    if (fin) {
+        d.common.flags |= MIXDYN_STOPPED;
+        const uint32_t k = atomicAdd(&stopped_hdr[0], 1u);
+        if (k < stopped_cap) stopped_hdr[1 + k] = d.common.id;
+        skip[i] = 1;
+        dyn[i] = d;
+        return;
+    }
+    skip[i] = 0;
+    const uint32_t C = s.channels ? s.channels : 1u;
+    float* my = slabs + (size_t)i * 2 * n_frames;
+    for (uint32_t done = 0; done < n_frames; done += 1024u) {                                                   // mixer.rs:109-117
+        const uint32_t len = (n_frames - done) < 1024u ? (n_frames - done) : 1024u;
+        inner_sample(s, d, interval, my + (size_t)done * C, len);
+    }
+    dyn[i] = d;
+}
+
+__global__ void mixer_general_reduce(const float* __restrict__ slabs, const uint32_t* __restrict__ skip, const BufStatic* __restrict__ st,
+                                     uint32_t n_sources, uint32_t n_frames, float* __restrict__ out, int postfx) {
+    const uint32_t o = blockIdx.x * blockDim.x + threadIdx.x;
+    if (o >= 2 * n_frames) return;
+    const uint32_t f = o >> 1, ch = o & 1;
+    float s = 0.0f;
+    for (uint32_t i = n_sources; i-- > 0;) {
+        if (skip[i]) continue;
+        const float* my = slabs + (size_t)i * 2 * n_frames;
+        const float v = (st[i].channels == 2) ? my[2 * f + ch] : my[f];   // MonoToStereo: duplicate (signal.rs:73-80)
+        s = s + v;                                                          // frame::mix, mixer.rs:114-116
+    }
+    out[o] = postfx_apply(s, postfx);
+}
+
+// fast representation -> general representation (when the first filtered / cycle / stereo source arrives)
+__global__ void mixer_convert_to_general(uint32_t n, const MixStatic* __restrict__ ms, const MixDyn* __restrict__ md,
+                                         BufStatic* __restrict__ bs, BufDyn* __restrict__ bd) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    BufStatic s = {};
+    s.clip = ms[i].clip; s.clip_len = ms[i].clip_len; s.clip_rate = ms[i].clip_rate; s.freq_or_value = ms[i].freq_or_value;
+    s.kind = ms[i].kind; s.channels = 1;
+    if (ms[i].fixed_gain != 1.0f) { s.n_wrap = 1; s.wrap_kind[0] = WRAP_FIXED_GAIN; s.wrap_param[0] = ms[i].fixed_gain; }
+    BufDyn d = {};
+    d.common.t = md[i].t; d.common.phase = md[i].phase; d.common.flags = md[i].flags; d.common.id = md[i].id;
+    for (int w = 0; w < MAX_WRAP; ++w) { d.shared[w] = 1.0f; d.sm_prev[w] = 1.0f; d.sm_next[w] = 1.0f; d.sm_progress[w] = 1.0f; }
+    bs[i] = s;
+    bd[i] = d;
+}
+
+__global__ void mixer_general_request_stop(const uint32_t* __restrict__ slots, uint32_t n, BufDyn* dyn) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dyn[slots[i]].common.flags |= MIXDYN_STOP_REQUESTED;
+}
+__global__ void mixer_general_apply_moves(const BufMove* __restrict__ mv, uint32_t n, BufStatic* st, BufDyn* dyn) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    st[mv[i].dst] = st[mv[i].src];
+    dyn[mv[i].dst] = dyn[mv[i].src];
 }
 
 struct MixerMove { uint32_t dst, src; };

@@ -62,20 +62,21 @@ struct DeviceGuard {
 struct oddio_hip_frames {
     int device = 0;
     uint32_t rate = 0;
-    size_t len = 0;
+    size_t len = 0;          // frames
+    uint32_t channels = 1;   // 1: Frames<f32>; 2: Frames<[f32;2]> (interleaved), Mixer general path only
     float* dev = nullptr;
     bool owned = true;
     std::atomic<int> refs{1};
 };
 
-static int frames_alloc(int device, uint32_t rate, size_t len, oddio_hip_frames** out) {
+static int frames_alloc(int device, uint32_t rate, size_t len, uint32_t channels, oddio_hip_frames** out) {
     if (!out) return fail(ODDIO_HIP_EINVAL, "out is NULL");
     if (len == 0) return fail(ODDIO_HIP_EINVAL, "empty clip (the reference panics in Frames::get_pair, frames.rs:111)");
     if (len > 0x7fffff00u) return fail(ODDIO_HIP_EINVAL, "clip too long (%zu samples)", len);
     if (rate == 0) return fail(ODDIO_HIP_EINVAL, "rate must be > 0");
     auto* f = new oddio_hip_frames();
-    f->device = device; f->rate = rate; f->len = len;
-    const size_t padded = (len + 3) & ~size_t(3);
+    f->device = device; f->rate = rate; f->len = len; f->channels = channels;
+    const size_t padded = (len * channels + 3) & ~size_t(3);
     DeviceGuard g(device);
     if (!g.ok) { delete f; return fail(ODDIO_HIP_ENODEV, "hipSetDevice(%d) failed", device); }
     hipError_t e = hipMalloc(&f->dev, padded * sizeof(float));
@@ -89,10 +90,22 @@ static int frames_alloc(int device, uint32_t rate, size_t len, oddio_hip_frames*
 extern "C" int oddio_hip_frames_from_slice(int device, uint32_t rate, const float* samples, size_t len, oddio_hip_frames** out) {
     if (!samples && len) return fail(ODDIO_HIP_EINVAL, "samples is NULL");
     oddio_hip_frames* f = nullptr;
-    int rc = frames_alloc(device, rate, len, &f);
+    int rc = frames_alloc(device, rate, len, 1, &f);
     if (rc) return rc;
     DeviceGuard g(device);
     hipError_t e = hipMemcpy(f->dev, samples, len * sizeof(float), hipMemcpyHostToDevice);
+    if (e != hipSuccess) { (void)hipFree(f->dev); delete f; return fail((int)e, "hipMemcpy H2D: %s", hipGetErrorString(e)); }
+    *out = f;
+    return 0;
+}
+
+extern "C" int oddio_hip_frames_from_slice_stereo(int device, uint32_t rate, const float* interleaved, size_t n_frames, oddio_hip_frames** out) {
+    if (!interleaved && n_frames) return fail(ODDIO_HIP_EINVAL, "samples is NULL");
+    oddio_hip_frames* f = nullptr;
+    int rc = frames_alloc(device, rate, n_frames, 2, &f);
+    if (rc) return rc;
+    DeviceGuard g(device);
+    hipError_t e = hipMemcpy(f->dev, interleaved, 2 * n_frames * sizeof(float), hipMemcpyHostToDevice);
     if (e != hipSuccess) { (void)hipFree(f->dev); delete f; return fail((int)e, "hipMemcpy H2D: %s", hipGetErrorString(e)); }
     *out = f;
     return 0;
@@ -102,7 +115,7 @@ extern "C" int oddio_hip_frames_from_device(int device, uint32_t rate, const flo
     if (!dev_samples || !out) return fail(ODDIO_HIP_EINVAL, "NULL argument");
     if (copy) {
         oddio_hip_frames* f = nullptr;
-        int rc = frames_alloc(device, rate, len, &f);
+        int rc = frames_alloc(device, rate, len, 1, &f);
         if (rc) return rc;
         DeviceGuard g(device);
         hipError_t e = hipMemcpy(f->dev, dev_samples, len * sizeof(float), hipMemcpyDeviceToDevice);
@@ -352,6 +365,7 @@ extern "C" int oddio_hip_scene_play_frames(oddio_hip_scene* s, oddio_hip_frames*
                                            const float position[3], const float velocity[3], float radius, uint32_t* source_id) {
     if (!s || !frames) return fail(ODDIO_HIP_EINVAL, "NULL argument");
     if (frames->device != s->device) return fail(ODDIO_HIP_EINVAL, "frames live on device %d, scene on %d", frames->device, s->device);
+    if (frames->channels != 1) return fail(ODDIO_HIP_EINVAL, "spatial scenes take mono clips (Frame = Sample, spatial.rs:291)");
     SrcStatic st = {};
     st.clip = frames->dev; st.clip_len = (uint32_t)frames->len; st.clip_rate = frames->rate;
     st.fixed_gain = db_to_gain(fixed_gain_db); st.kind = KIND_FRAMES;
@@ -366,7 +380,7 @@ extern "C" int oddio_hip_scene_play_frames_batch(oddio_hip_scene* s, size_t n, o
         std::lock_guard<std::mutex> lk(s->mu);
         if (s->live_count + n > s->max_sources) return fail(ODDIO_HIP_ENOMEM, "scene would overflow (max_sources = %u)", s->max_sources);
         for (size_t i = 0; i < n; ++i)
-            if (!frames[i] || frames[i]->device != s->device) return fail(ODDIO_HIP_EINVAL, "frames[%zu] invalid", i);
+            if (!frames[i] || frames[i]->device != s->device || frames[i]->channels != 1) return fail(ODDIO_HIP_EINVAL, "frames[%zu] invalid", i);
         s->live_count += n;
         s->pending_plays.reserve(s->pending_plays.size() + n);
         s->handles.reserve(s->handles.size() + n);
@@ -574,8 +588,13 @@ extern "C" int oddio_hip_scene_play_buffered(oddio_hip_scene* s, int leaf_kind, 
     if (leaf_kind == (int)KIND_FRAMES) {
         if (!frames) return fail(ODDIO_HIP_EINVAL, "frames is NULL");
         if (frames->device != s->device) return fail(ODDIO_HIP_EINVAL, "frames live on another device");
+        if (frames->channels != 1) return fail(ODDIO_HIP_EINVAL, "spatial scenes take mono clips");
         st.clip = frames->dev; st.clip_len = (uint32_t)frames->len; st.clip_rate = frames->rate;
         d.common.t = start_seconds;
+    } else if (leaf_kind == (int)KIND_CYCLE) {
+        if (!frames || frames->device != s->device || frames->channels != 1) return fail(ODDIO_HIP_EINVAL, "Cycle needs a mono clip on the scene device");
+        st.clip = frames->dev; st.clip_len = (uint32_t)frames->len; st.clip_rate = frames->rate;
+        d.common.t = 0.0;   // Cycle::new (cycle.rs:17-23)
     } else if (leaf_kind == (int)KIND_SINE) {
         st.freq_or_value = freq_hz_or_value * ODDIO_TAU;   // sine.rs:21
         d.common.phase = phase;
@@ -587,6 +606,7 @@ extern "C" int oddio_hip_scene_play_buffered(oddio_hip_scene* s, int leaf_kind, 
         return fail(ODDIO_HIP_EINVAL, "unknown leaf kind %d", leaf_kind);
     }
     st.kind = (uint32_t)leaf_kind;
+    st.channels = 1;
     st.n_wrap = (uint32_t)n_filters;
     for (int w = 0; w < n_filters; ++w) {
         st.wrap_kind[w] = (uint32_t)filters[w].kind;

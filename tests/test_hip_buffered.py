@@ -133,3 +133,20 @@ def test_buffered_fast_mode_tolerance():
         a, b = ref.sample_n(INTERVAL, 1024), scene.sample_n(INTERVAL, 1024)
         assert np.abs(b - a).max() <= 1e-5 * np.abs(a).max()
     scene.close()
+
+
+def test_buffered_cycle_leaf():
+    # Cycle is a valid play_buffered argument (any Signal); loops a short clip through Speed
+    oa, control, scene, ref = pair()
+    clip = synth.noise_clip(31, 0, 1234)
+    sc_h, s_h = oa.Speed.new(oa.Cycle(oa.Frames.from_slice(32000, clip)))
+    os_ = oc.Speed(oc.Cycle(oc.Frames(32000, clip)))
+    control.play_buffered(s_h, opts(oa, [6.0, 1.0, 2.0], [-4.0, 0.0, 3.0]), 80.0, 48000, 0.1)
+    ref.play_buffered(os_, opts(oc, [6.0, 1.0, 2.0], [-4.0, 0.0, 3.0]), 80.0, 48000, 0.1)
+    for cb in range(5):
+        if cb == 2:
+            sc_h.set_speed(0.75); os_.set_speed(0.75)
+        a, b = ref.sample_n(INTERVAL, 1024), scene.sample_n(INTERVAL, 1024)
+        assert np.abs(a).max() > 0 or cb == 0
+        np.testing.assert_array_equal(b, a)
+    scene.close()

@@ -90,3 +90,86 @@ def test_mixer_frames_sources(mode, n_frames):
         assert len(mixer) == len(cm)
         assert [h.is_stopped() for h in hs] == [h.is_stopped() for h in hc]
     mixer.close()
+
+
+# ---- general path: Cycle, Gain / Speed chains, stereo clips (mixer.rs + cycle.rs + gain.rs + speed.rs) ----
+
+CYCLE_FRAMES = [1.0, 2.0, 3.0]
+
+
+def _cycle_mixer(frames=CYCLE_FRAMES):
+    import oddio_amd as oa
+    control, mixer = oa.Mixer(max_sources=8, max_frames=64)
+    control.play(oa.MonoToStereo(oa.Cycle(oa.Frames.from_slice(1, frames))))
+    return mixer
+
+
+def test_cycle_kats_through_mixer():
+    # src/cycle.rs:69-122 (seek-free cases), L == R == the mono cycle
+    m = _cycle_mixer()
+    np.testing.assert_array_equal(m.sample_n(1.0, 5)[:, 0], arr(1.0, 2.0, 3.0, 1.0, 2.0))            # wrap_single
+    m.close()
+    m = _cycle_mixer()
+    buf = np.concatenate([m.sample_n(1.0, 2), m.sample_n(1.0, 3)])[:, 1]                             # wrap_multi
+    np.testing.assert_array_equal(buf, arr(1.0, 2.0, 3.0, 1.0, 2.0))
+    m.close()
+    m = _cycle_mixer()
+    buf = np.concatenate([m.sample_n(0.5, 2), m.sample_n(0.5, 6)])[:, 0]                             # wrap_fract
+    np.testing.assert_array_equal(buf, arr(1.0, 1.5, 2.0, 2.5, 3.0, 2.0, 1.0, 1.5))
+    m.close()
+    m = _cycle_mixer()
+    buf = np.concatenate([m.sample_n(10.0, 2), m.sample_n(10.0, 1)])[:, 0]                           # wrap_large_interval
+    np.testing.assert_array_equal(buf, arr(1.0, 2.0, 3.0))
+    m.close()
+
+
+def test_gain_smoothing_kat_through_mixer():
+    # src/gain.rs:171-179
+    import oddio_amd as oa
+    control, mixer = oa.Mixer(max_sources=4, max_frames=16)
+    gc, g = oa.Gain.new(oa.Constant(1.0))
+    control.play(oa.MonoToStereo(g))
+    gc.set_amplitude_ratio(5.0)
+    np.testing.assert_array_equal(mixer.sample_n(0.025, 6)[:, 0], arr(1.0, 2.0, 3.0, 4.0, 5.0, 5.0))
+    np.testing.assert_array_equal(mixer.sample_n(0.025, 6)[:, 1], arr(5.0, 5.0, 5.0, 5.0, 5.0, 5.0))
+    mixer.close()
+
+
+def test_mixer_general_vs_oracle():
+    import oddio_amd as oa
+    control, mixer = oa.Mixer(max_sources=64, max_frames=4096)
+    mixer.set_mode(oa.MODE_ORDERED)
+    cm = oc.Mixer(2)
+    hs, hc, ctl = [], [], []
+    # plain sources first (fast representation), then the ones that force the general path
+    for i in range(6):
+        clip = synth.noise_clip(13, i, 5000 + 300 * i)
+        hs.append(control.play(oa.MonoToStereo(oa.FramesSignal(oa.Frames.from_slice(48000, clip), 0.0))))
+        hc.append(cm.play(oc.MonoToStereo(oc.FramesSignal(oc.Frames(48000, clip), 0.0))))
+    ref0 = oc.run(cm, 48000, np.zeros((1024, 2), np.float32))
+    np.testing.assert_array_equal(oa.run(mixer, 48000, np.zeros((1024, 2), np.float32)), ref0)   # still the fast kernels
+    stereo = np.stack([synth.noise_clip(14, 0, 7000), synth.noise_clip(14, 1, 7000)], axis=1)
+    gcs, g_h = oa.Gain.new(oa.FramesSignal(oa.Frames.from_slice(44100, stereo), 0.0))
+    og = oc.Gain(oc.FramesSignal(oc.Frames(44100, stereo), 0.0))
+    hs.append(control.play(g_h)); hc.append(cm.play(og))
+    cyc = synth.noise_clip(15, 0, 777)
+    scs, s_h = oa.Speed.new(oa.MonoToStereo(oa.FixedGain(oa.Cycle(oa.Frames.from_slice(32000, cyc)), -4.0)))
+    osd = oc.Speed(oc.MonoToStereo(oc.FixedGain(oc.Cycle(oc.Frames(32000, cyc)), -4.0)))
+    hs.append(control.play(s_h)); hc.append(cm.play(osd))
+    gc2, g2 = oa.Gain.new(oa.MonoToStereo(oa.Constant(0.25)))
+    og2 = oc.Gain(oc.MonoToStereo(oc.Constant(0.25)))
+    hs.append(control.play(g2)); hc.append(cm.play(og2))
+    for cb in range(7):
+        n = (1024, 700, 2500, 1024, 1024, 1024, 512)[cb]
+        if cb == 1:
+            gcs.set_gain(-9.0); og.set_gain(-9.0)
+            scs.set_speed(1.25); osd.set_speed(1.25)
+        if cb == 3:
+            gc2.set_amplitude_ratio(3.0); og2.set_amplitude_ratio(3.0)
+            hs[2].stop(); hc[2].stop()
+        got = oa.run(mixer, 48000, np.zeros((n, 2), np.float32))
+        ref = oc.run(cm, 48000, np.zeros((n, 2), np.float32))
+        np.testing.assert_array_equal(got, ref)
+        assert len(mixer) == len(cm)
+        assert [h.is_stopped() for h in hs] == [h.is_stopped() for h in hc]
+    mixer.close()
