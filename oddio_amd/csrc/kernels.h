@@ -120,7 +120,7 @@ __device__ __forceinline__ long long f64_as_isize(double x) {
 __global__ __launch_bounds__(256) void spatial_prepass(SceneParams P, const SrcStatic* __restrict__ st,
                                                        SrcDyn* __restrict__ dyn, SrcPending* __restrict__ pend,
                                                        EarParams* __restrict__ ear, uint32_t* __restrict__ stopped_hdr,
-                                                       uint32_t stopped_cap) {
+                                                       uint32_t stopped_cap, int check_pending) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= P.n_sources) return;
     SrcDyn d = dyn[i];
@@ -137,14 +137,18 @@ __global__ __launch_bounds__(256) void spatial_prepass(SceneParams P, const SrcS
     V3 tvel = {d.tgt_vel[0], d.tgt_vel[1], d.tgt_vel[2]};
     V3 ppos = {d.prev_pos[0], d.prev_pos[1], d.prev_pos[2]};
     // spatial.rs:216-226 motion.refresh()
-    const SrcPending pm = pend[i];
-    if (pm.flags & PEND_FRESH) {
-        V3 npos = {pm.pos[0], pm.pos[1], pm.pos[2]};
-        V3 nvel = {pm.vel[0], pm.vel[1], pm.vel[2]};
-        ppos = (pm.flags & PEND_DISCONTINUITY) ? npos : smoothed_position(ppos, d.state_dt, 0.0f, tpos, tvel);
-        tpos = npos; tvel = nvel;
-        d.state_dt = 0.0f;
-        pend[i].flags = 0;
+    // (the host passes check_pending == 0 when no set_motion has been flushed since every pending
+    // slot was last consumed: saves 32 B/source of reads)
+    if (check_pending) {
+        const SrcPending pm = pend[i];
+        if (pm.flags & PEND_FRESH) {
+            V3 npos = {pm.pos[0], pm.pos[1], pm.pos[2]};
+            V3 nvel = {pm.vel[0], pm.vel[1], pm.vel[2]};
+            ppos = (pm.flags & PEND_DISCONTINUITY) ? npos : smoothed_position(ppos, d.state_dt, 0.0f, tpos, tvel);
+            tpos = npos; tvel = nvel;
+            d.state_dt = 0.0f;
+            pend[i].flags = 0;
+        }
     }
     const Quat prev_rot = {P.prev_rot[0], P.prev_rot[1], P.prev_rot[2], P.prev_rot[3]};
     const Quat rot = {P.rot[0], P.rot[1], P.rot[2], P.rot[3]};

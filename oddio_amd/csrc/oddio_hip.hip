@@ -778,6 +778,7 @@ static int scene_sample_impl(oddio_hip_scene* s, float interval, float* host_out
     if (rc) return rc;
 
     // ---- set.update(): drain control messages (set.rs:141-168) ----
+    bool motion_applied = false;   // a seekable source got a fresh Motion this callback
     std::vector<PendingPlay> plays;
     std::vector<PendingPlayB> plays_b;
     std::vector<PendingControl> controls;
@@ -884,6 +885,7 @@ static int scene_sample_impl(oddio_hip_scene* s, float interval, float* host_out
             HIP_TRY(hipGetLastError());
         }
         if (!ups.empty()) {
+            motion_applied = true;
             HIP_TRY(hipMemcpyAsync(s->d_motion, ups.data(), ups.size() * sizeof(MotionUpdate), hipMemcpyHostToDevice, s->stream));
             HIP_TRY(hipStreamSynchronize(s->stream));
             const uint32_t n = (uint32_t)ups.size();
@@ -909,7 +911,7 @@ static int scene_sample_impl(oddio_hip_scene* s, float interval, float* host_out
     if (prof) HIP_TRY(hipEventRecord(pev[0], s->stream));
     if (s->len > 0) {
         hipLaunchKernelGGL(spatial_prepass, dim3((s->len + 255) / 256), dim3(256), 0, s->stream, P, s->d_static, s->d_dyn, s->d_pend,
-                           s->d_ear, s->d_stopped[r], STOPPED_CAP);
+                           s->d_ear, s->d_stopped[r], STOPPED_CAP, motion_applied ? 1 : 0);
         HIP_TRY(hipGetLastError());
     }
     const float* init = nullptr;
