@@ -187,3 +187,55 @@ def test_play_during_run_and_empty_scene():
     ref, got, ob, hb = run_pair(spec, 1024, 5, mode=1, events=events, max_sources=16)
     np.testing.assert_array_equal(got, ref)
     hb.close()
+
+
+def test_long_run_drift_fast_mode():
+    # 60 callbacks (1.28 s of audio): cursor bookkeeping (f64 clock + the rounded f32 seeks of
+    # spatial.rs:449,465,468) must not drift from the reference; motion updates every 7th callback
+    spec = scenario.random_spec(91, 512, clip_len=80000, noise=False)
+    ob = scenario.play_all(scenario.OracleBackend(), spec)
+    hb = scenario.play_all(scenario.HipBackend(max_sources=512, max_frames=1024, mode=0), spec)
+    rng = np.random.default_rng(5)
+    for cb in range(60):
+        if cb % 7 == 3:
+            for j in rng.integers(0, 512, size=40):
+                p = (spec["sources"][j]["pos"] + rng.normal(size=3).astype(np.float32) * np.float32(0.3)).astype(np.float32)
+                ob.handles[j].set_motion(p, spec["sources"][j]["vel"], False)
+                hb.handles[j].set_motion(p, spec["sources"][j]["vel"], False)
+        ref = ob.sample(INTERVAL, 1024)
+        got = hb.sample(INTERVAL, 1024)
+        assert np.abs(got - ref).max() <= 1e-5 * np.abs(ref).max(), cb
+    hb.close()
+
+
+def test_capacity_and_error_codes():
+    import oddio_amd as oa
+    from oddio_amd._lib import OddioHipError
+    control, scene = oa.SpatialScene(max_sources=2, max_frames=64)
+    fr = oa.Frames.from_slice(48000, np.ones(100, np.float32))
+    control.play(oa.FramesSignal(fr, 0.0), oa.SpatialOptions())
+    control.play(oa.FramesSignal(fr, 0.0), oa.SpatialOptions())
+    with pytest.raises(OddioHipError) as e:
+        control.play(oa.FramesSignal(fr, 0.0), oa.SpatialOptions())
+    assert e.value.code == -2                      # ODDIO_HIP_ENOMEM: scene is full
+    with pytest.raises(OddioHipError) as e:
+        scene.sample_n(INTERVAL, 65)
+    assert e.value.code == -2                      # n_frames > max_frames
+    with pytest.raises(OddioHipError):
+        oa.Frames.from_slice(48000, np.zeros(0, np.float32))   # empty clip rejected
+    with pytest.raises(TypeError):
+        control.play(oa.Gain(oa.FramesSignal(fr, 0.0)), oa.SpatialOptions())   # Gain is not Seek
+    out = scene.sample_n(INTERVAL, 64)
+    assert np.isfinite(out).all()
+    scene.close()
+
+
+def test_source_at_listener_and_huge_distance():
+    # distance < 1e-3 branch of EarState::new (spatial.rs:537-538) and a source 100 km away
+    srcs = []
+    for pos in ([0.0, 0.0, 0.0], [1e-4, 0.0, 0.0], [1.0e5, 0.0, 0.0], [0.1075, 0.0, 0.0]):
+        srcs.append({"kind": "frames", "clip": synth.noise_clip(61, len(srcs), 30000), "rate": 48000, "start": 0.3,
+                     "pos": np.array(pos, np.float32), "vel": np.zeros(3, np.float32), "radius": 0.1, "gain_db": None})
+    ref, got, ob, hb = run_pair({"sources": srcs}, 1024, 3, mode=1)
+    np.testing.assert_array_equal(got, ref)
+    hb.close()
