@@ -8,7 +8,7 @@
 // Kernels
 //   spatial_prepass   1 thread / source   walk_set + EarState + cursor bookkeeping
 //                                         (spatial.rs:191-265, :445-469 scalar part, :501-549)
-//   spatial_mix       1 wave  / 8 sources per step; the per-sample loop
+//   spatial_mix       4-wave workgroups, 16 sources per wave-group; the per-sample loop
 //                                         (spatial.rs:456-463 + frames.rs:176-201 + sine.rs:34-40)
 //   reduce_stage1/2   fixed-order sum of the workgroup partial tiles + Reinhard/Tanh epilogue
 //                                         (reinhard.rs:32, tanh.rs:26)
@@ -17,13 +17,18 @@
 //   FramesSignal's slow path advances its f32 cursor by a *sequentially rounded* `offset += ds`
 //   (frames.rs:189-196) restarted from the f64 clock every <=256-frame chunk (spatial.rs:456).
 //   A closed form offset0 + k*ds is not within tolerance, so the running sum must
-//   be reproduced exactly.  Phase A: 64 lanes = 8 sources x 2 ears x 4 chunks each run the exact
-//   255-step f32 scan once and leave 16 checkpoints (every 16 frames) in LDS.  Phase B: for one
-//   source at a time, lane l owns output frames 16l..16l+15 (both ears, 32 register accumulators),
-//   restarts from its checkpoint and replays 15 exact adds.  The source's sample window
-//   (~N*ds + 32 floats) is staged once, coalesced (16 B/lane), into LDS with one pad float per
-//   16 samples (lane stride 17 => conflict-free ds_read2_b32), zero-filled outside the clip so that
-//   frames.rs:105-123 `get_pair` needs no branches.
+//   be reproduced exactly.  A tile is 512 output frames (two 256-frame chunks).
+//   Phase A: 64 lanes = 16 sources x 2 ears x 2 chunks each run the exact 255-step f32 scan once
+//   and leave 16 checkpoints (every 16 frames) in xor-swizzled LDS.
+//   Phase B: for one source at a time, lanes 0-31 are the left ear and 32-63 the right ear; lane l
+//   owns 16 consecutive output frames of its ear (16 register accumulators), restarts from its
+//   checkpoint and replays 15 exact adds.  The source's sample window (~N*ds + 32 floats) is
+//   fetched one source ahead with bounds-checked 16 B buffer loads (out-of-clip reads return 0, so
+//   frames.rs:105-123 `get_pair` needs no branches), staged into LDS, and read back as
+//   ds_read2_b32 pairs.  Windows with |ds-1| < PAD_EPS use a layout with one pad float per 16
+//   samples so that the near-unit lane stride does not alias LDS banks.
+//   The 4 waves of a workgroup sum their register tiles through LDS in fixed order and write one
+//   planar partial tile per workgroup; DESIGN.md section 3 has the byte and cycle accounting.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <float.h>
