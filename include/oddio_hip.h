@@ -88,7 +88,11 @@ int oddio_hip_scene_destroy(oddio_hip_scene* scene);
  *   FramesSignal::new(frames, start_seconds)  (src/frames.rs:156-169), optionally wrapped in
  *   FixedGain::new(.., gain_db) (src/gain.rs:18-23; pass NAN for "no FixedGain wrapper");
  *   Sine::new(phase, frequency_hz)            (src/sine.rs:18-23);
- *   Constant::new(value)                      (src/constant.rs).
+ *   Constant::new(value)                      (src/constant.rs);
+ *   Cycle::new(frames)                        (src/cycle.rs:17-23; Seek: src/cycle.rs:56-61), optionally
+ *   inside FixedGain.  A Cycle's cursor is a serial rounding chain through both ears
+ *   (src/cycle.rs:52 inside src/spatial.rs:446-468), so it is rendered one thread per source; at most
+ *   1024 per scene (environment ODDIO_HIP_MAX_CYCLE), ODDIO_HIP_ENOMEM beyond that.
  * `*source_id` is the handle (== the returned `Spatial`). */
 int oddio_hip_scene_play_frames(oddio_hip_scene* scene, oddio_hip_frames* frames,
                                 double start_seconds, float fixed_gain_db, const float position[3],
@@ -98,6 +102,9 @@ int oddio_hip_scene_play_sine(oddio_hip_scene* scene, float phase, float frequen
                               const float velocity[3], float radius, uint32_t* source_id);
 int oddio_hip_scene_play_constant(oddio_hip_scene* scene, float value, const float position[3],
                                   const float velocity[3], float radius, uint32_t* source_id);
+int oddio_hip_scene_play_cycle(oddio_hip_scene* scene, oddio_hip_frames* frames, float fixed_gain_db,
+                               const float position[3], const float velocity[3], float radius,
+                               uint32_t* source_id);
 /* Bulk form of play_frames for large scenes: n sources, arrays of length n (positions and
  * velocities are [n][3]); ids receives n handles (may be NULL). */
 int oddio_hip_scene_play_frames_batch(oddio_hip_scene* scene, size_t n,

@@ -98,8 +98,8 @@ class FramesSignal(Signal):
 
 
 class Cycle(Signal):
-    """Cycle::new(frames) (src/cycle.rs:17-23): loops a clip end to end.  Device support: buffered
-    spatial sources and Mixer chains (the general, one-thread-per-source paths)."""
+    """Cycle::new(frames) (src/cycle.rs:17-23): loops a clip end to end.  Seek (src/cycle.rs:56-61):
+    playable in a spatial scene through `play` and `play_buffered`, and in Mixer chains."""
 
     def __init__(self, frames: Frames):
         self.frames = frames
@@ -260,9 +260,9 @@ def _unwrap(signal):
     if isinstance(signal, (Gain, Speed)) or (isinstance(signal, FixedGain)):
         raise TypeError("Gain / Speed are not Seek (src/gain.rs:53-57, src/speed.rs): use play_buffered; "
                         "nested FixedGain needs play_buffered too")
-    if not isinstance(signal, (FramesSignal, Sine, Constant)):
+    if not isinstance(signal, (FramesSignal, Sine, Constant, Cycle)):
         raise TypeError(f"{type(signal).__name__} is not implemented on the device path "
-                        "(supported: FramesSignal, Sine, Constant, FixedGain around them)")
+                        "(supported: FramesSignal, Cycle, Sine, Constant, FixedGain around them)")
     return signal, db
 
 
@@ -394,6 +394,11 @@ class SpatialSceneControl:
             _lib.check(L.oddio_hip_scene_play_frames(s._h, leaf.frames._h, leaf.start_seconds, db, _fp(pos), _fp(vel), np.float32(options.radius), C.byref(sid)))
         elif isinstance(leaf, Sine):
             _lib.check(L.oddio_hip_scene_play_sine(s._h, leaf.phase, leaf.frequency_hz, db, _fp(pos), _fp(vel), np.float32(options.radius), C.byref(sid)))
+        elif isinstance(leaf, Cycle):
+            if leaf.frames.channels != 1:
+                raise TypeError("signals in a spatial scene must be single-channel (src/spatial.rs:278-279)")
+            s._keep.append(leaf.frames)
+            _lib.check(L.oddio_hip_scene_play_cycle(s._h, leaf.frames._h, db, _fp(pos), _fp(vel), np.float32(options.radius), C.byref(sid)))
         else:
             _lib.check(L.oddio_hip_scene_play_constant(s._h, leaf.value, _fp(pos), _fp(vel), np.float32(options.radius), C.byref(sid)))
         return Spatial(s, sid.value)

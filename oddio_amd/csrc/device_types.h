@@ -11,7 +11,10 @@
 
 namespace oddio_hip {
 
-enum : uint32_t { KIND_FRAMES = 0, KIND_SINE = 1, KIND_CONSTANT = 2, KIND_CYCLE = 3 };   // CYCLE: general (thread-per-source) paths only
+// KIND_CYCLE: Mixer general path and the buffered set sample it thread-per-source; in the Seek set it is
+// rendered serially by `cycle_sources` into a contribution row that the mix kernel adds in set order
+// (SrcStatic::freq_or_value holds the row index as raw bits, SrcDyn::t the cursor in samples).
+enum : uint32_t { KIND_FRAMES = 0, KIND_SINE = 1, KIND_CONSTANT = 2, KIND_CYCLE = 3 };
 enum : uint32_t { DYN_HAS_FINISHED_FOR = 1u, DYN_STOPPED = 2u };
 enum : uint32_t { PEND_FRESH = 1u, PEND_DISCONTINUITY = 2u };
 enum : uint32_t { EAR_SKIP = 1u };
@@ -54,6 +57,8 @@ struct alignas(16) EarParams {
     float g0;               // prev_state.gain
     float dg;               // d_gain (spatial.rs:453)
     float phase_ear;        // Sine phase after seek(prev_state.offset)
+                            // (KIND_CYCLE: phase_ear = prev_state.offset, t_ear = effective_elapsed; the
+                            //  cursor itself is advanced by cycle_sources)
     uint32_t flags;         // EAR_SKIP: source stopped / not mixed this callback
     uint32_t pad;
 };
@@ -66,6 +71,9 @@ struct SceneParams {
     float elapsed;          // interval * N as f32 (spatial.rs:394)
     uint32_t n_frames;
     uint32_t n_sources;     // live slots
+    float* cycle_rows;      // Seek-set Cycle contribution rows: [row][ear][cycle_plane] (null: none played)
+    uint32_t cycle_plane;   // floats per ear plane (= max_frames)
+    uint32_t pad;
 };
 
 // Mixer<[f32;2]> of MonoToStereo<mono source> (mixer.rs, signal.rs:61-91)

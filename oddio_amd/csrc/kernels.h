@@ -212,12 +212,79 @@ __global__ __launch_bounds__(256) void spatial_prepass(SceneParams P, const SrcS
                 d.phase = fmodf(d.phase + (dt * (float)len) * fr, ODDIO_TAU);   // sine.rs:39
             }
             d.phase = fmodf(d.phase + back * fr, ODDIO_TAU);
+        } else if (s.kind == KIND_CYCLE) {
+            ep.phase_ear = off0;                        // cycle_sources replays the seeks around the chunks
+            ep.t_ear = (double)eff;
         }
         ear[2 * i + e] = ep;
     }
     if (s.kind == KIND_FRAMES) d.t = d.t + (double)elapsed;                                     // :468
     else if (s.kind == KIND_SINE) d.phase = fmodf(d.phase + elapsed * s.freq_or_value, ODDIO_TAU);
     dyn[i] = d;
+}
+
+__device__ __forceinline__ double f64_rem_euclid(double a, double b) {   // core f64::rem_euclid
+    const double r = fmod(a, b);
+    return r < 0.0 ? r + fabs(b) : r;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Cycle in the Seek set (cycle.rs:26-60 inside spatial.rs:446-468), one thread per slot.
+// Cycle::sample leaves `cursor = base + offset` with the f32-accumulated offset, and the scene
+// seeks it back and forth between the ears, so every chunk's start depends on the rounding of all
+// the chunks before it (left ear first): the source is rendered serially.  The thread writes the
+// source's finished contribution s * gain (spatial.rs:459-460) to its row; spatial_mix adds the row
+// at the source's place in the set walk, so ORDERED mode stays bit-exact.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void cycle_sources(SceneParams P, const SrcStatic* __restrict__ st, SrcDyn* __restrict__ dyn,
+                                                    const EarParams* __restrict__ ear) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= P.n_sources) return;
+    const SrcStatic s = st[i];
+    if (s.kind != KIND_CYCLE) return;
+    const EarParams e0 = ear[2 * i], e1 = ear[2 * i + 1];
+    if (e0.flags & EAR_SKIP) return;
+    double cursor = dyn[i].t;
+    const double rate = (double)s.clip_rate, lenf = (double)s.clip_len;
+    const size_t len = s.clip_len;
+    const uint32_t n = P.n_frames;
+    float* row = P.cycle_rows + (size_t)__float_as_uint(s.freq_or_value) * 2u * P.cycle_plane;
+    for (int e = 0; e < 2; ++e) {
+        const EarParams ep = e ? e1 : e0;
+        const float off0 = ep.phase_ear, eff = (float)ep.t_ear;
+        float* plane = row + (size_t)e * P.cycle_plane;
+        cursor = f64_rem_euclid(cursor + (double)off0 * rate, lenf);          // spatial.rs:449 -> cycle.rs:57-60
+        const float ds = ep.dt * (float)s.clip_rate;                          // cycle.rs:27
+        uint32_t frame = 0;
+        for (uint32_t done = 0; done < n; done += 256u) {                     // spatial.rs:456
+            const uint32_t len_c = (n - done) < 256u ? (n - done) : 256u;
+            size_t base = (size_t)f64_as_isize(cursor);                       // cycle.rs:28
+            float offset = (float)(cursor - (double)base);                    // :29
+            for (uint32_t k = 0; k < len_c; ++k, ++frame) {
+                const size_t trunc = (size_t)offset;
+                const float fract = offset - (float)trunc;
+                const size_t x = base + trunc;
+                size_t ia, ib;
+                if (x < len - 1) { ia = x; ib = x + 1; }
+                else if (x < len) { ia = x; ib = 0; }
+                else {
+                    base = 0;
+                    offset = (float)(x % len) + fract;
+                    const size_t x2 = (size_t)offset;
+                    if (x2 < len - 1) { ia = x2; ib = x2 + 1; } else { ia = x2; ib = 0; }
+                }
+                const float a = s.clip[ia], b = s.clip[ib];
+                float v = a + fract * (b - a);                                // frame::lerp
+                v = v * s.fixed_gain;                                         // FixedGain, gain.rs:32-37
+                plane[frame] = v * (ep.g0 + (float)frame * ep.dg);            // spatial.rs:459-460
+                offset = offset + ds;
+            }
+            cursor = (double)base + (double)offset;                           // cycle.rs:52
+        }
+        cursor = f64_rem_euclid(cursor + (double)(-eff - off0) * rate, lenf); // spatial.rs:465
+    }
+    cursor = f64_rem_euclid(cursor + (double)P.elapsed * rate, lenf);         // spatial.rs:468
+    dyn[i].t = cursor;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -260,7 +327,7 @@ constexpr int WIN_VECS = WIN_CAP / 256;      // float4 loads per lane covering W
 #endif
 constexpr float PAD_EPS = ODDIO_PAD_EPS;           // |ds - 1| below this: lanes' runs sit 16 samples apart -> padded layout
 
-enum : int { PATH_SKIP = 0, PATH_LDS = 1, PATH_GENERIC = 2, PATH_SINE = 3, PATH_CONST = 4 };
+enum : int { PATH_SKIP = 0, PATH_LDS = 1, PATH_GENERIC = 2, PATH_SINE = 3, PATH_CONST = 4, PATH_ROW = 5 };
 
 // LDS map of one wave (bytes)
 //   WIN   the source's sample window, one copy.  General sources: plain (sample s at 4*s), pairs
@@ -477,6 +544,13 @@ __device__ __noinline__ void mix_source_analytic(float* acc_lds, int lane, float
     }
 }
 
+// Seek-set Cycle: the contribution was rendered by cycle_sources; add it at this source's position
+__device__ __noinline__ void mix_source_row(float* acc_lds, int lane, uint32_t frame0, uint32_t n_frames, const float* plane) {
+#pragma unroll 1
+    for (int i = 0; i < 16; ++i)
+        if (frame0 + (uint32_t)i < n_frames) acc_lds[i * 64 + lane] = acc_lds[i * 64 + lane] + plane[frame0 + (uint32_t)i];
+}
+
 // grid = (n_workgroups, n_tiles); block = 64 * MIX_WG_WAVES.  Wave w walks groups [g_lo, g_hi) of
 // 16 slots in DESCENDING order (the reference's reverse set walk, spatial.rs:204).  A workgroup
 // leaves ONE partial tile: partials[(tile * n_wgs + wg) * 1024 + e * 512 + f] (planar L | R).
@@ -595,6 +669,7 @@ __global__ __launch_bounds__(64 * MIX_WG_WAVES, MIX_WAVES_PER_SIMD) void spatial
         if (live) {
             if (ss.kind == KIND_SINE) path = PATH_SINE;
             else if (ss.kind == KIND_CONSTANT) path = PATH_CONST;
+            else if (ss.kind == KIND_CYCLE) path = PATH_ROW;
             else if (generic) path = PATH_GENERIC;
             else if (lo > hi) path = PATH_SKIP;      // no frames in this tile
             else path = (count <= WIN_CAP) ? PATH_LDS : PATH_GENERIC;
@@ -667,6 +742,9 @@ __global__ __launch_bounds__(64 * MIX_WG_WAVES, MIX_WAVES_PER_SIMD) void spatial
                     const double t_ear = eB ? rl_d(ep.t_ear, laR) : rl_d(ep.t_ear, laL);
                     mix_source_generic(park, lane, fbase, frame0, n_frames, cB_abs, rl_ptr(ss.clip, laL), (uint32_t)rl_i((int)ss.clip_len, laL),
                                        (uint32_t)rl_i((int)ss.clip_rate, laL), pe.w, t_ear, dt, pe.x, pe.y);
+                } else if (path_j == PATH_ROW) {
+                    const uint32_t row = (uint32_t)rl_i(__float_as_int(ss.freq_or_value), laL);
+                    mix_source_row(park, lane, frame0, n_frames, P.cycle_rows + ((size_t)row * 2u + (uint32_t)eB) * P.cycle_plane);
                 } else {
                     const float ph = eB ? rl_f(ep.phase_ear, laR) : rl_f(ep.phase_ear, laL);
                     mix_source_analytic(park, lane, fbase, frame0, n_frames, cB_abs, path_j == PATH_SINE ? 1 : 0, rl_f(ss.freq_or_value, laL), pe.w,
@@ -812,6 +890,7 @@ __global__ void seek_all_kernel(SrcDyn* __restrict__ dyn, const SrcStatic* __res
     if (i >= n) return;
     if (st[i].kind == KIND_FRAMES) dyn[i].t = dyn[i].t + (double)seconds;                              // frames.rs:211-213
     else if (st[i].kind == KIND_SINE) dyn[i].phase = fmodf(dyn[i].phase + seconds * st[i].freq_or_value, ODDIO_TAU);
+    else if (st[i].kind == KIND_CYCLE) dyn[i].t = f64_rem_euclid(dyn[i].t + (double)seconds * (double)st[i].clip_rate, (double)st[i].clip_len);
 }
 
 }  // namespace oddio_hip

@@ -221,6 +221,11 @@ struct oddio_hip_scene {
     std::vector<PendingControl> pending_controls;
     size_t live_count_b = 0;
     std::vector<float*> ring_garbage;      // rings of removed sources, freed off the audio thread
+    // Seek-set Cycle sources: contribution rows, allocated by the control thread on first use
+    float* d_cycle_rows = nullptr;
+    uint32_t cycle_cap = 0, cycle_next = 0;
+    std::vector<uint32_t> cycle_free;      // rows of removed sources
+    uint32_t cycle_live = 0;               // Cycle sources in the Seek set (audio thread)
     MotionUpdate* d_motion = nullptr;
     SlotMove* d_moves = nullptr;
     // pinned staging
@@ -259,7 +264,7 @@ static int scene_free(oddio_hip_scene* s) {
     (void)hipFree(s->d_static); (void)hipFree(s->d_dyn); (void)hipFree(s->d_pend); (void)hipFree(s->d_ear);
     (void)hipFree(s->d_partials); (void)hipFree(s->d_out); (void)hipFree(s->d_stage1);
     (void)hipFree(s->d_bstatic); (void)hipFree(s->d_bdyn); (void)hipFree(s->d_bpend); (void)hipFree(s->d_contrib); (void)hipFree(s->d_bskip);
-    (void)hipFree(s->d_outb); (void)hipFree(s->d_bmoves); (void)hipFree(s->d_ctrl);
+    (void)hipFree(s->d_outb); (void)hipFree(s->d_bmoves); (void)hipFree(s->d_ctrl); (void)hipFree(s->d_cycle_rows);
     for (auto& h : s->handles) if (h.ring) { (void)hipFree(h.ring); h.ring = nullptr; }
     for (float* r : s->ring_garbage) (void)hipFree(r); (void)hipFree(s->d_motion); (void)hipFree(s->d_moves);
     for (int r = 0; r < RING; ++r) {
@@ -418,6 +423,38 @@ extern "C" int oddio_hip_scene_play_constant(oddio_hip_scene* s, float value, co
     SrcStatic st = {};
     st.freq_or_value = value; st.fixed_gain = 1.0f; st.kind = KIND_CONSTANT;
     return scene_play_common(s, st, 0.0, 0.0f, nullptr, position, velocity, radius, source_id);
+}
+
+constexpr uint32_t CYCLE_ROWS_DEFAULT = 1024;   // Seek-set Cycle sources per scene (ODDIO_HIP_MAX_CYCLE overrides)
+
+extern "C" int oddio_hip_scene_play_cycle(oddio_hip_scene* s, oddio_hip_frames* frames, float fixed_gain_db,
+                                          const float position[3], const float velocity[3], float radius, uint32_t* source_id) {
+    if (!s || !frames) return fail(ODDIO_HIP_EINVAL, "NULL argument");
+    if (frames->device != s->device) return fail(ODDIO_HIP_EINVAL, "frames live on device %d, scene on %d", frames->device, s->device);
+    if (frames->channels != 1) return fail(ODDIO_HIP_EINVAL, "spatial scenes take mono clips (Frame = Sample, spatial.rs:291)");
+    uint32_t row;
+    {
+        std::lock_guard<std::mutex> lk(s->mu);
+        if (!s->d_cycle_rows) {   // control thread, never inside sample()
+            uint32_t cap = std::min(CYCLE_ROWS_DEFAULT, s->max_sources);
+            if (const char* e = getenv("ODDIO_HIP_MAX_CYCLE")) { long v = atol(e); if (v > 0) cap = (uint32_t)std::min<long>(v, s->max_sources); }
+            DeviceGuard g(s->device);
+            if (!g.ok) return fail(ODDIO_HIP_ENODEV, "hipSetDevice(%d) failed", s->device);
+            hipError_t e = hipMalloc(&s->d_cycle_rows, (size_t)cap * 2 * s->max_frames * sizeof(float));
+            if (e != hipSuccess) { s->d_cycle_rows = nullptr; return fail(ODDIO_HIP_ENOMEM, "hipMalloc(cycle rows): %s", hipGetErrorString(e)); }
+            s->cycle_cap = cap;
+        }
+        if (!s->cycle_free.empty()) { row = s->cycle_free.back(); s->cycle_free.pop_back(); }
+        else if (s->cycle_next < s->cycle_cap) row = s->cycle_next++;
+        else return fail(ODDIO_HIP_ENOMEM, "too many Cycle sources in the Seek set (%u); raise ODDIO_HIP_MAX_CYCLE or use play_buffered", s->cycle_cap);
+    }
+    SrcStatic st = {};
+    st.clip = frames->dev; st.clip_len = (uint32_t)frames->len; st.clip_rate = frames->rate;
+    st.fixed_gain = db_to_gain(fixed_gain_db); st.kind = KIND_CYCLE;
+    memcpy(&st.freq_or_value, &row, sizeof(row));
+    int rc = scene_play_common(s, st, 0.0, 0.0f, frames, position, velocity, radius, source_id);   // Cycle::new: cursor 0 (cycle.rs:17-23)
+    if (rc) { std::lock_guard<std::mutex> lk(s->mu); s->cycle_free.push_back(row); }
+    return rc;
 }
 
 extern "C" int oddio_hip_source_set_motion(oddio_hip_scene* s, uint32_t id, const float position[3], const float velocity[3], int discontinuity) {
@@ -805,6 +842,7 @@ static int scene_sample_impl(oddio_hip_scene* s, float interval, float* host_out
             std::lock_guard<std::mutex> lk(s->mu);
             for (size_t i = 0; i < k; ++i) {
                 hs[i] = plays[i].st; hd[i] = plays[i].dyn;
+                if (hs[i].kind == KIND_CYCLE) s->cycle_live++;
                 const uint32_t slot = first + (uint32_t)i;
                 s->id_of_slot[slot] = plays[i].id;
                 HandleRec& h = s->handles[plays[i].id];
@@ -903,6 +941,9 @@ static int scene_sample_impl(oddio_hip_scene* s, float interval, float* host_out
     P.elapsed = interval * (float)n_frames;   // spatial.rs:394
     P.n_frames = (uint32_t)n_frames;
     P.n_sources = s->len;
+    P.cycle_rows = s->d_cycle_rows;
+    P.cycle_plane = s->max_frames;
+    P.pad = 0;
 
     float* out_dev = dev_out ? dev_out : s->d_out;
     const bool prof = s->profiling && !s->ev_prof.empty();
@@ -913,6 +954,10 @@ static int scene_sample_impl(oddio_hip_scene* s, float interval, float* host_out
         hipLaunchKernelGGL(spatial_prepass, dim3((s->len + 255) / 256), dim3(256), 0, s->stream, P, s->d_static, s->d_dyn, s->d_pend,
                            s->d_ear, s->d_stopped[r], STOPPED_CAP, motion_applied ? 1 : 0);
         HIP_TRY(hipGetLastError());
+        if (s->cycle_live > 0) {
+            hipLaunchKernelGGL(cycle_sources, dim3((s->len + 63) / 64), dim3(64), 0, s->stream, P, s->d_static, s->d_dyn, s->d_ear);
+            HIP_TRY(hipGetLastError());
+        }
     }
     const float* init = nullptr;
     if (s->len_b > 0) {

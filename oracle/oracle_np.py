@@ -139,6 +139,14 @@ def constant_source(value):
     return {"kind": "constant", "value": f32(value)}
 
 
+def cycle_source(rate, samples, fixed_gain_db=None):
+    """Cycle::new (src/cycle.rs:17-23): cursor (f64, in samples) starts at 0."""
+    s = {"kind": "cycle", "rate": int(rate), "samples": np.asarray(samples, dtype=f32), "cursor": f64(0.0)}
+    if fixed_gain_db is not None:
+        s["fixed_gain"] = powf(10.0, f32(fixed_gain_db) / f32(20.0))
+    return s
+
+
 def _gather_pair(samples, idx):
     """pair(i) = (S(i), S(i+1)) with S(i) = samples[i] inside the clip, 0 outside."""
     n = samples.shape[0]
@@ -178,6 +186,28 @@ def src_sample(src, interval, n):
         src["phase"] = fmodf(src["phase"] + (interval * f32(n)) * src["freq"], TAU)
     elif kind == "constant":
         out = np.full(n, src["value"], dtype=f32)
+    elif kind == "cycle":
+        # src/cycle.rs:26-53.  The f32 offset restarts whenever the read position passes the end of
+        # the clip, so the loop is written frame by frame (numpy scalars: every op rounds to f32).
+        smp = src["samples"]
+        length = len(smp)
+        ds = interval * f32(src["rate"])
+        base = int(src["cursor"])                       # `as usize`: toward zero, cursor >= 0
+        offset = f32(src["cursor"] - f64(base))
+        out = np.zeros(n, dtype=f32)
+        for i in range(n):
+            tr = int(offset)
+            fract = offset - f32(tr)
+            x = base + tr
+            if x >= length:
+                base = 0
+                offset = f32(x % length) + fract
+                x = int(offset)
+            a = smp[x]
+            b = smp[x + 1] if x < length - 1 else smp[0]
+            out[i] = a + fract * (b - a)
+            offset = offset + ds
+        src["cursor"] = f64(base) + f64(offset)
     else:
         raise ValueError(kind)
     if "fixed_gain" in src:
@@ -191,6 +221,10 @@ def src_seek(src, seconds):
         src["t"] = src["t"] + f64(seconds)
     elif src["kind"] == "sine":
         src["phase"] = fmodf(src["phase"] + seconds * src["freq"], TAU)
+    elif src["kind"] == "cycle":                        # src/cycle.rs:57-60, f64::rem_euclid
+        length = f64(len(src["samples"]))
+        r = np.fmod(src["cursor"] + f64(seconds) * f64(src["rate"]), length)
+        src["cursor"] = r + length if r < 0 else r
 
 
 def src_is_finished(src):

@@ -23,7 +23,7 @@ import scenario  # noqa: E402
 from oddio_amd import synth  # noqa: E402
 from oracle import oracle_np as on  # noqa: E402
 
-KIND_ID = {"frames": 0, "sine": 1, "constant": 2}
+KIND_ID = {"frames": 0, "sine": 1, "constant": 2, "cycle": 3}
 
 
 def pack(spec, events, n_frames, n_callbacks, interval, postfx, outputs):
@@ -60,6 +60,8 @@ def numpy_render(spec, events, n_frames, n_callbacks, interval, postfx):
     for s in spec["sources"]:
         if s["kind"] == "frames":
             src = on.frames_source(s["rate"], s["clip"], s["start"], fixed_gain_db=s.get("gain_db"))
+        elif s["kind"] == "cycle":
+            src = on.cycle_source(s["rate"], s["clip"], fixed_gain_db=s.get("gain_db"))
         elif s["kind"] == "sine":
             src = on.sine_source(s["phase"], s["hz"], fixed_gain_db=s.get("gain_db"))
         else:
@@ -117,6 +119,11 @@ def main():
              "pos": np.array([2.0 + i, 0.5, -1.0], np.float32), "vel": np.array([-25.0, 4.0, 9.0], np.float32), "radius": 0.1, "gain_db": None}
             for i, r in enumerate((44100, 22050, 96000))]
     make("resample_reinhard", {"sources": srcs}, {}, 512, 3, postfx=1)
+    # 5. Cycle sources in the Seek set (short loops wrap many times per callback) between FramesSignals
+    spec = scenario.random_spec(1005, 5, kinds=("cycle", "frames", "cycle"), gain_db=(None, None, -4.0), clip_len=5200, cube=8.0, start=0.05, cycle_len=150)
+    spec["sources"][2]["clip"] = spec["sources"][2]["clip"][:7]
+    ev = {1: [("motion", 0, spec["sources"][0]["pos"] + np.float32(0.7), spec["sources"][0]["vel"], False)]}
+    make("cycle_in_scene", spec, ev, 700, 3)
 
 
 if __name__ == "__main__":

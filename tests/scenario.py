@@ -11,7 +11,7 @@ from oddio_amd import synth
 
 
 def random_spec(seed, n_src, kinds=("frames",), clip_len=24000, rate=48000, start=0.3, gain_db=(None,),
-                cube=50.0, vmax=20.0, noise=True):
+                cube=50.0, vmax=20.0, noise=True, cycle_len=1000):
     sc = synth.make_scene(seed, n_src, cube=cube, vmax=vmax)
     sources = []
     for i in range(n_src):
@@ -22,6 +22,9 @@ def random_spec(seed, n_src, kinds=("frames",), clip_len=24000, rate=48000, star
             src["clip"] = synth.noise_clip(seed, i, clip_len) if noise else synth.sine_clip(sc["freq_hz"][i], clip_len, rate)
             src["rate"] = rate
             src["start"] = start
+        elif kind == "cycle":
+            src["clip"] = synth.noise_clip(seed, i, cycle_len) if noise else synth.sine_clip(sc["freq_hz"][i], cycle_len, rate)
+            src["rate"] = rate
         elif kind == "sine":
             src["phase"] = float(sc["phase"][i])
             src["hz"] = float(sc["freq_hz"][i])
@@ -46,6 +49,8 @@ class OracleBackend:
         oc = self.oc
         if src["kind"] == "frames":
             sig = oc.FramesSignal(oc.Frames(src["rate"], src["clip"]), src["start"])
+        elif src["kind"] == "cycle":
+            sig = oc.Cycle(oc.Frames(src["rate"], src["clip"]))
         elif src["kind"] == "sine":
             sig = oc.Sine(src["phase"], src["hz"])
         else:
@@ -91,6 +96,11 @@ class HipBackend:
             if key not in self._clips:
                 self._clips[key] = oa.Frames.from_slice(src["rate"], src["clip"])
             sig = oa.FramesSignal(self._clips[key], src["start"])
+        elif src["kind"] == "cycle":
+            key = id(src["clip"])
+            if key not in self._clips:
+                self._clips[key] = oa.Frames.from_slice(src["rate"], src["clip"])
+            sig = oa.Cycle(self._clips[key])
         elif src["kind"] == "sine":
             sig = oa.Sine(src["phase"], src["hz"])
         else:

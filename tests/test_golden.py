@@ -11,7 +11,7 @@ import pytest
 import scenario
 
 GOLDEN = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "*.npz")))
-KINDS = {0: "frames", 1: "sine", 2: "constant"}
+KINDS = {0: "frames", 1: "sine", 2: "constant", 3: "cycle"}
 
 
 def load(path):
@@ -26,6 +26,9 @@ def load(path):
             s["clip"] = z["clip_data"][z["clip_offsets"][i]:z["clip_offsets"][i + 1]].copy()
             s["rate"] = int(z["rate"][i])
             s["start"] = float(z["start"][i])
+        elif kind == "cycle":
+            s["clip"] = z["clip_data"][z["clip_offsets"][i]:z["clip_offsets"][i + 1]].copy()
+            s["rate"] = int(z["rate"][i])
         elif kind == "sine":
             s["phase"], s["hz"] = float(z["phase"][i]), float(z["hz"][i])
         else:
@@ -40,7 +43,7 @@ def load(path):
 
 
 def test_fixtures_exist():
-    assert len(GOLDEN) >= 4
+    assert len(GOLDEN) >= 5
 
 
 @pytest.mark.parametrize("path", GOLDEN, ids=[os.path.basename(p)[:-4] for p in GOLDEN])

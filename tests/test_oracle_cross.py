@@ -12,7 +12,7 @@ from oracle import oracle_c as oc
 from oracle import oracle_np as on
 
 
-def build_pair(seed, n_src, kinds, clip_len=22000, rate=48000, start=0.3, gain_db=None):
+def build_pair(seed, n_src, kinds, clip_len=22000, rate=48000, start=0.3, gain_db=None, cycle_len=500):
     sc = synth.make_scene(seed, n_src)
     cs, ns = oc.SpatialScene(), on.Scene()
     hc, hn = [], []
@@ -24,6 +24,10 @@ def build_pair(seed, n_src, kinds, clip_len=22000, rate=48000, start=0.3, gain_d
             clip = synth.noise_clip(seed, i, clip_len)
             sig = oc.FramesSignal(oc.Frames(rate, clip), start)
             nsrc = on.frames_source(rate, clip, start, fixed_gain_db=db)
+        elif kind == "cycle":
+            clip = synth.noise_clip(seed, i, cycle_len)
+            sig = oc.Cycle(oc.Frames(rate, clip))
+            nsrc = on.cycle_source(rate, clip, fixed_gain_db=db)
         elif kind == "sine":
             sig = oc.Sine(sc["phase"][i], sc["freq_hz"][i])
             nsrc = on.sine_source(sc["phase"][i], sc["freq_hz"][i], fixed_gain_db=db)
@@ -47,6 +51,17 @@ def test_scene_frames_bit_equal(seed, n_src, n_frames):
         b = ns.sample(interval, n_frames)
         np.testing.assert_array_equal(a, b)
         assert np.abs(a).max() > 0 or cb > 2
+
+
+@pytest.mark.parametrize("cycle_len,n_frames", [(500, 1024), (3, 300), (1, 64), (40000, 700)])
+def test_scene_cycle_bit_equal(cycle_len, n_frames):
+    # Cycle in the Seek set (cycle.rs:26-61 under spatial.rs:446-468): two transcriptions must agree
+    sc, cs, ns, hc, hn = build_pair(20 + cycle_len, 4, ["cycle", "frames", "cycle"], gain_db=[None, None, -5.0], cycle_len=cycle_len)
+    interval = np.float32(1.0) / np.float32(48000)
+    for cb in range(3):
+        a = cs.sample_n(interval, n_frames)
+        b = ns.sample(interval, n_frames)
+        np.testing.assert_array_equal(a, b)
 
 
 def test_scene_mixed_kinds_motion_rotation():
