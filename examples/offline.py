@@ -11,7 +11,6 @@ side; the scene is rendered in 512-frame blocks with `oddio::run` semantics and 
 import argparse
 import os
 import sys
-import wave
 
 import numpy as np
 
@@ -42,13 +41,9 @@ def main():
     args = ap.parse_args()
     import oddio_amd as oa
     out = render(oa, lambda: oa.SpatialScene(max_sources=8, max_frames=BLOCK_SIZE))
-    pcm = np.clip(out * np.float32(32767.0), -32768, 32767).astype(np.int16)   # Rust `as i16` saturates
-    with wave.open(args.out, "wb") as w:
-        w.setnchannels(2)
-        w.setsampwidth(2)
-        w.setframerate(RATE)
-        w.writeframes(pcm.tobytes())
-    print(f"wrote {args.out}: {len(pcm)} frames, peak {np.abs(out).max():.4f}")
+    from oddio_amd import wav
+    wav.write_wav(args.out, RATE, out)                     # (sample * i16::MAX as f32) as i16, offline.rs:38
+    print(f"wrote {args.out}: {len(out)} frames, peak {np.abs(out).max():.4f}")
     if args.check:
         from oracle import oracle_c as oc
 

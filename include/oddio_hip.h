@@ -155,6 +155,14 @@ int oddio_hip_source_release(oddio_hip_scene* scene, uint32_t source_id);
 /* FramesSignalControl::playback_position (src/frames.rs:238-240), as of the last sample call. */
 int oddio_hip_source_playback_position(oddio_hip_scene* scene, uint32_t source_id, double* seconds);
 
+/* Adapt::new(scene, initial_rms, AdaptOptions{tau, max_gain, low, high}) (src/adapt.rs:25-31, :36-61;
+ * the filter itself :63-87): adaptive gain that keeps the running RMS of the (channel-summed) output
+ * inside [low, high].  Applied on the device to the scene's stereo sum BEFORE the Reinhard/Tanh post
+ * filter, i.e. the composition is Reinhard::new(Adapt::new(scene, ..)) as src/adapt.rs:7-9 recommends.
+ * Calling it (re)starts the filter state at initial_rms^2; enable = 0 removes the filter.  Call it
+ * while no `sample` is in flight (it is a constructor in the reference). */
+int oddio_hip_scene_set_adapt(oddio_hip_scene* scene, int enable, float initial_rms, float tau,
+                              float max_gain, float low, float high);
 /* SpatialSceneControl::set_listener_rotation (src/spatial.rs:345-349); stores the inverse. */
 int oddio_hip_scene_set_listener_rotation(oddio_hip_scene* scene, const float rotation_sxyz[4]);
 
@@ -232,6 +240,9 @@ int oddio_hip_mixer_stop(oddio_hip_mixer* mixer, uint32_t source_id);
 int oddio_hip_mixer_is_stopped(oddio_hip_mixer* mixer, uint32_t source_id, int* stopped);
 int oddio_hip_mixer_len(oddio_hip_mixer* mixer, size_t* len);
 int oddio_hip_mixer_set_postfx(oddio_hip_mixer* mixer, int postfx);
+/* Adapt::new(mixer, ..): same as oddio_hip_scene_set_adapt for a Mixer (examples/adapt.rs:6-16). */
+int oddio_hip_mixer_set_adapt(oddio_hip_mixer* mixer, int enable, float initial_rms, float tau,
+                              float max_gain, float low, float high);
 int oddio_hip_mixer_set_mode(oddio_hip_mixer* mixer, int mode);
 /* Signal::sample for Mixer (src/mixer.rs:92-119) / oddio::run */
 int oddio_hip_mixer_sample(oddio_hip_mixer* mixer, float interval, float* out, size_t n_frames);

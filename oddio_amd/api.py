@@ -336,6 +336,10 @@ class _SceneSignal(Signal):
     def set_postfx(self, kind):
         _lib.check(_lib.lib().oddio_hip_scene_set_postfx(self._h, int(kind)))
 
+    def set_adapt(self, enable, initial_rms=0.0, options=None):
+        o = options or AdaptOptions()
+        _lib.check(_lib.lib().oddio_hip_scene_set_adapt(self._h, int(bool(enable)), np.float32(initial_rms), o.tau, o.max_gain, o.low, o.high))
+
     def set_mode(self, mode):
         _lib.check(_lib.lib().oddio_hip_scene_set_mode(self._h, int(mode)))
 
@@ -464,17 +468,52 @@ def SpatialScene(device: int = 0, max_sources: int = 4096, max_frames: int = 409
     return SpatialSceneControl(scene), scene
 
 
+class AdaptOptions:
+    """src/adapt.rs:36-61 (defaults :52-61)."""
+
+    def __init__(self, tau=0.1, max_gain=np.inf, low=None, high=None):
+        r2 = np.sqrt(np.float32(2.0))
+        self.tau, self.max_gain = np.float32(tau), np.float32(max_gain)
+        self.low = np.float32(0.1) / r2 if low is None else np.float32(low)
+        self.high = np.float32(0.5) / r2 if high is None else np.float32(high)
+
+
+class Adapt(Signal):
+    """Adapt::new(scene_or_mixer, initial_rms, options) (src/adapt.rs:25-31): device epilogue over
+    the stereo sum (one lane walks the avg_squared recurrence, the block does the rest)."""
+    channels = 2
+    seekable = False
+
+    def __init__(self, inner, initial_rms, options: AdaptOptions = None):
+        if not isinstance(inner, (_SceneSignal, _MixerSignal)):
+            raise TypeError("the device Adapt wraps a SpatialScene or a Mixer directly (Reinhard/Tanh go outside it)")
+        o = options or AdaptOptions()
+        self.inner = inner
+        inner.set_adapt(True, initial_rms, o)
+
+    def sample(self, interval, out):
+        return self.inner.sample(interval, out)
+
+    def sample_n(self, interval, n):
+        return self.inner.sample_n(interval, n)
+
+    def is_finished(self):
+        return self.inner.is_finished()
+
+
 class Reinhard(Signal):
-    """Reinhard::new(scene_or_mixer) (src/reinhard.rs): fused into the reduce kernel's epilogue."""
+    """Reinhard::new(scene_or_mixer) (src/reinhard.rs): fused into the reduce kernel's epilogue
+    (or into the Adapt epilogue for Reinhard::new(Adapt::new(..)))."""
     channels = 2
     seekable = False
     _KIND = POSTFX_REINHARD
 
     def __init__(self, inner):
-        if not isinstance(inner, (_SceneSignal, _MixerSignal)):
-            raise TypeError("device post-filters wrap a SpatialScene or a Mixer")
+        target = inner.inner if isinstance(inner, Adapt) else inner
+        if not isinstance(target, (_SceneSignal, _MixerSignal)):
+            raise TypeError("device post-filters wrap a SpatialScene, a Mixer, or an Adapt around one")
         self.inner = inner
-        inner.set_postfx(self._KIND)
+        target.set_postfx(self._KIND)
 
     def sample(self, interval, out):
         return self.inner.sample(interval, out)
@@ -528,6 +567,10 @@ class _MixerSignal(Signal):
 
     def set_postfx(self, kind):
         _lib.check(_lib.lib().oddio_hip_mixer_set_postfx(self._h, int(kind)))
+
+    def set_adapt(self, enable, initial_rms=0.0, options=None):
+        o = options or AdaptOptions()
+        _lib.check(_lib.lib().oddio_hip_mixer_set_adapt(self._h, int(bool(enable)), np.float32(initial_rms), o.tau, o.max_gain, o.low, o.high))
 
     def set_mode(self, mode):
         _lib.check(_lib.lib().oddio_hip_mixer_set_mode(self._h, int(mode)))

@@ -851,6 +851,59 @@ __global__ void postfx_kernel(float* __restrict__ buf, uint32_t n, int postfx) {
     if (i < n) buf[i] = postfx_apply(buf[i], postfx);
 }
 
+// ---------------------------------------------------------------------------------------------
+// Adapt (adapt.rs:63-87) as an epilogue over the stereo sum, followed by the Reinhard/Tanh filter:
+//   avg_squared = sample^2 * alpha + avg_squared * (1 - alpha)   -- a rounding-exact recurrence over
+// the output frames, so one lane walks it; everything around it (the channel sum, sample^2 * alpha,
+// sqrt, the gain law, the scaling and the post filter) is done by the whole block.
+// ---------------------------------------------------------------------------------------------
+struct AdaptParams { float alpha, one_minus_alpha, max_gain, low, high; };
+constexpr int ADAPT_CHUNK = 2048;
+
+__global__ __launch_bounds__(256) void adapt_kernel(float* __restrict__ buf, uint32_t n_frames, AdaptParams A,
+                                                    float* __restrict__ avg_squared, int postfx) {
+    __shared__ __attribute__((aligned(16))) float drive[ADAPT_CHUNK];
+    const uint32_t tid = threadIdx.x;
+    float avg = *avg_squared;
+    for (uint32_t base = 0; base < n_frames; base += ADAPT_CHUNK) {
+        const uint32_t cnt = (n_frames - base) < (uint32_t)ADAPT_CHUNK ? (n_frames - base) : (uint32_t)ADAPT_CHUNK;
+        for (uint32_t i = tid; i < cnt; i += 256) {
+            const float2 x = reinterpret_cast<const float2*>(buf)[base + i];
+            float sample = 0.0f;                              // x.channels().iter().sum::<f32>()
+            sample = sample + x.x;
+            sample = sample + x.y;
+            drive[i] = sample * sample * A.alpha;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            uint32_t i = 0;
+            for (; i + 8 <= cnt; i += 8) {                    // loads up front, then the dependent chain
+                float d[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) d[k] = drive[i + k];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) { avg = d[k] + avg * A.one_minus_alpha; d[k] = avg; }
+#pragma unroll
+                for (int k = 0; k < 8; ++k) drive[i + k] = d[k];
+            }
+            for (; i < cnt; ++i) { avg = drive[i] + avg * A.one_minus_alpha; drive[i] = avg; }
+        }
+        __syncthreads();
+        for (uint32_t i = tid; i < cnt; i += 256) {
+            const float avg_peak = sqrtf(drive[i]) * sqrtf(2.0f);
+            float gain = 1.0f;
+            if (avg_peak < A.low) gain = fminf(A.low / avg_peak, A.max_gain);   // f32::min: NaN-ignoring
+            else if (avg_peak > A.high) gain = A.high / avg_peak;
+            float2 x = reinterpret_cast<float2*>(buf)[base + i];
+            x.x = postfx_apply(x.x * gain, postfx);
+            x.y = postfx_apply(x.y * gain, postfx);
+            reinterpret_cast<float2*>(buf)[base + i] = x;
+        }
+        __syncthreads();
+    }
+    if (tid == 0) *avg_squared = avg;
+}
+
 __global__ void zero_kernel(float* __restrict__ buf, uint32_t n) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) buf[i] = 0.0f;

@@ -192,6 +192,40 @@ constexpr int RING = 2;
 
 }  // namespace
 
+// Adapt::new(signal, initial_rms, options) wrapped around a scene / mixer (adapt.rs:14-61)
+struct AdaptHost {
+    bool on = false;
+    float tau = 0.1f, max_gain = INFINITY, low = 0.0f, high = 0.0f;
+    float* d_state = nullptr;          // avg_squared
+};
+
+static int adapt_configure(AdaptHost& a, int device, hipStream_t stream, int enable, float initial_rms, float tau, float max_gain,
+                           float low, float high) {
+    if (!enable) { a.on = false; return 0; }
+    if (!(tau > 0.0f)) return fail(ODDIO_HIP_EINVAL, "AdaptOptions::tau must be > 0");
+    DeviceGuard g(device);
+    if (!g.ok) return fail(ODDIO_HIP_ENODEV, "hipSetDevice(%d) failed", device);
+    if (!a.d_state) HIP_TRY(hipMalloc(&a.d_state, sizeof(float)));
+    const float avg_squared = initial_rms * initial_rms;                                        // adapt.rs:28
+    HIP_TRY(hipStreamSynchronize(stream));
+    HIP_TRY(hipMemcpy(a.d_state, &avg_squared, sizeof(float), hipMemcpyHostToDevice));
+    a.tau = tau; a.max_gain = max_gain; a.low = low; a.high = high;
+    a.on = true;
+    return 0;
+}
+
+// Launches the epilogue on `buf` (interleaved stereo, raw sum) and applies `postfx` after it.
+static int adapt_launch(const AdaptHost& a, hipStream_t stream, float interval, float* buf, size_t n_frames, int postfx) {
+    if (n_frames == 0) return 0;
+    AdaptParams A;
+    A.alpha = 1.0f - expf(-interval / a.tau);                                                   // adapt.rs:70
+    A.one_minus_alpha = 1.0f - A.alpha;
+    A.max_gain = a.max_gain; A.low = a.low; A.high = a.high;
+    hipLaunchKernelGGL(adapt_kernel, dim3(1), dim3(256), 0, stream, buf, (uint32_t)n_frames, A, a.d_state, postfx);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
 struct oddio_hip_scene {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -226,6 +260,7 @@ struct oddio_hip_scene {
     uint32_t cycle_cap = 0, cycle_next = 0;
     std::vector<uint32_t> cycle_free;      // rows of removed sources
     uint32_t cycle_live = 0;               // Cycle sources in the Seek set (audio thread)
+    AdaptHost adapt;
     MotionUpdate* d_motion = nullptr;
     SlotMove* d_moves = nullptr;
     // pinned staging
@@ -264,7 +299,7 @@ static int scene_free(oddio_hip_scene* s) {
     (void)hipFree(s->d_static); (void)hipFree(s->d_dyn); (void)hipFree(s->d_pend); (void)hipFree(s->d_ear);
     (void)hipFree(s->d_partials); (void)hipFree(s->d_out); (void)hipFree(s->d_stage1);
     (void)hipFree(s->d_bstatic); (void)hipFree(s->d_bdyn); (void)hipFree(s->d_bpend); (void)hipFree(s->d_contrib); (void)hipFree(s->d_bskip);
-    (void)hipFree(s->d_outb); (void)hipFree(s->d_bmoves); (void)hipFree(s->d_ctrl); (void)hipFree(s->d_cycle_rows);
+    (void)hipFree(s->d_outb); (void)hipFree(s->d_bmoves); (void)hipFree(s->d_ctrl); (void)hipFree(s->d_cycle_rows); (void)hipFree(s->adapt.d_state);
     for (auto& h : s->handles) if (h.ring) { (void)hipFree(h.ring); h.ring = nullptr; }
     for (float* r : s->ring_garbage) (void)hipFree(r); (void)hipFree(s->d_motion); (void)hipFree(s->d_moves);
     for (int r = 0; r < RING; ++r) {
@@ -515,6 +550,10 @@ extern "C" int oddio_hip_scene_set_postfx(oddio_hip_scene* s, int postfx) {
     if (!s || postfx < 0 || postfx > 2) return fail(ODDIO_HIP_EINVAL, "bad postfx");
     s->postfx = postfx;
     return 0;
+}
+extern "C" int oddio_hip_scene_set_adapt(oddio_hip_scene* s, int enable, float initial_rms, float tau, float max_gain, float low, float high) {
+    if (!s) return fail(ODDIO_HIP_EINVAL, "NULL scene");
+    return adapt_configure(s->adapt, s->device, s->stream, enable, initial_rms, tau, max_gain, low, high);
 }
 extern "C" int oddio_hip_scene_set_mode(oddio_hip_scene* s, int mode) {
     if (!s || mode < 0 || mode > 1) return fail(ODDIO_HIP_EINVAL, "bad mode");
@@ -992,17 +1031,19 @@ static int scene_sample_impl(oddio_hip_scene* s, float interval, float* host_out
     if (prof) HIP_TRY(hipEventRecord(pev[2], s->stream));
     if (n_frames > 0) {
         const uint32_t n_out = 2u * (uint32_t)n_frames;
+        const int fused_postfx = s->adapt.on ? 0 : s->postfx;   // with Adapt the filter order is Reinhard(Adapt(scene))
         if (n_wgs > 0) {
             hipLaunchKernelGGL(reduce_stage1, dim3(((uint32_t)n_frames + 31) / 32, RED_SPLIT), dim3(256), 0, s->stream, s->d_partials, s->d_stage1,
                                n_wgs, (uint32_t)n_frames);
             hipLaunchKernelGGL(reduce_stage2, dim3((n_out + 255) / 256), dim3(256), 0, s->stream, s->d_stage1, out_dev, n_wgs,
-                               (uint32_t)n_frames, s->postfx);
+                               (uint32_t)n_frames, fused_postfx);
         } else if (init) {
-            hipLaunchKernelGGL(copy_postfx_kernel, dim3((n_out + 255) / 256), dim3(256), 0, s->stream, init, out_dev, n_out, s->postfx);
+            hipLaunchKernelGGL(copy_postfx_kernel, dim3((n_out + 255) / 256), dim3(256), 0, s->stream, init, out_dev, n_out, fused_postfx);
         } else {
             hipLaunchKernelGGL(zero_kernel, dim3((n_out + 255) / 256), dim3(256), 0, s->stream, out_dev, n_out);   // spatial.rs:389-391
         }
         HIP_TRY(hipGetLastError());
+        if (s->adapt.on) { rc = adapt_launch(s->adapt, s->stream, interval, out_dev, n_frames, s->postfx); if (rc) return rc; }
     }
     if (prof) { HIP_TRY(hipEventRecord(pev[3], s->stream)); s->prof_calls++; }
 

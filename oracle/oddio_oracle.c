@@ -234,7 +234,7 @@ void oo_ring_sample(const oo_ring* r, uint32_t rate, float t, float interval, fl
 
 enum {
     K_FRAMES, K_SINE, K_CONSTANT, K_CYCLE, K_FIXED_GAIN, K_GAIN, K_SPEED, K_MONO_TO_STEREO,
-    K_REINHARD, K_TANH, K_MIXER, K_SCENE, K_COUNTING, K_TIME, K_FINISHED
+    K_REINHARD, K_TANH, K_MIXER, K_SCENE, K_COUNTING, K_TIME, K_FINISHED, K_ADAPT
 };
 
 typedef struct { int stop; oo_signal* inner; } mixed_entry; /* mixer.rs:46-49 */
@@ -288,6 +288,8 @@ struct oo_signal {
     float gain;        /* FixedGain.gain */
     float shared;      /* Gain.shared / Speed.speed (atomics in the reference) */
     oo_smoothed smooth;
+    /* K_ADAPT, adapt.rs:14-18 + AdaptOptions :36-50 */
+    float avg_squared, tau, max_gain, low, high;
     /* fixtures */
     uint32_t counter;
     float time;
@@ -357,6 +359,14 @@ oo_signal* oo_speed_new(oo_signal* inner) { /* speed.rs:16-24 */
     return s;
 }
 oo_signal* oo_mono_to_stereo_new(oo_signal* inner) { oo_signal* s = sig_new(K_MONO_TO_STEREO, 2); s->inner = inner; return s; }
+oo_signal* oo_adapt_new(oo_signal* inner, float initial_rms, float tau, float max_gain, float low, float high) { /* adapt.rs:25-31 */
+    oo_signal* s = sig_new(K_ADAPT, inner->channels);
+    s->inner = inner;
+    s->avg_squared = initial_rms * initial_rms;
+    s->tau = tau; s->max_gain = max_gain; s->low = low; s->high = high;
+    return s;
+}
+void oo_constant_set(oo_signal* s, float v0, float v1) { s->cval[0] = v0; s->cval[1] = v1; } /* adapt.rs:127 `adapt.inner.0 = ..` */
 oo_signal* oo_reinhard_new(oo_signal* inner) { oo_signal* s = sig_new(K_REINHARD, inner->channels); s->inner = inner; return s; }
 oo_signal* oo_tanh_new(oo_signal* inner) { oo_signal* s = sig_new(K_TANH, inner->channels); s->inner = inner; return s; }
 oo_signal* oo_mixer_new(int channels) { /* mixer.rs:70-81 */
@@ -763,6 +773,22 @@ void oo_sample(oo_signal* s, float interval, float* out, size_t n) {
         oo_sample(s->inner, interval, out, n);
         for (size_t i = 0; i < n * C; i++) out[i] = tanhf(out[i]);
         break;
+    case K_ADAPT: { /* adapt.rs:69-87 */
+        const float alpha = 1.0f - expf(-interval / s->tau);
+        oo_sample(s->inner, interval, out, n);
+        for (size_t i = 0; i < n; i++) {
+            float sample = 0.0f; /* iter().sum::<f32>(): the zero's sign cannot survive the squaring below */
+            for (int c = 0; c < C; c++) sample = sample + out[i * C + c];
+            s->avg_squared = sample * sample * alpha + s->avg_squared * (1.0f - alpha);
+            const float avg_peak = sqrtf(s->avg_squared) * sqrtf(2.0f);
+            float gain;
+            if (avg_peak < s->low) { gain = s->low / avg_peak; gain = f32_min(gain, s->max_gain); }
+            else if (avg_peak > s->high) gain = s->high / avg_peak;
+            else gain = 1.0f;
+            for (int c = 0; c < C; c++) out[i * C + c] = out[i * C + c] * gain;
+        }
+        break;
+    }
     case K_MIXER: mixer_sample(s, interval, out, n); break;
     case K_SCENE: scene_sample_impl(s, interval, out, NULL, n); break;
     case K_COUNTING: /* signal.rs:101-107 */
@@ -798,7 +824,7 @@ int oo_is_finished(const oo_signal* s) {
     case K_FRAMES: /* frames.rs:204-206; (len - 1) is usize arithmetic */
         return s->t >= (double)(uint64_t)((uint64_t)s->data->len - 1) / s->data->rate;
     case K_FINISHED: return 1;
-    case K_FIXED_GAIN: case K_GAIN: case K_SPEED: case K_MONO_TO_STEREO: case K_REINHARD: case K_TANH:
+    case K_FIXED_GAIN: case K_GAIN: case K_SPEED: case K_MONO_TO_STEREO: case K_REINHARD: case K_TANH: case K_ADAPT:
         return oo_is_finished(s->inner);
     default: return 0;
     }

@@ -45,6 +45,9 @@ oo_signal* oo_fixed_gain_new(oo_signal* inner, float db);                /* gain
 oo_signal* oo_gain_new(oo_signal* inner);                                /* gain.rs:66-74 */
 oo_signal* oo_speed_new(oo_signal* inner);                               /* speed.rs:16-24 */
 oo_signal* oo_mono_to_stereo_new(oo_signal* inner);                      /* signal.rs:61-68 */
+oo_signal* oo_adapt_new(oo_signal* inner, float initial_rms, float tau, float max_gain,
+                       float low, float high);                          /* adapt.rs:25-31, :36-61 */
+void oo_constant_set(oo_signal* s, float v0, float v1);                  /* test fixture: adapt.rs:127 */
 oo_signal* oo_reinhard_new(oo_signal* inner);                            /* reinhard.rs:16-20 */
 oo_signal* oo_tanh_new(oo_signal* inner);                                /* tanh.rs:10-14 */
 oo_signal* oo_mixer_new(int channels);                                   /* mixer.rs:70-81 */

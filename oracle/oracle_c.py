@@ -48,6 +48,8 @@ def lib():
             "oo_speed_new": (vp, [vp]),
             "oo_mono_to_stereo_new": (vp, [vp]),
             "oo_reinhard_new": (vp, [vp]),
+            "oo_adapt_new": (vp, [vp, f32, f32, f32, f32, f32]),
+            "oo_constant_set": (None, [vp, f32, f32]),
             "oo_tanh_new": (vp, [vp]),
             "oo_mixer_new": (vp, [i32]),
             "oo_scene_new": (vp, []),
@@ -207,6 +209,11 @@ class Constant(Signal):
             h = lib().oo_constant_new(np.float32(value[0]), np.float32(value[1]), 2)
         super().__init__(h)
 
+    def set(self, value):
+        """`constant.0 = value` (the tests mutate the fixture in place, src/adapt.rs:127)."""
+        v = np.atleast_1d(np.asarray(value, np.float32))
+        lib().oo_constant_set(self._h, v[0], v[-1])
+
 
 class Cycle(Signal):
     def __init__(self, frames: Frames):
@@ -254,6 +261,24 @@ class Reinhard(Signal):
 class Tanh(Signal):
     def __init__(self, inner: Signal):
         super().__init__(lib().oo_tanh_new(inner._h), inner)
+
+
+class AdaptOptions:
+    """src/adapt.rs:36-61 (defaults :52-61)."""
+
+    def __init__(self, tau=0.1, max_gain=np.inf, low=None, high=None):
+        r2 = np.sqrt(np.float32(2.0))
+        self.tau, self.max_gain = np.float32(tau), np.float32(max_gain)
+        self.low = np.float32(0.1) / r2 if low is None else np.float32(low)
+        self.high = np.float32(0.5) / r2 if high is None else np.float32(high)
+
+
+class Adapt(Signal):
+    """Adapt::new(signal, initial_rms, options) (src/adapt.rs:25-31)."""
+
+    def __init__(self, inner: Signal, initial_rms, options: AdaptOptions = None):
+        o = options or AdaptOptions()
+        super().__init__(lib().oo_adapt_new(inner._h, np.float32(initial_rms), o.tau, o.max_gain, o.low, o.high), inner)
 
 
 class CountingSignal(Signal):

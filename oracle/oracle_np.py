@@ -21,7 +21,7 @@ f32 = np.float32
 f64 = np.float64
 
 _libm = ctypes.CDLL(ctypes.util.find_library("m") or "libm.so.6")
-for _n in ("sinf", "tanhf"):
+for _n in ("sinf", "tanhf", "expf"):
     getattr(_libm, _n).restype = ctypes.c_float
     getattr(_libm, _n).argtypes = [ctypes.c_float]
 for _n in ("powf", "fmodf"):
@@ -37,6 +37,10 @@ def sinf(x):
 def tanhf(x):
     x = np.asarray(x, dtype=f32)
     return np.array([_libm.tanhf(float(v)) for v in x.ravel()], dtype=f32).reshape(x.shape)
+
+
+def expf(x):
+    return f32(_libm.expf(float(f32(x))))
 
 
 def powf(a, b):
@@ -374,6 +378,39 @@ class Mixer:
 def reinhard(x):
     x = np.asarray(x, dtype=f32)
     return (x / (ONE + np.abs(x))).astype(f32)
+
+
+class Adapt:
+    """src/adapt.rs:14-87 as a filter over already-rendered frames x[n] or x[n, C] (second,
+    independent transcription: the recurrence runs on numpy scalars, the gain law is vectorised)."""
+
+    def __init__(self, initial_rms, tau=0.1, max_gain=np.inf, low=None, high=None):
+        r2 = np.sqrt(f32(2.0))
+        self.avg_squared = f32(initial_rms) * f32(initial_rms)
+        self.tau, self.max_gain = f32(tau), f32(max_gain)
+        self.low = f32(0.1) / r2 if low is None else f32(low)
+        self.high = f32(0.5) / r2 if high is None else f32(high)
+
+    def __call__(self, interval, x):
+        x = np.asarray(x, dtype=f32)
+        frames = x.reshape(len(x), -1)
+        alpha = ONE - expf(-f32(interval) / self.tau)
+        oma = ONE - alpha
+        sample = np.zeros(len(x), dtype=f32)
+        for c in range(frames.shape[1]):
+            sample = sample + frames[:, c]
+        drive = (sample * sample) * alpha
+        avg = np.empty(len(x), dtype=f32)
+        a = self.avg_squared
+        for i in range(len(x)):
+            a = drive[i] + a * oma
+            avg[i] = a
+        self.avg_squared = a
+        with np.errstate(divide="ignore", invalid="ignore"):
+            peak = np.sqrt(avg) * np.sqrt(f32(2.0))
+            up = np.where(np.isnan(self.low / peak), self.max_gain, np.minimum(self.low / peak, self.max_gain))   # f32::min ignores NaN
+            gain = np.where(peak < self.low, up, np.where(peak > self.high, self.high / peak, ONE)).astype(f32)
+            return (frames * gain[:, None]).astype(f32).reshape(x.shape)
 
 
 def tanh_clip(x):

@@ -261,3 +261,42 @@ def test_analytic_doppler_offline_example():
     vr = speed * (-px) / math.hypot(px, 10.0)
     f_exp = 500.0 * (1.0 + vr / 343.0)
     assert abs(f_obs - f_exp) / f_exp < 0.003, (f_obs, f_exp)
+
+
+# ---- src/adapt.rs:96-148 `smoke` --------------------------------------------------------------
+def test_adapt_smoke_kat():
+    LOW, HIGH, MAX_GAIN = 0.1, 1.0, 10.0
+    const = oo.Constant(0.0)
+    adapt = oo.Adapt(const, 0.0, oo.AdaptOptions(tau=0.5, low=LOW, high=HIGH, max_gain=MAX_GAIN))
+    for _ in range(10):                                   # silence isn't modified
+        assert adapt.sample_n(np.float32(0.1), 1)[0] == 0.0
+    const.set(10.0)                                       # suddenly loud
+    out = adapt.sample_n(np.float32(0.1), 10)
+    assert 0.0 < out[0] < 10.0
+    assert (out[:-1] > out[1:]).all()
+    const.set(0.01)                                       # back to quiet
+    out = adapt.sample_n(np.float32(0.1), 10)
+    assert out[0] > 0.0
+    assert (out[:-1] < out[1:]).all()
+    const.set(1e-6)                                       # super quiet: gain is capped
+    for _ in range(100):
+        out = adapt.sample_n(np.float32(0.1), 10)
+        assert (out <= np.float32(1e-6) * np.float32(MAX_GAIN)).all()
+
+
+def test_adapt_c_equals_numpy():
+    # two independent transcriptions of adapt.rs:69-87 over the same stereo material
+    from oracle import oracle_np as on
+    rng = np.random.default_rng(5)
+    env = np.concatenate([np.full(700, 1e-3), np.full(900, 0.9), np.full(600, 0.05), np.zeros(100), np.full(300, 0.3)]).astype(np.float32)
+    x = (rng.uniform(-1, 1, size=(len(env), 2)).astype(np.float32) * env[:, None]).astype(np.float32)
+    clip = oo.Frames(48000, x)
+    sig = oo.Adapt(oo.FramesSignal(clip, 0.0), 1e-3 / np.sqrt(np.float32(2.0)), oo.AdaptOptions(max_gain=1e6))
+    raw = oo.FramesSignal(clip, 0.0)                      # the same inner signal, unfiltered
+    nf = on.Adapt(1e-3 / np.sqrt(np.float32(2.0)), max_gain=1e6)
+    interval = np.float32(1.0) / np.float32(48000)
+    for n in (512, 512, 1000, 1, 575):
+        a = sig.sample_n(interval, n)
+        b = nf(interval, raw.sample_n(interval, n))
+        np.testing.assert_array_equal(a, b)
+        assert np.isfinite(a).all()
