@@ -43,7 +43,7 @@ def algorithmic_bytes(n_sources: int, n_frames: int) -> float:
     return n_sources * (4.0 * (n_frames + 32) + PARAM_BYTES) + 8.0 * n_frames
 
 
-def build_gpu_scene(device: int, n_sources: int, clip_len: int, seed: int, start_seconds: float):
+def build_gpu_scene(device: int, n_sources: int, clip_len: int, seed: int, start_seconds: float, n_clips: int = 0):
     """Clips are synthesised on the GPU (A*sin(2*pi*f*n/48000), f from the shared generator) and
     borrowed zero-copy as oddio Frames; scene parameters come from oddio_amd.synth."""
     import torch
@@ -53,20 +53,22 @@ def build_gpu_scene(device: int, n_sources: int, clip_len: int, seed: int, start
 
     sc = synth.make_scene(seed, n_sources)
     dev = torch.device("cuda", device)
-    clips = torch.empty((n_sources, clip_len), dtype=torch.float32, device=dev)
-    freq = torch.from_numpy(sc["freq_hz"]).to(dev).double()
+    n_clips = n_sources if n_clips <= 0 else min(n_clips, n_sources)   # < n_sources: source i plays clip i % n_clips
+    clips = torch.empty((n_clips, clip_len), dtype=torch.float32, device=dev)
+    freq = torch.from_numpy(sc["freq_hz"][:n_clips]).to(dev).double()
     n = torch.arange(clip_len, device=dev, dtype=torch.float64)
     chunk = max(1, (1 << 28) // clip_len)
-    for s0 in range(0, n_sources, chunk):
-        s1 = min(n_sources, s0 + chunk)
+    for s0 in range(0, n_clips, chunk):
+        s1 = min(n_clips, s0 + chunk)
         ph = (2.0 * np.pi / RATE) * freq[s0:s1, None] * n[None, :]
         clips[s0:s1] = torch.sin(ph).float()
         del ph
     torch.cuda.synchronize(dev)
     control, scene = oa.SpatialScene(device=device, max_sources=n_sources, max_frames=N_FRAMES)
     base = clips.data_ptr()
-    frames = [oa.Frames.from_device_ptr(RATE, base + 4 * clip_len * i, clip_len, device=device, copy=False) for i in range(n_sources)]
-    handles = control.play_frames_batch(frames, np.full(n_sources, start_seconds), sc["position"], sc["velocity"], sc["radius"])
+    frames = [oa.Frames.from_device_ptr(RATE, base + 4 * clip_len * i, clip_len, device=device, copy=False) for i in range(n_clips)]
+    handles = control.play_frames_batch(frames if n_clips == n_sources else [frames[i % n_clips] for i in range(n_sources)],
+                                        np.full(n_sources, start_seconds), sc["position"], sc["velocity"], sc["radius"])
     ids = np.array([h.id for h in handles], dtype=np.uint32)
     return {"control": control, "scene": scene, "clips": clips, "frames": frames, "handles": handles, "ids": ids, "spec": sc}
 
@@ -111,6 +113,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--sources", type=int, default=262144, help="sources per GPU (config 3: 262144; config 2: 4096)")
     ap.add_argument("--clip-len", type=int, default=65536)
+    ap.add_argument("--clips", type=int, default=0,
+                    help="distinct clips (default: one per source, the BASELINE workload); fewer lets --sources exceed what 288 GB of "
+                         "own clips allows, e.g. to run AT the reported max_realtime_sources")
     ap.add_argument("--seed", type=int, default=2024)
     ap.add_argument("--mode", choices=["scenes", "sharded"], default="scenes",
                     help="N>1: 'scenes' = one independent scene per GPU (configs[3] pattern, no collective); "
@@ -140,7 +145,7 @@ def main():
 
     S, L = args.sources, args.clip_len
     start_seconds = 0.6
-    g = build_gpu_scene(device, S, L, args.seed + rank, start_seconds)
+    g = build_gpu_scene(device, S, L, args.seed + rank, start_seconds, args.clips)
     scene, control = g["scene"], g["control"]
     out = torch.zeros((N_FRAMES, 2), dtype=torch.float32, device=torch.device("cuda", device))
     interval = np.float32(1.0) / np.float32(RATE)
@@ -222,7 +227,9 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {
-                "workload": (f"BASELINE configs[2]: SpatialScene, {S} moving FramesSignal sources (own {L}-sample clip each), "
+                "workload": ((f"BASELINE configs[2]: SpatialScene, {S} moving FramesSignal sources (own {L}-sample clip each), " if args.clips <= 0 or args.clips >= S
+                              else f"real-time confirmation run: SpatialScene, {S} moving FramesSignal sources sharing {args.clips} clips of {L} samples, ")
+                             +
                              f"Doppler + propagation delay, 48 kHz stereo, {N_FRAMES}-frame callbacks"
                              + ("" if world == 1 else (f"; ONE scene of {world * S} sources in {world} index shards + RCCL reduce (configs[4] pattern)" if sharded
                                                       else f"; {world} independent scenes, one per GPU (configs[3] pattern)"))),
