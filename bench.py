@@ -53,7 +53,7 @@ def build_gpu_scene(device: int, n_sources: int, clip_len: int, seed: int, start
 
     sc = synth.make_scene(seed, n_sources)
     dev = torch.device("cuda", device)
-    n_clips = n_sources if n_clips <= 0 else min(n_clips, n_sources)   # < n_sources: source i plays clip i % n_clips
+    n_clips = n_sources if n_clips <= 0 else min(n_clips, n_sources)   # < n_sources: clips are shared, scattered
     clips = torch.empty((n_clips, clip_len), dtype=torch.float32, device=dev)
     freq = torch.from_numpy(sc["freq_hz"][:n_clips]).to(dev).double()
     n = torch.arange(clip_len, device=dev, dtype=torch.float64)
@@ -67,7 +67,11 @@ def build_gpu_scene(device: int, n_sources: int, clip_len: int, seed: int, start
     control, scene = oa.SpatialScene(device=device, max_sources=n_sources, max_frames=N_FRAMES)
     base = clips.data_ptr()
     frames = [oa.Frames.from_device_ptr(RATE, base + 4 * clip_len * i, clip_len, device=device, copy=False) for i in range(n_clips)]
-    handles = control.play_frames_batch(frames if n_clips == n_sources else [frames[i % n_clips] for i in range(n_sources)],
+    if n_clips < n_sources:
+        # scattered assignment: sources that share a clip must not be neighbours in the set walk, or
+        # their windows would hit in L2/MALL and flatter the HBM figure
+        pick = ((np.arange(n_sources, dtype=np.uint64) * np.uint64(0x9E3779B97F4A7C15)) >> np.uint64(20)) % np.uint64(n_clips)
+    handles = control.play_frames_batch(frames if n_clips == n_sources else [frames[int(k)] for k in pick],
                                         np.full(n_sources, start_seconds), sc["position"], sc["velocity"], sc["radius"])
     ids = np.array([h.id for h in handles], dtype=np.uint32)
     return {"control": control, "scene": scene, "clips": clips, "frames": frames, "handles": handles, "ids": ids, "spec": sc}
