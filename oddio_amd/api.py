@@ -292,6 +292,10 @@ class Spatial:
         _lib.check(_lib.lib().oddio_hip_source_playback_position(self._scene._h, self.id, C.byref(out)))
         return out.value
 
+    def release(self):
+        """Dropping the `Spatial` handle: the source keeps playing; its id may be reused once it is removed."""
+        _lib.check(_lib.lib().oddio_hip_source_release(self._scene._h, self.id))
+
 
 class _SceneSignal(Signal):
     """The `SpatialScene` half: implements Signal<Frame = [f32; 2]> (src/spatial.rs:373-477)."""
