@@ -113,3 +113,90 @@ def test_random_operations_bit_exact(seed):
         assert [e[0].is_finished() for e in live] == [e[1].is_finished() for e in live]
     assert clip_no >= 15 and peak_len >= 5 and removed_seen, (clip_no, peak_len, removed_seen)   # the run exercised something
     scene.close()
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_mixer_random_operations_bit_exact(seed):
+    # Mixer<[f32;2]> (src/mixer.rs:92-119): plays of mono / stereo clips, Cycle, Constant under
+    # FixedGain / Gain / Speed chains, stops, control changes, ragged callbacks; the mixer starts on
+    # its fast kernels and switches to the general path at the first source that needs it.
+    import oddio_amd as oa
+    rng = np.random.default_rng(7000 + seed)
+    control, mixer = oa.Mixer(max_sources=64, max_frames=2048)
+    mixer.set_mode(oa.MODE_ORDERED)
+    mixer.set_postfx(seed % 2)
+    cm = oc.Mixer(2)
+    ref = oc.Reinhard(cm) if seed % 2 else cm
+    live, clip_no, stops = [], 0, 0
+    for cb in range(50):
+        for _ in range(int(rng.integers(0, 4))):
+            op = rng.choice(["play", "play", "stop", "control"])
+            if op == "play" and len(live) < 48:
+                clip_no += 1
+                simple = cb < 6 and seed % 2 == 0        # keep the fast path alive for a while on even seeds
+                kind = rng.choice(["mono", "mono", "constant"] if simple else ["mono", "stereo", "cycle", "constant"])
+                rate = int(rng.choice([48000, 44100, 16000]))
+                hc, rc = [], []
+                if kind == "mono":
+                    clip = synth.noise_clip(seed, clip_no, int(rng.integers(1, 12000)))
+                    start = float(rng.uniform(-0.01, 0.01))
+                    sh, so = oa.FramesSignal(oa.Frames.from_slice(rate, clip), start), oc.FramesSignal(oc.Frames(rate, clip), start)
+                elif kind == "stereo":
+                    n = int(rng.integers(1, 9000))
+                    clip = np.stack([synth.noise_clip(seed, clip_no, n), synth.noise_clip(seed + 50, clip_no, n)], axis=1)
+                    sh, so = oa.FramesSignal(oa.Frames.from_slice(rate, clip), 0.0), oc.FramesSignal(oc.Frames(rate, clip), 0.0)
+                elif kind == "cycle":
+                    clip = synth.noise_clip(seed, clip_no, int(rng.integers(1, 900)))
+                    sh, so = oa.Cycle(oa.Frames.from_slice(rate, clip)), oc.Cycle(oc.Frames(rate, clip))
+                else:
+                    val = float(rng.uniform(-0.5, 0.5))
+                    sh, so = oa.Constant(val), oc.Constant(val)
+                if simple:
+                    if kind == "mono" and rng.random() < 0.5:
+                        db = float(rng.uniform(-10, 4))
+                        sh, so = oa.FixedGain(sh, db), oc.FixedGain(so, db)
+                    sh, so = oa.MonoToStereo(sh), oc.MonoToStereo(so)
+                else:
+                    n_filters = int(rng.integers(0, 4))
+                    lift_at = -1 if kind == "stereo" else int(rng.integers(0, n_filters + 1))   # where MonoToStereo sits in the nest
+                    for f in range(n_filters + 1):
+                        if f == lift_at:
+                            sh, so = oa.MonoToStereo(sh), oc.MonoToStereo(so)
+                        if f == n_filters:
+                            break
+                        which = rng.choice(["fixed", "gain", "speed"])
+                        if which == "fixed":
+                            db = float(rng.uniform(-10, 4))
+                            sh, so = oa.FixedGain(sh, db), oc.FixedGain(so, db)
+                        elif which == "gain":
+                            c, sh = oa.Gain.new(sh)
+                            so = oc.Gain(so)
+                            hc.append(c); rc.append(so)
+                        else:
+                            c, sh = oa.Speed.new(sh)
+                            so = oc.Speed(so)
+                            hc.append(c); rc.append(so)
+                live.append([control.play(sh), cm.play(so), hc, rc])
+            elif op == "stop" and live:
+                k = int(rng.integers(0, len(live)))
+                live[k][0].stop(); live[k][1].stop()
+                stops += 1
+            elif op == "control":
+                cands = [e for e in live if e[2]]
+                if cands:
+                    e = cands[int(rng.integers(0, len(cands)))]
+                    i = int(rng.integers(0, len(e[2])))
+                    if isinstance(e[2][i], oa.GainControl):
+                        v = float(rng.uniform(0.0, 2.0))
+                        e[2][i].set_amplitude_ratio(v); e[3][i].set_amplitude_ratio(v)
+                    else:
+                        v = float(rng.uniform(0.5, 1.6))
+                        e[2][i].set_speed(v); e[3][i].set_speed(v)
+        n = int(rng.choice([1024, 1024, 2048, 512, 1, 700, 1500]))
+        a = ref.sample_n(INTERVAL, n)
+        b = mixer.sample_n(INTERVAL, n)
+        np.testing.assert_array_equal(b, a, err_msg=f"seed {seed} callback {cb} n {n}")
+        assert len(mixer) == len(cm)
+        assert [e[0].is_stopped() for e in live] == [e[1].is_stopped() for e in live]
+    assert clip_no >= 15 and stops >= 3
+    mixer.close()
