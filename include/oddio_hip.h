@@ -102,6 +102,14 @@ int oddio_hip_scene_play_sine(oddio_hip_scene* scene, float phase, float frequen
                               const float velocity[3], float radius, uint32_t* source_id);
 int oddio_hip_scene_play_constant(oddio_hip_scene* scene, float value, const float position[3],
                                   const float velocity[3], float radius, uint32_t* source_id);
+/* play(Downmix::new(FramesSignal::new(stereo_frames, start_seconds)), options) (src/downmix.rs:8-47),
+ * optionally inside FixedGain: both channels are interpolated and summed.  `frames` must come from
+ * oddio_hip_frames_from_slice_stereo.  Like the reference's Downmix::sample (src/downmix.rs:24-29) the
+ * inner clock advances a whole 256-frame buffer per chunk, also for a short last chunk. */
+int oddio_hip_scene_play_frames_downmix(oddio_hip_scene* scene, oddio_hip_frames* frames,
+                                        double start_seconds, float fixed_gain_db,
+                                        const float position[3], const float velocity[3], float radius,
+                                        uint32_t* source_id);
 int oddio_hip_scene_play_cycle(oddio_hip_scene* scene, oddio_hip_frames* frames, float fixed_gain_db,
                                const float position[3], const float velocity[3], float radius,
                                uint32_t* source_id);

@@ -76,6 +76,7 @@ def lib():
         "oddio_hip_scene_play_constant": (i32, [vp, f32, fp, fp, f32, u32p]),
         "oddio_hip_scene_set_adapt": (i32, [vp, i32, f32, f32, f32, f32, f32]),
         "oddio_hip_mixer_set_adapt": (i32, [vp, i32, f32, f32, f32, f32, f32]),
+        "oddio_hip_scene_play_frames_downmix": (i32, [vp, vp, f64, f32, fp, fp, f32, u32p]),
         "oddio_hip_scene_play_cycle": (i32, [vp, vp, f32, fp, fp, f32, u32p]),
         "oddio_hip_scene_play_frames_batch": (i32, [vp, sz, vpp, C.POINTER(f64), fp, fp, fp, fp, u32p]),
         "oddio_hip_source_set_motion": (i32, [vp, u32, fp, fp, i32]),

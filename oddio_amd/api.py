@@ -242,6 +242,18 @@ def _unwrap_chain(signal):
     return signal, chain[::-1]
 
 
+class Downmix(Signal):
+    """Downmix::new(signal) (src/downmix.rs:8-16): sums the channels.  Device support: a stereo
+    FramesSignal played in a spatial scene (`play(Downmix(FramesSignal(stereo_frames)), ..)`)."""
+    channels = 1
+
+    def __init__(self, inner: Signal):
+        if not isinstance(inner, FramesSignal) or inner.frames.channels != 2:
+            raise TypeError("the device Downmix wraps a FramesSignal over a stereo clip")
+        self.inner = inner
+        self.seekable = True
+
+
 class MonoToStereo(Signal):
     channels = 2
 
@@ -260,9 +272,9 @@ def _unwrap(signal):
     if isinstance(signal, (Gain, Speed)) or (isinstance(signal, FixedGain)):
         raise TypeError("Gain / Speed are not Seek (src/gain.rs:53-57, src/speed.rs): use play_buffered; "
                         "nested FixedGain needs play_buffered too")
-    if not isinstance(signal, (FramesSignal, Sine, Constant, Cycle)):
+    if not isinstance(signal, (FramesSignal, Sine, Constant, Cycle, Downmix)):
         raise TypeError(f"{type(signal).__name__} is not implemented on the device path "
-                        "(supported: FramesSignal, Cycle, Sine, Constant, FixedGain around them)")
+                        "(supported: FramesSignal, Downmix of a stereo FramesSignal, Cycle, Sine, Constant, FixedGain around them)")
     return signal, db
 
 
@@ -397,7 +409,11 @@ class SpatialSceneControl:
         L, s = _lib.lib(), self._scene
         sid = C.c_uint32()
         pos, vel = _vec3(options.position), _vec3(options.velocity)
-        if isinstance(leaf, FramesSignal):
+        if isinstance(leaf, Downmix):
+            s._keep.append(leaf.inner.frames)
+            _lib.check(L.oddio_hip_scene_play_frames_downmix(s._h, leaf.inner.frames._h, leaf.inner.start_seconds, db, _fp(pos), _fp(vel),
+                                                             np.float32(options.radius), C.byref(sid)))
+        elif isinstance(leaf, FramesSignal):
             s._keep.append(leaf.frames)
             _lib.check(L.oddio_hip_scene_play_frames(s._h, leaf.frames._h, leaf.start_seconds, db, _fp(pos), _fp(vel), np.float32(options.radius), C.byref(sid)))
         elif isinstance(leaf, Sine):

@@ -14,7 +14,9 @@ namespace oddio_hip {
 // KIND_CYCLE: Mixer general path and the buffered set sample it thread-per-source; in the Seek set it is
 // rendered serially by `cycle_sources` into a contribution row that the mix kernel adds in set order
 // (SrcStatic::freq_or_value holds the row index as raw bits, SrcDyn::t the cursor in samples).
-enum : uint32_t { KIND_FRAMES = 0, KIND_SINE = 1, KIND_CONSTANT = 2, KIND_CYCLE = 3 };
+// KIND_DOWNMIX: Downmix<FramesSignal<[f32;2]>> (downmix.rs) in the Seek set: interleaved stereo clip, each
+// channel interpolated and the two summed; rendered by the per-lane global-memory path of spatial_mix.
+enum : uint32_t { KIND_FRAMES = 0, KIND_SINE = 1, KIND_CONSTANT = 2, KIND_CYCLE = 3, KIND_DOWNMIX = 4 };
 enum : uint32_t { DYN_HAS_FINISHED_FOR = 1u, DYN_STOPPED = 2u };
 enum : uint32_t { PEND_FRESH = 1u, PEND_DISCONTINUITY = 2u };
 enum : uint32_t { EAR_SKIP = 1u };

@@ -171,7 +171,7 @@ __global__ __launch_bounds__(256) void spatial_prepass(SceneParams P, const SrcS
         else d.finished_for = d.finished_for + elapsed;
     } else {
         bool fin = false;
-        if (s.kind == KIND_FRAMES) fin = d.t >= (double)(s.clip_len - 1u) / (double)s.clip_rate;     // frames.rs:204-206
+        if (s.kind == KIND_FRAMES || s.kind == KIND_DOWNMIX) fin = d.t >= (double)(s.clip_len - 1u) / (double)s.clip_rate;     // frames.rs:204-206
         if (fin) { d.flags |= DYN_HAS_FINISHED_FOR; d.finished_for = elapsed; }
     }
     if (d.flags & DYN_STOPPED) {
@@ -195,11 +195,13 @@ __global__ __launch_bounds__(256) void spatial_prepass(SceneParams P, const SrcS
         EarParams ep = {};
         ep.dt = dt; ep.g0 = g0; ep.dg = dg;
         const float back = -eff - off0;                 // :465
-        if (s.kind == KIND_FRAMES) {
+        if (s.kind == KIND_FRAMES || s.kind == KIND_DOWNMIX) {
             d.t = d.t + (double)off0;                   // seek(prev_state.offset), frames.rs:211-213
             ep.t_ear = d.t;
             for (uint32_t done = 0; done < n; done += 256u) {
-                const uint32_t len = (n - done) < 256u ? (n - done) : 256u;
+                // Downmix::sample always renders its whole 256-frame buffer (downmix.rs:24-29), so the
+                // inner clock of a Downmix source advances 256 frames even for a short last chunk
+                const uint32_t len = (s.kind == KIND_DOWNMIX || (n - done) >= 256u) ? 256u : (n - done);
                 d.t = d.t + (double)dt * (double)len;   // frames.rs:198
             }
             d.t = d.t + (double)back;
@@ -218,7 +220,7 @@ __global__ __launch_bounds__(256) void spatial_prepass(SceneParams P, const SrcS
         }
         ear[2 * i + e] = ep;
     }
-    if (s.kind == KIND_FRAMES) d.t = d.t + (double)elapsed;                                     // :468
+    if (s.kind == KIND_FRAMES || s.kind == KIND_DOWNMIX) d.t = d.t + (double)elapsed;           // :468
     else if (s.kind == KIND_SINE) d.phase = fmodf(d.phase + elapsed * s.freq_or_value, ODDIO_TAU);
     dyn[i] = d;
 }
@@ -498,7 +500,7 @@ __device__ __forceinline__ float clip_at(const float* clip, uint32_t len, long l
 // reduction, 64-bit indices) do not inflate the hot kernel's allocation.
 __device__ __noinline__ void mix_source_generic(float* acc_lds, int lane, float fbase, uint32_t frame0, uint32_t n_frames,
                                                 uint32_t c_abs, const float* clip, uint32_t clip_len, uint32_t clip_rate,
-                                                float fixed_gain, double t_ear, float dt, float g0, float dg) {
+                                                float fixed_gain, double t_ear, float dt, float g0, float dg, int downmix) {
     const int b = lane & 15;
     double t_c = t_ear;
     for (uint32_t cc = 0; cc < c_abs; ++cc) t_c = t_c + (double)dt * 256.0;
@@ -514,8 +516,19 @@ __device__ __noinline__ void mix_source_generic(float* acc_lds, int lane, float 
         long long idx; float fr;
         if (fast) { idx = base + (long long)(16 * b + i); fr = frac0; }
         else { const long long tr = (long long)x; idx = base + tr; fr = x - (float)tr; }
-        const float a = clip_at(clip, clip_len, idx), bb = clip_at(clip, clip_len, idx + 1);
-        float v = a + fr * (bb - a);
+        float v;
+        if (downmix) {   // downmix.rs:27-29: per-channel lerp of the stereo frame, then channels().sum()
+            const bool in_a = idx >= 0 && idx < (long long)clip_len, in_b = idx + 1 >= 0 && idx + 1 < (long long)clip_len;
+            const float2 fa = in_a ? reinterpret_cast<const float2*>(clip)[idx] : make_float2(0.0f, 0.0f);
+            const float2 fb = in_b ? reinterpret_cast<const float2*>(clip)[idx + 1] : make_float2(0.0f, 0.0f);
+            const float l = fa.x + fr * (fb.x - fa.x), r = fa.y + fr * (fb.y - fa.y);
+            v = 0.0f;
+            v = v + l;
+            v = v + r;
+        } else {
+            const float a = clip_at(clip, clip_len, idx), bb = clip_at(clip, clip_len, idx + 1);
+            v = a + fr * (bb - a);
+        }
         v = v * fixed_gain;
         const float p = v * (g0 + (fbase + (float)i) * dg);
         if (frame0 + (uint32_t)i < n_frames) acc_lds[i * 64 + lane] = acc_lds[i * 64 + lane] + p;
@@ -608,6 +621,7 @@ __global__ __launch_bounds__(64 * MIX_WG_WAVES, MIX_WAVES_PER_SIMD) void spatial
         int generic = 0, wbase = 0;
         int fl = 0;                              // SFLAG_* contributed by this stream
         float frac0 = 0.0f, ds = 0.0f;
+        if (live && ss.kind == KIND_DOWNMIX) generic = 1;
         if (live && ss.kind == KIND_FRAMES) {
             double t_c = ep.t_ear;
             for (uint32_t cc = 0; cc < cA_abs; ++cc) t_c = t_c + (double)ep.dt * 256.0;   // frames.rs:198 per chunk
@@ -741,7 +755,8 @@ __global__ __launch_bounds__(64 * MIX_WG_WAVES, MIX_WAVES_PER_SIMD) void spatial
                 if (path_j == PATH_GENERIC) {
                     const double t_ear = eB ? rl_d(ep.t_ear, laR) : rl_d(ep.t_ear, laL);
                     mix_source_generic(park, lane, fbase, frame0, n_frames, cB_abs, rl_ptr(ss.clip, laL), (uint32_t)rl_i((int)ss.clip_len, laL),
-                                       (uint32_t)rl_i((int)ss.clip_rate, laL), pe.w, t_ear, dt, pe.x, pe.y);
+                                       (uint32_t)rl_i((int)ss.clip_rate, laL), pe.w, t_ear, dt, pe.x, pe.y,
+                                       rl_i((int)ss.kind, laL) == (int)KIND_DOWNMIX);
                 } else if (path_j == PATH_ROW) {
                     const uint32_t row = (uint32_t)rl_i(__float_as_int(ss.freq_or_value), laL);
                     mix_source_row(park, lane, frame0, n_frames, P.cycle_rows + ((size_t)row * 2u + (uint32_t)eB) * P.cycle_plane);
@@ -941,7 +956,7 @@ __global__ void apply_slot_moves(const SlotMove* __restrict__ mv, uint32_t n, Sr
 __global__ void seek_all_kernel(SrcDyn* __restrict__ dyn, const SrcStatic* __restrict__ st, uint32_t n, float seconds) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    if (st[i].kind == KIND_FRAMES) dyn[i].t = dyn[i].t + (double)seconds;                              // frames.rs:211-213
+    if (st[i].kind == KIND_FRAMES || st[i].kind == KIND_DOWNMIX) dyn[i].t = dyn[i].t + (double)seconds;   // frames.rs:211-213
     else if (st[i].kind == KIND_SINE) dyn[i].phase = fmodf(dyn[i].phase + seconds * st[i].freq_or_value, ODDIO_TAU);
     else if (st[i].kind == KIND_CYCLE) dyn[i].t = f64_rem_euclid(dyn[i].t + (double)seconds * (double)st[i].clip_rate, (double)st[i].clip_len);
 }

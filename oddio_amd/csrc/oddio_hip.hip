@@ -412,6 +412,17 @@ extern "C" int oddio_hip_scene_play_frames(oddio_hip_scene* s, oddio_hip_frames*
     return scene_play_common(s, st, start_seconds, 0.0f, frames, position, velocity, radius, source_id);
 }
 
+extern "C" int oddio_hip_scene_play_frames_downmix(oddio_hip_scene* s, oddio_hip_frames* frames, double start_seconds, float fixed_gain_db,
+                                                   const float position[3], const float velocity[3], float radius, uint32_t* source_id) {
+    if (!s || !frames) return fail(ODDIO_HIP_EINVAL, "NULL argument");
+    if (frames->device != s->device) return fail(ODDIO_HIP_EINVAL, "frames live on device %d, scene on %d", frames->device, s->device);
+    if (frames->channels != 2) return fail(ODDIO_HIP_EINVAL, "Downmix takes a stereo clip (oddio_hip_frames_from_slice_stereo)");
+    SrcStatic st = {};
+    st.clip = frames->dev; st.clip_len = (uint32_t)frames->len; st.clip_rate = frames->rate;
+    st.fixed_gain = db_to_gain(fixed_gain_db); st.kind = KIND_DOWNMIX;
+    return scene_play_common(s, st, start_seconds, 0.0f, frames, position, velocity, radius, source_id);
+}
+
 extern "C" int oddio_hip_scene_play_frames_batch(oddio_hip_scene* s, size_t n, oddio_hip_frames* const* frames, const double* start_seconds,
                                                  const float* fixed_gain_db, const float* positions, const float* velocities,
                                                  const float* radii, uint32_t* ids) {
@@ -1112,7 +1123,7 @@ extern "C" int oddio_hip_source_playback_position(oddio_hip_scene* s, uint32_t i
     SrcStatic st;
     HIP_TRY(hipMemcpy(&d, s->d_dyn + slot, sizeof(d), hipMemcpyDeviceToHost));
     HIP_TRY(hipMemcpy(&st, s->d_static + slot, sizeof(st), hipMemcpyDeviceToHost));
-    if (st.kind != KIND_FRAMES) return fail(ODDIO_HIP_ESTATE, "source %u is not a FramesSignal", id);
+    if (st.kind != KIND_FRAMES && st.kind != KIND_DOWNMIX) return fail(ODDIO_HIP_ESTATE, "source %u is not a FramesSignal", id);
     // frames.rs:199-200, :238-240: (t * rate) as isize, read back as isize as f64 / rate
     const double rate = (double)st.clip_rate;
     double sp = d.t * rate;

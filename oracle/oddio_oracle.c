@@ -234,7 +234,7 @@ void oo_ring_sample(const oo_ring* r, uint32_t rate, float t, float interval, fl
 
 enum {
     K_FRAMES, K_SINE, K_CONSTANT, K_CYCLE, K_FIXED_GAIN, K_GAIN, K_SPEED, K_MONO_TO_STEREO,
-    K_REINHARD, K_TANH, K_MIXER, K_SCENE, K_COUNTING, K_TIME, K_FINISHED, K_ADAPT
+    K_REINHARD, K_TANH, K_MIXER, K_SCENE, K_COUNTING, K_TIME, K_FINISHED, K_ADAPT, K_DOWNMIX
 };
 
 typedef struct { int stop; oo_signal* inner; } mixed_entry; /* mixer.rs:46-49 */
@@ -367,6 +367,7 @@ oo_signal* oo_adapt_new(oo_signal* inner, float initial_rms, float tau, float ma
     return s;
 }
 void oo_constant_set(oo_signal* s, float v0, float v1) { s->cval[0] = v0; s->cval[1] = v1; } /* adapt.rs:127 `adapt.inner.0 = ..` */
+oo_signal* oo_downmix_new(oo_signal* inner) { oo_signal* s = sig_new(K_DOWNMIX, 1); s->inner = inner; return s; } /* downmix.rs:10-15 */
 oo_signal* oo_reinhard_new(oo_signal* inner) { oo_signal* s = sig_new(K_REINHARD, inner->channels); s->inner = inner; return s; }
 oo_signal* oo_tanh_new(oo_signal* inner) { oo_signal* s = sig_new(K_TANH, inner->channels); s->inner = inner; return s; }
 oo_signal* oo_mixer_new(int channels) { /* mixer.rs:70-81 */
@@ -412,7 +413,7 @@ void oo_signal_free(oo_signal* s) {
 int oo_is_seek(const oo_signal* s) {
     switch (s->kind) {
     case K_FRAMES: case K_SINE: case K_CONSTANT: case K_CYCLE: case K_FINISHED: return 1;
-    case K_FIXED_GAIN: case K_MONO_TO_STEREO: case K_REINHARD: case K_TANH: return oo_is_seek(s->inner);
+    case K_FIXED_GAIN: case K_MONO_TO_STEREO: case K_REINHARD: case K_TANH: case K_DOWNMIX: return oo_is_seek(s->inner);
     default: return 0; /* Gain, Speed, Mixer, SpatialScene do not implement Seek */
     }
 }
@@ -773,6 +774,20 @@ void oo_sample(oo_signal* s, float interval, float* out, size_t n) {
         oo_sample(s->inner, interval, out, n);
         for (size_t i = 0; i < n * C; i++) out[i] = tanhf(out[i]);
         break;
+    case K_DOWNMIX: { /* downmix.rs:23-33: the inner signal always renders the whole 256-frame buffer */
+        const int IC = s->inner->channels;
+        float buf[256 * 2];
+        for (size_t done = 0; done < n; done += 256) {
+            const size_t len = n - done < 256 ? n - done : 256;
+            oo_sample(s->inner, interval, buf, 256);
+            for (size_t i = 0; i < len; i++) {
+                float acc = 0.0f; /* Iterator::sum::<f32>() */
+                for (int c = 0; c < IC; c++) acc = acc + buf[i * IC + c];
+                out[done + i] = acc;
+            }
+        }
+        break;
+    }
     case K_ADAPT: { /* adapt.rs:69-87 */
         const float alpha = 1.0f - expf(-interval / s->tau);
         oo_sample(s->inner, interval, out, n);
@@ -814,7 +829,7 @@ void oo_seek(oo_signal* s, float seconds) {
         s->t = r < 0.0 ? r + fabs(len) : r;
         break;
     }
-    case K_FIXED_GAIN: case K_MONO_TO_STEREO: case K_REINHARD: case K_TANH: oo_seek(s->inner, seconds); break;
+    case K_FIXED_GAIN: case K_MONO_TO_STEREO: case K_REINHARD: case K_TANH: case K_DOWNMIX: oo_seek(s->inner, seconds); break;
     default: break; /* Constant / FinishedSignal: no-op */
     }
 }
@@ -824,7 +839,7 @@ int oo_is_finished(const oo_signal* s) {
     case K_FRAMES: /* frames.rs:204-206; (len - 1) is usize arithmetic */
         return s->t >= (double)(uint64_t)((uint64_t)s->data->len - 1) / s->data->rate;
     case K_FINISHED: return 1;
-    case K_FIXED_GAIN: case K_GAIN: case K_SPEED: case K_MONO_TO_STEREO: case K_REINHARD: case K_TANH: case K_ADAPT:
+    case K_FIXED_GAIN: case K_GAIN: case K_SPEED: case K_MONO_TO_STEREO: case K_REINHARD: case K_TANH: case K_ADAPT: case K_DOWNMIX:
         return oo_is_finished(s->inner);
     default: return 0;
     }

@@ -48,6 +48,7 @@ oo_signal* oo_mono_to_stereo_new(oo_signal* inner);                      /* sign
 oo_signal* oo_adapt_new(oo_signal* inner, float initial_rms, float tau, float max_gain,
                        float low, float high);                          /* adapt.rs:25-31, :36-61 */
 void oo_constant_set(oo_signal* s, float v0, float v1);                  /* test fixture: adapt.rs:127 */
+oo_signal* oo_downmix_new(oo_signal* inner);                             /* downmix.rs:10-15 */
 oo_signal* oo_reinhard_new(oo_signal* inner);                            /* reinhard.rs:16-20 */
 oo_signal* oo_tanh_new(oo_signal* inner);                                /* tanh.rs:10-14 */
 oo_signal* oo_mixer_new(int channels);                                   /* mixer.rs:70-81 */

@@ -48,6 +48,7 @@ def lib():
             "oo_speed_new": (vp, [vp]),
             "oo_mono_to_stereo_new": (vp, [vp]),
             "oo_reinhard_new": (vp, [vp]),
+            "oo_downmix_new": (vp, [vp]),
             "oo_adapt_new": (vp, [vp, f32, f32, f32, f32, f32]),
             "oo_constant_set": (None, [vp, f32, f32]),
             "oo_tanh_new": (vp, [vp]),
@@ -251,6 +252,13 @@ class Speed(Signal):
 class MonoToStereo(Signal):
     def __init__(self, inner: Signal):
         super().__init__(lib().oo_mono_to_stereo_new(inner._h), inner)
+
+
+class Downmix(Signal):
+    """Downmix::new(signal) (src/downmix.rs:8-16)."""
+
+    def __init__(self, inner: Signal):
+        super().__init__(lib().oo_downmix_new(inner._h), inner)
 
 
 class Reinhard(Signal):

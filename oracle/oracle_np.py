@@ -143,6 +143,16 @@ def constant_source(value):
     return {"kind": "constant", "value": f32(value)}
 
 
+def downmix_source(rate, stereo_samples, start_seconds=0.0, fixed_gain_db=None):
+    """Downmix::new(FramesSignal::new(Frames<[f32;2]>, start)) (src/downmix.rs, src/frames.rs)."""
+    x = np.asarray(stereo_samples, dtype=f32)
+    assert x.ndim == 2 and x.shape[1] == 2
+    s = {"kind": "downmix", "rate": int(rate), "samples": x, "t": f64(start_seconds)}
+    if fixed_gain_db is not None:
+        s["fixed_gain"] = powf(10.0, f32(fixed_gain_db) / f32(20.0))
+    return s
+
+
 def cycle_source(rate, samples, fixed_gain_db=None):
     """Cycle::new (src/cycle.rs:17-23): cursor (f64, in samples) starts at 0."""
     s = {"kind": "cycle", "rate": int(rate), "samples": np.asarray(samples, dtype=f32), "cursor": f64(0.0)}
@@ -190,6 +200,23 @@ def src_sample(src, interval, n):
         src["phase"] = fmodf(src["phase"] + (interval * f32(n)) * src["freq"], TAU)
     elif kind == "constant":
         out = np.full(n, src["value"], dtype=f32)
+    elif kind == "downmix":
+        # src/downmix.rs:23-33: chunks of 256; the inner FramesSignal always renders the whole buffer,
+        # so its clock moves 256 frames per chunk even when fewer are used.  Each channel is a mono
+        # FramesSignal over the same clock (frame::lerp is per channel, src/frame.rs:39-41).
+        out = np.zeros(n, dtype=f32)
+        for done in range(0, n, 256):
+            ln = min(256, n - done)
+            chans = []
+            for c in range(2):
+                mono = {"kind": "frames", "rate": src["rate"], "samples": np.ascontiguousarray(src["samples"][:, c]), "t": src["t"]}
+                chans.append(src_sample(mono, interval, 256))
+                t_after = mono["t"]
+            acc = np.zeros(256, dtype=f32)
+            acc = acc + chans[0]
+            acc = acc + chans[1]
+            out[done:done + ln] = acc[:ln]
+            src["t"] = t_after
     elif kind == "cycle":
         # src/cycle.rs:26-53.  The f32 offset restarts whenever the read position passes the end of
         # the clip, so the loop is written frame by frame (numpy scalars: every op rounds to f32).
@@ -221,7 +248,7 @@ def src_sample(src, interval, n):
 
 def src_seek(src, seconds):
     seconds = f32(seconds)
-    if src["kind"] == "frames":
+    if src["kind"] in ("frames", "downmix"):
         src["t"] = src["t"] + f64(seconds)
     elif src["kind"] == "sine":
         src["phase"] = fmodf(src["phase"] + seconds * src["freq"], TAU)
@@ -232,7 +259,7 @@ def src_seek(src, seconds):
 
 
 def src_is_finished(src):
-    if src["kind"] == "frames":
+    if src["kind"] in ("frames", "downmix"):
         return bool(src["t"] >= f64(len(src["samples"]) - 1) / f64(src["rate"]))
     return False
 

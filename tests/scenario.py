@@ -22,6 +22,10 @@ def random_spec(seed, n_src, kinds=("frames",), clip_len=24000, rate=48000, star
             src["clip"] = synth.noise_clip(seed, i, clip_len) if noise else synth.sine_clip(sc["freq_hz"][i], clip_len, rate)
             src["rate"] = rate
             src["start"] = start
+        elif kind == "downmix":
+            src["clip"] = np.stack([synth.noise_clip(seed, i, clip_len), synth.noise_clip(seed + 999, i, clip_len)], axis=1)
+            src["rate"] = rate
+            src["start"] = start
         elif kind == "cycle":
             src["clip"] = synth.noise_clip(seed, i, cycle_len) if noise else synth.sine_clip(sc["freq_hz"][i], cycle_len, rate)
             src["rate"] = rate
@@ -49,6 +53,8 @@ class OracleBackend:
         oc = self.oc
         if src["kind"] == "frames":
             sig = oc.FramesSignal(oc.Frames(src["rate"], src["clip"]), src["start"])
+        elif src["kind"] == "downmix":
+            sig = oc.Downmix(oc.FramesSignal(oc.Frames(src["rate"], src["clip"]), src["start"]))
         elif src["kind"] == "cycle":
             sig = oc.Cycle(oc.Frames(src["rate"], src["clip"]))
         elif src["kind"] == "sine":
@@ -96,6 +102,11 @@ class HipBackend:
             if key not in self._clips:
                 self._clips[key] = oa.Frames.from_slice(src["rate"], src["clip"])
             sig = oa.FramesSignal(self._clips[key], src["start"])
+        elif src["kind"] == "downmix":
+            key = id(src["clip"])
+            if key not in self._clips:
+                self._clips[key] = oa.Frames.from_slice(src["rate"], src["clip"])
+            sig = oa.Downmix(oa.FramesSignal(self._clips[key], src["start"]))
         elif src["kind"] == "cycle":
             key = id(src["clip"])
             if key not in self._clips:

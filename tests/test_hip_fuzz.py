@@ -40,7 +40,7 @@ def test_random_operations_bit_exact(seed):
             op = rng.choice(["play", "play", "buffered", "motion", "motion", "rotation", "control", "drop"])
             if op in ("play", "buffered") and len(live) < 60:
                 clip_no += 1
-                kind = rng.choice(["frames", "frames", "cycle", "constant"])
+                kind = rng.choice(["frames", "frames", "cycle", "constant"] + (["downmix"] if op == "play" else []))
                 rate = int(rng.choice([48000, 44100, 22050]))
                 pos, vel = _vec(rng, 12.0), _vec(rng, 25.0)
                 radius = float(rng.choice([0.1, 0.5]))
@@ -49,6 +49,12 @@ def test_random_operations_bit_exact(seed):
                     clip = synth.noise_clip(seed, clip_no, int(rng.integers(1, 9000)))
                     start = float(rng.uniform(-0.01, 0.02))
                     sh, so = oa.FramesSignal(oa.Frames.from_slice(rate, clip), start), oc.FramesSignal(oc.Frames(rate, clip), start)
+                elif kind == "downmix":
+                    n = int(rng.integers(1, 9000))
+                    clip = np.stack([synth.noise_clip(seed, clip_no, n), synth.noise_clip(seed + 77, clip_no, n)], axis=1)
+                    start = float(rng.uniform(-0.01, 0.02))
+                    sh = oa.Downmix(oa.FramesSignal(oa.Frames.from_slice(rate, clip), start))
+                    so = oc.Downmix(oc.FramesSignal(oc.Frames(rate, clip), start))
                 elif kind == "cycle":
                     clip = synth.noise_clip(seed, clip_no, int(rng.integers(1, 700)))
                     sh, so = oa.Cycle(oa.Frames.from_slice(rate, clip)), oc.Cycle(oc.Frames(rate, clip))

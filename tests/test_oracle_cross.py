@@ -24,6 +24,10 @@ def build_pair(seed, n_src, kinds, clip_len=22000, rate=48000, start=0.3, gain_d
             clip = synth.noise_clip(seed, i, clip_len)
             sig = oc.FramesSignal(oc.Frames(rate, clip), start)
             nsrc = on.frames_source(rate, clip, start, fixed_gain_db=db)
+        elif kind == "downmix":
+            clip = np.stack([synth.noise_clip(seed, i, clip_len), synth.noise_clip(seed + 999, i, clip_len)], axis=1)
+            sig = oc.Downmix(oc.FramesSignal(oc.Frames(rate, clip), start))
+            nsrc = on.downmix_source(rate, clip, start, fixed_gain_db=db)
         elif kind == "cycle":
             clip = synth.noise_clip(seed, i, cycle_len)
             sig = oc.Cycle(oc.Frames(rate, clip))
@@ -59,6 +63,17 @@ def test_scene_cycle_bit_equal(cycle_len, n_frames):
     sc, cs, ns, hc, hn = build_pair(20 + cycle_len, 4, ["cycle", "frames", "cycle"], gain_db=[None, None, -5.0], cycle_len=cycle_len)
     interval = np.float32(1.0) / np.float32(48000)
     for cb in range(3):
+        a = cs.sample_n(interval, n_frames)
+        b = ns.sample(interval, n_frames)
+        np.testing.assert_array_equal(a, b)
+
+
+@pytest.mark.parametrize("n_frames", [1024, 300, 1, 700])
+def test_scene_downmix_bit_equal(n_frames):
+    # Downmix<FramesSignal<[f32;2]>> in the Seek set, incl. ragged callbacks (whole-buffer clock advance)
+    sc, cs, ns, hc, hn = build_pair(31, 4, ["downmix", "frames", "downmix"], gain_db=[None, None, -5.0], clip_len=9000)
+    interval = np.float32(1.0) / np.float32(48000)
+    for cb in range(4):
         a = cs.sample_n(interval, n_frames)
         b = ns.sample(interval, n_frames)
         np.testing.assert_array_equal(a, b)

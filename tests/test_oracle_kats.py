@@ -300,3 +300,20 @@ def test_adapt_c_equals_numpy():
         b = nf(interval, raw.sample_n(interval, n))
         np.testing.assert_array_equal(a, b)
         assert np.isfinite(a).all()
+
+
+# ---- src/downmix.rs:53-59 `smoke` -------------------------------------------------------------
+def test_downmix_smoke_kat():
+    signal = oo.Downmix(oo.Constant([1.0, 2.0]))
+    out = signal.sample_n(f32(1.0), 384)
+    np.testing.assert_array_equal(out, np.full(384, 3.0, np.float32))
+
+
+def test_downmix_renders_whole_buffers():
+    # downmix.rs:24-29: the inner signal is sampled 256 frames per chunk regardless of the chunk length
+    x = np.stack([np.arange(2000, dtype=np.float32), -0.5 * np.arange(2000, dtype=np.float32)], axis=1)
+    sig = oo.Downmix(oo.FramesSignal(oo.Frames(1, x), 0.0))
+    a = sig.sample_n(f32(1.0), 300)                       # 256 + 44 frames, but the clip clock moved 512
+    np.testing.assert_array_equal(a, 0.5 * np.arange(300, dtype=np.float32))
+    b = sig.sample_n(f32(1.0), 4)
+    np.testing.assert_array_equal(b, 0.5 * np.arange(512, 516, dtype=np.float32))
