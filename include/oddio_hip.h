@@ -220,6 +220,33 @@ int oddio_hip_scene_kernel_ms_history(oddio_hip_scene* scene, float* ms, size_t 
 int oddio_hip_debug_mix_occupancy(int device, int* blocks_per_cu, int* num_cus, int* vgprs,
                                   int* lds_bytes);
 
+/* ---- Stream (src/stream.rs) ------------------------------------------------------------------
+ * Stream::new(rate, size) -> (StreamControl, Stream) (src/stream.rs:24-34): dynamic audio pushed by
+ * another thread.  The SPSC ring (src/spsc.rs) lives in pinned, GPU-visible host memory: `write` is a
+ * memcpy plus one release store (no lock, no GPU call), the kernels read the ring directly and publish
+ * the read index back.  `channels` is 1 (spatial scenes, mixers) or 2 (mixers).  The handle is the
+ * StreamControl; the Stream itself is moved into a scene / mixer by exactly one play call. */
+typedef struct oddio_hip_stream oddio_hip_stream;
+int oddio_hip_stream_create(int device, uint32_t rate, size_t size_frames, uint32_t channels,
+                            oddio_hip_stream** out);
+/* StreamControl::write (src/stream.rs:107-113): appends a prefix of `samples` (interleaved when
+ * stereo); *consumed = frames taken (the rest should be passed again later). */
+int oddio_hip_stream_write(oddio_hip_stream* stream, const float* samples, size_t n_frames,
+                           size_t* consumed);
+/* StreamControl::free (src/stream.rs:101-103): lower bound of what the next write will take. */
+int oddio_hip_stream_free(oddio_hip_stream* stream, size_t* n_frames);
+/* drop(StreamControl): no more data will come; the playing Stream reports is_finished once it has
+ * been drained (src/stream.rs:71-73, :88-90) and is then removed like any finished source.  Invalidates
+ * the handle; the ring is freed when the scene / mixer has dropped the Stream too. */
+int oddio_hip_stream_drop(oddio_hip_stream* stream);
+/* SpatialSceneControl::play_buffered(filters(Stream), ..) (src/spatial.rs:314-340): the only way a
+ * Stream (not Seek) enters a spatial scene. */
+int oddio_hip_scene_play_buffered_stream(oddio_hip_scene* scene, oddio_hip_stream* stream,
+                                         const oddio_hip_filter* filters, int n_filters,
+                                         const float position[3], const float velocity[3],
+                                         float radius, float max_distance, uint32_t rate,
+                                         float buffer_duration, uint32_t* source_id);
+
 /* ---- Mixer<[f32;2]> (src/mixer.rs:70-81 `Mixer::new`) ---- */
 int oddio_hip_mixer_create(int device, uint32_t max_sources, uint32_t max_frames,
                            oddio_hip_mixer** out);
@@ -240,6 +267,9 @@ int oddio_hip_mixer_play_chain(oddio_hip_mixer* mixer, int leaf_kind, oddio_hip_
                                double start_seconds, float phase, float frequency_hz_or_value,
                                const oddio_hip_filter* filters, int n_filters, uint32_t* source_id);
 /* GainControl / SpeedControl of filter `filter_index` of a mixer source */
+/* MixerControl::play(filters(Stream)) (a mono stream is wrapped in MonoToStereo like other mono leaves) */
+int oddio_hip_mixer_play_stream(oddio_hip_mixer* mixer, oddio_hip_stream* stream,
+                                const oddio_hip_filter* filters, int n_filters, uint32_t* source_id);
 int oddio_hip_mixer_set_gain(oddio_hip_mixer* mixer, uint32_t source_id, int filter_index, float amplitude_ratio);
 int oddio_hip_mixer_set_gain_db(oddio_hip_mixer* mixer, uint32_t source_id, int filter_index, float db);
 int oddio_hip_mixer_set_speed(oddio_hip_mixer* mixer, uint32_t source_id, int filter_index, float factor);

@@ -2,6 +2,6 @@
 
 from .api import (  # noqa: F401
     Adapt, AdaptOptions, Constant, Cycle, Downmix, FixedGain, Frames, FramesSignal, Gain, GainControl, Mixed, Mixer, MixerControl, MonoToStereo, Reinhard, Signal, Sine,
-    Spatial, SpatialOptions, SpatialScene, SpatialSceneControl, Speed, SpeedControl, Tanh, frame_stereo, run,
+    Spatial, SpatialOptions, SpatialScene, SpatialSceneControl, Speed, SpeedControl, Stream, StreamControl, Tanh, frame_stereo, run,
     MODE_FAST, MODE_ORDERED, POSTFX_NONE, POSTFX_REINHARD, POSTFX_TANH,
 )

@@ -77,6 +77,12 @@ def lib():
         "oddio_hip_scene_set_adapt": (i32, [vp, i32, f32, f32, f32, f32, f32]),
         "oddio_hip_mixer_set_adapt": (i32, [vp, i32, f32, f32, f32, f32, f32]),
         "oddio_hip_scene_play_frames_downmix": (i32, [vp, vp, f64, f32, fp, fp, f32, u32p]),
+        "oddio_hip_stream_create": (i32, [i32, u32, C.c_size_t, u32, vpp]),
+        "oddio_hip_stream_write": (i32, [vp, fp, C.c_size_t, C.POINTER(C.c_size_t)]),
+        "oddio_hip_stream_free": (i32, [vp, C.POINTER(C.c_size_t)]),
+        "oddio_hip_stream_drop": (i32, [vp]),
+        "oddio_hip_scene_play_buffered_stream": (i32, [vp, vp, vp, i32, fp, fp, f32, f32, u32, f32, u32p]),
+        "oddio_hip_mixer_play_stream": (i32, [vp, vp, vp, i32, u32p]),
         "oddio_hip_scene_play_cycle": (i32, [vp, vp, f32, fp, fp, f32, u32p]),
         "oddio_hip_scene_play_frames_batch": (i32, [vp, sz, vpp, C.POINTER(f64), fp, fp, fp, fp, u32p]),
         "oddio_hip_source_set_motion": (i32, [vp, u32, fp, fp, i32]),

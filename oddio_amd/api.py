@@ -116,6 +116,51 @@ class Constant(Signal):
         self.value = np.float32(value)
 
 
+class StreamControl:
+    """src/stream.rs:96-114: the producer's half.  `write` is a memcpy into pinned memory plus a
+    release store; it never calls into the GPU runtime."""
+
+    def __init__(self, handle, channels):
+        self._h, self._channels = handle, channels
+
+    def write(self, samples) -> int:
+        a = np.ascontiguousarray(np.asarray(samples, dtype=np.float32))
+        if a.ndim != (1 if self._channels == 1 else 2) or (a.ndim == 2 and a.shape[1] != 2):
+            raise TypeError("samples must be [n] (mono stream) or [n, 2] (stereo stream)")
+        n = C.c_size_t()
+        _lib.check(_lib.lib().oddio_hip_stream_write(self._h, _fp(a), a.shape[0], C.byref(n)))
+        return int(n.value)
+
+    def free(self) -> int:
+        n = C.c_size_t()
+        _lib.check(_lib.lib().oddio_hip_stream_free(self._h, C.byref(n)))
+        return int(n.value)
+
+    def drop(self):
+        """drop(StreamControl): the Stream finishes once it has been drained (src/stream.rs:88-90)."""
+        if self._h is not None:
+            _lib.check(_lib.lib().oddio_hip_stream_drop(self._h))
+            self._h = None
+
+    close = drop
+
+
+class Stream(Signal):
+    """Stream::new(rate, size) -> (StreamControl, Stream)  (src/stream.rs:24-34).  Not `Seek`: enters a
+    spatial scene through play_buffered, a Mixer through play."""
+    seekable = False
+
+    def __init__(self, control: StreamControl, rate, channels):
+        self.control, self.rate, self.channels = control, int(rate), channels
+
+    @classmethod
+    def new(cls, rate: int, size: int, channels: int = 1, device: int = 0):
+        h = C.c_void_p()
+        _lib.check(_lib.lib().oddio_hip_stream_create(device, int(rate), int(size), int(channels), C.byref(h)))
+        control = StreamControl(h, channels)
+        return control, cls(control, rate, channels)
+
+
 class FixedGain(Signal):
     def __init__(self, inner: Signal, db: float):
         self.inner, self.db = inner, np.float32(db)
@@ -235,7 +280,7 @@ def _unwrap_chain(signal):
         else:
             chain.append((FILTER_SPEED, float(signal.control._speed), signal.control))
         signal = signal.inner
-    if not isinstance(signal, (FramesSignal, Sine, Constant, Cycle)):
+    if not isinstance(signal, (FramesSignal, Sine, Constant, Cycle, Stream)):
         raise TypeError(f"{type(signal).__name__} is not implemented on the device path")
     if len(chain) > 4:
         raise TypeError("at most 4 filters around a buffered source")
@@ -438,10 +483,17 @@ class SpatialSceneControl:
         filt = (_Filter * max(len(chain), 1))()
         for i, (kind, param, _) in enumerate(chain):
             filt[i].kind, filt[i].param = kind, param
-        args = _leaf_args(leaf, s._keep)
-        _lib.check(L.oddio_hip_scene_play_buffered(s._h, args[0], args[1], args[2], args[3], args[4], C.cast(filt, C.c_void_p), len(chain),
-                                                   _fp(pos), _fp(vel), np.float32(options.radius), np.float32(max_distance), int(rate),
-                                                   np.float32(buffer_duration), C.byref(sid)))
+        if isinstance(leaf, Stream):
+            if leaf.control._h is None:
+                raise ValueError("the StreamControl has already been dropped")
+            _lib.check(L.oddio_hip_scene_play_buffered_stream(s._h, leaf.control._h, C.cast(filt, C.c_void_p), len(chain), _fp(pos), _fp(vel),
+                                                              np.float32(options.radius), np.float32(max_distance), int(rate),
+                                                              np.float32(buffer_duration), C.byref(sid)))
+        else:
+            args = _leaf_args(leaf, s._keep)
+            _lib.check(L.oddio_hip_scene_play_buffered(s._h, args[0], args[1], args[2], args[3], args[4], C.cast(filt, C.c_void_p), len(chain),
+                                                       _fp(pos), _fp(vel), np.float32(options.radius), np.float32(max_distance), int(rate),
+                                                       np.float32(buffer_duration), C.byref(sid)))
         for i, (_, _, control) in enumerate(chain):
             if control is not None:
                 control._bind(s, sid.value, i)
@@ -634,7 +686,7 @@ class MixerControl:
             else:
                 chain.append((FILTER_SPEED, float(sig.control._speed), sig.control))
             sig = sig.inner
-        if not isinstance(sig, (FramesSignal, Sine, Constant, Cycle)):
+        if not isinstance(sig, (FramesSignal, Sine, Constant, Cycle, Stream)):
             raise TypeError(f"{type(sig).__name__} is not implemented on the device path")
         leaf_channels = getattr(sig, "channels", 1)
         if (leaf_channels == 1) != stereo_seen:
@@ -647,8 +699,13 @@ class MixerControl:
         filt = (_Filter * max(len(chain), 1))()
         for i, (kind, param, _) in enumerate(chain):
             filt[i].kind, filt[i].param = kind, param
-        args = _leaf_args(sig, m._keep)
-        _lib.check(L.oddio_hip_mixer_play_chain(m._h, args[0], args[1], args[2], args[3], args[4], C.cast(filt, C.c_void_p), len(chain), C.byref(sid)))
+        if isinstance(sig, Stream):
+            if sig.control._h is None:
+                raise ValueError("the StreamControl has already been dropped")
+            _lib.check(L.oddio_hip_mixer_play_stream(m._h, sig.control._h, C.cast(filt, C.c_void_p), len(chain), C.byref(sid)))
+        else:
+            args = _leaf_args(sig, m._keep)
+            _lib.check(L.oddio_hip_mixer_play_chain(m._h, args[0], args[1], args[2], args[3], args[4], C.cast(filt, C.c_void_p), len(chain), C.byref(sid)))
         for i, (_, _, control) in enumerate(chain):
             if control is not None:
                 control._bind(m, sid.value, i)

@@ -40,7 +40,9 @@ static_assert(sizeof(BufStatic) == 96, "BufStatic layout");
 struct alignas(16) BufDyn {
     SrcDyn common;          // clock / phase, Motion, State, finished_for, flags, id
     float ring_write;       // Ring::write (ring.rs:6)
-    uint32_t pad0[3];
+    uint32_t stream_len;    // KIND_STREAM: spsc::Receiver::len (spsc.rs:121); Stream::t is common.phase
+    uint32_t stream_stopping;   // Stream::stopping (stream.rs:12)
+    uint32_t pad0;
     float shared[MAX_WRAP]; // Gain: atomically shared target (gain.rs:59) / Speed: factor (speed.rs:9)
     float sm_prev[MAX_WRAP];     // Smoothed<f32> of each Gain (smooth.rs:26-30)
     float sm_next[MAX_WRAP];
@@ -66,7 +68,7 @@ __device__ __forceinline__ float clip_ch(const float* clip, uint32_t len, uint32
     return (i >= 0 && i < (long long)len) ? clip[(size_t)i * C + ch] : 0.0f;   // frames.rs:105-123
 }
 
-__device__ void leaf_sample(const BufStatic& s, SrcDyn& d, float interval, float* out, uint32_t n) {
+__device__ void leaf_sample(const BufStatic& s, SrcDyn& d, uint32_t& bd_stream_len, uint32_t& bd_stream_stopping, float interval, float* out, uint32_t n) {
     const uint32_t C = s.channels ? s.channels : 1u;
     if (s.kind == KIND_FRAMES) {   // frames.rs:176-201
         const double s0 = d.t * (double)s.clip_rate;
@@ -117,6 +119,38 @@ __device__ void leaf_sample(const BufStatic& s, SrcDyn& d, float interval, float
             offset = offset + ds;
         }
         d.t = (double)base + (double)offset;
+    } else if (s.kind == KIND_STREAM) {   // stream.rs:69-85 over the spsc ring in pinned host memory
+        StreamHeader* hdr = reinterpret_cast<StreamHeader*>(const_cast<float*>(s.clip)) - 1;
+        const uint32_t size = s.clip_len;                                    // capacity + 1 (spsc.rs:12)
+        const uint32_t read = hdr->read;                                     // only this thread ever stores it
+        const uint32_t write = __hip_atomic_load(&hdr->write, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);
+        uint32_t len = write >= read ? write - read : write + size - read;  // update(): readable_len, spsc.rs:218-225
+        if (len < bd_stream_len) len = bd_stream_len;                        // never shrinks (debug_assert, spsc.rs:131)
+        if (__hip_atomic_load(&hdr->closed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)) bd_stream_stopping = 1u;   // :71-73
+        const float s0 = d.phase;                                            // Stream::t
+        const float ds = interval * (float)s.clip_rate;
+        for (uint32_t i = 0; i < n; ++i) {
+            const float sv = s0 + ds * (float)i;                             // :78
+            const float x0f = truncf(sv);
+            const long long x0 = f64_as_isize((double)x0f);                  // s.trunc() as isize
+            const float fract = sv - x0f;                                    // f32::fract
+            for (uint32_t ch = 0; ch < C; ++ch) {
+                float a = 0.0f, b = 0.0f;                                    // Stream::get: zero outside [0, len)
+                if (x0 >= 0 && x0 < (long long)len) a = s.clip[(size_t)((read + (uint32_t)x0) % size) * C + ch];
+                if (x0 + 1 >= 0 && x0 + 1 < (long long)len) b = s.clip[(size_t)((read + (uint32_t)(x0 + 1)) % size) * C + ch];
+                out[i * C + ch] = a + fract * (b - a);
+            }
+        }
+        {   // advance(interval * out.len() as f32), stream.rs:59-64
+            const float next = d.phase + (interval * (float)n) * (float)s.clip_rate;
+            const float t = fminf(next, (float)len);
+            uint32_t rel = (uint32_t)f32_as_usize(t);
+            if (rel > len) rel = len;
+            if (rel) __hip_atomic_store(&hdr->read, (read + rel) % size, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);   // release(), spsc.rs:227-235
+            len -= rel;
+            d.phase = t - truncf(t);
+        }
+        bd_stream_len = len;
     } else if (s.kind == KIND_SINE) {   // sine.rs:34-40
         for (uint32_t i = 0; i < n; ++i) {
             const float t = interval * (float)i;
@@ -137,7 +171,7 @@ __device__ void inner_sample(const BufStatic& s, BufDyn& d, float interval, floa
         level_interval[w] = cur;
         if (s.wrap_kind[w] == WRAP_SPEED) cur = cur * d.shared[w];   // speed.rs:32-35
     }
-    leaf_sample(s, d.common, cur, out, n);
+    leaf_sample(s, d.common, d.stream_len, d.stream_stopping, cur, out, n);
     for (uint32_t w = 0; w < s.n_wrap; ++w) {
         if (s.wrap_kind[w] == WRAP_FIXED_GAIN) {                      // gain.rs:32-37
             const float g = s.wrap_param[w];
@@ -207,6 +241,7 @@ __global__ __launch_bounds__(64) void buffered_sources(SceneParams P, uint32_t n
     } else {
         bool fin = false;
         if (s.kind == KIND_FRAMES) fin = c.t >= (double)(s.clip_len - 1u) / (double)s.clip_rate;   // is_finished passes through the filters
+        if (s.kind == KIND_STREAM) fin = d.stream_stopping && c.phase == (float)d.stream_len;       // stream.rs:88-90
         if (fin) { c.flags |= DYN_HAS_FINISHED_FOR; c.finished_for = elapsed; }
     }
     if (c.flags & DYN_STOPPED) {

@@ -16,7 +16,13 @@ namespace oddio_hip {
 // (SrcStatic::freq_or_value holds the row index as raw bits, SrcDyn::t the cursor in samples).
 // KIND_DOWNMIX: Downmix<FramesSignal<[f32;2]>> (downmix.rs) in the Seek set: interleaved stereo clip, each
 // channel interpolated and the two summed; rendered by the per-lane global-memory path of spatial_mix.
-enum : uint32_t { KIND_FRAMES = 0, KIND_SINE = 1, KIND_CONSTANT = 2, KIND_CYCLE = 3, KIND_DOWNMIX = 4 };
+// KIND_STREAM: Stream<T> (stream.rs): the SPSC ring lives in pinned, GPU-visible host memory (StreamHeader
+// followed by the samples); general (thread-per-source) paths only.
+enum : uint32_t { KIND_FRAMES = 0, KIND_SINE = 1, KIND_CONSTANT = 2, KIND_CYCLE = 3, KIND_DOWNMIX = 4, KIND_STREAM = 5 };
+
+// spsc.rs Header (:246-249) plus the "sender dropped" flag that Arc::strong_count provides there (:165-167).
+// `write` is stored by the producer (host, release), `read` by the consumer (device, system scope).
+struct StreamHeader { uint32_t read, write, closed, pad; };
 enum : uint32_t { DYN_HAS_FINISHED_FOR = 1u, DYN_STOPPED = 2u };
 enum : uint32_t { PEND_FRESH = 1u, PEND_DISCONTINUITY = 2u };
 enum : uint32_t { EAR_SKIP = 1u };

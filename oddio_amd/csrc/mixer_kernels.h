@@ -291,6 +291,7 @@ __global__ __launch_bounds__(64) void mixer_general_sources(uint32_t n_sources, 
     if (d.common.flags & MIXDYN_STOPPED) { skip[i] = 1; return; }
     bool fin = (d.common.flags & MIXDYN_STOP_REQUESTED) != 0;                                                   // mixer.rs:102
     if (s.kind == KIND_FRAMES) fin = fin || d.common.t >= (double)(s.clip_len - 1u) / (double)s.clip_rate;      // frames.rs:204-206
+    if (s.kind == KIND_STREAM) fin = fin || (d.stream_stopping && d.common.phase == (float)d.stream_len);       // stream.rs:88-90
     if (fin) {
         d.common.flags |= MIXDYN_STOPPED;
         const uint32_t k = atomicAdd(&stopped_hdr[0], 1u);

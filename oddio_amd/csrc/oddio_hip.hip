@@ -66,6 +66,7 @@ struct oddio_hip_frames {
     uint32_t channels = 1;   // 1: Frames<f32>; 2: Frames<[f32;2]> (interleaved), Mixer general path only
     float* dev = nullptr;
     bool owned = true;
+    void* pinned_block = nullptr;   // Stream rings: the hipHostMalloc'ed block `dev` points into
     std::atomic<int> refs{1};
 };
 
@@ -139,7 +140,8 @@ extern "C" int oddio_hip_frames_retain(oddio_hip_frames* f) {
 extern "C" int oddio_hip_frames_release(oddio_hip_frames* f) {
     if (!f) return fail(ODDIO_HIP_EINVAL, "NULL frames");
     if (f->refs.fetch_sub(1, std::memory_order_acq_rel) == 1) {
-        if (f->owned && f->dev) { DeviceGuard g(f->device); (void)hipFree(f->dev); }
+        if (f->pinned_block) { DeviceGuard g(f->device); (void)hipHostFree(f->pinned_block); }
+        else if (f->owned && f->dev) { DeviceGuard g(f->device); (void)hipFree(f->dev); }
         delete f;
     }
     return 0;
@@ -148,6 +150,91 @@ extern "C" int oddio_hip_frames_info(const oddio_hip_frames* f, uint32_t* rate, 
     if (!f) return fail(ODDIO_HIP_EINVAL, "NULL frames");
     if (rate) *rate = f->rate;
     if (len) *len = f->len;
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Stream (stream.rs): StreamControl on the host, the SPSC ring (spsc.rs) in pinned GPU-visible memory
+// ---------------------------------------------------------------------------------------------
+struct oddio_hip_stream {
+    oddio_hip_frames* ring = nullptr;   // refcounted owner of the pinned block; ->dev = device address of the samples
+    StreamHeader* hdr = nullptr;        // host addresses
+    float* data = nullptr;
+    uint32_t size = 0;                  // capacity + 1 slots (spsc.rs:12)
+    uint32_t channels = 1, rate = 0;
+    bool played = false;
+};
+
+extern "C" int oddio_hip_stream_create(int device, uint32_t rate, size_t size_frames, uint32_t channels, oddio_hip_stream** out) {
+    if (!out) return fail(ODDIO_HIP_EINVAL, "out is NULL");
+    if (rate == 0 || (channels != 1 && channels != 2)) return fail(ODDIO_HIP_EINVAL, "rate must be > 0, channels 1 or 2");
+    if (size_frames >= 0x7ffffff0u) return fail(ODDIO_HIP_EINVAL, "stream too large");
+    DeviceGuard g(device);
+    if (!g.ok) return fail(ODDIO_HIP_ENODEV, "hipSetDevice(%d) failed", device);
+    const uint32_t size = (uint32_t)size_frames + 1u;
+    void* block = nullptr;
+    const size_t bytes = sizeof(StreamHeader) + (size_t)size * channels * sizeof(float);
+    hipError_t e = hipHostMalloc(&block, bytes, hipHostMallocCoherent | hipHostMallocMapped);
+    if (e != hipSuccess) return fail(ODDIO_HIP_ENOMEM, "hipHostMalloc(%zu): %s", bytes, hipGetErrorString(e));
+    memset(block, 0, bytes);
+    void* dblock = nullptr;
+    e = hipHostGetDevicePointer(&dblock, block, 0);
+    if (e != hipSuccess) { (void)hipHostFree(block); return fail((int)e, "hipHostGetDevicePointer: %s", hipGetErrorString(e)); }
+    auto* f = new oddio_hip_frames();
+    f->device = device; f->rate = rate; f->len = size; f->channels = channels; f->owned = false; f->pinned_block = block;
+    f->dev = reinterpret_cast<float*>(reinterpret_cast<unsigned char*>(dblock) + sizeof(StreamHeader));
+    auto* st = new oddio_hip_stream();
+    st->ring = f;
+    st->hdr = reinterpret_cast<StreamHeader*>(block);
+    st->data = reinterpret_cast<float*>(reinterpret_cast<unsigned char*>(block) + sizeof(StreamHeader));
+    st->size = size; st->channels = channels; st->rate = rate;
+    *out = st;
+    return 0;
+}
+
+// spsc::Sender::free (spsc.rs:75-86)
+static uint32_t stream_free_slots(const oddio_hip_stream* st, uint32_t write, uint32_t read) {
+    if (write < read) return read - write - 1u;
+    if (read >= 1u) return st->size - write + (read - 1u);
+    return st->size - write - 1u;
+}
+
+extern "C" int oddio_hip_stream_free(oddio_hip_stream* st, size_t* n_frames) {
+    if (!st || !n_frames) return fail(ODDIO_HIP_EINVAL, "NULL argument");
+    const uint32_t write = st->hdr->write;
+    const uint32_t read = __atomic_load_n(&st->hdr->read, __ATOMIC_ACQUIRE);
+    *n_frames = stream_free_slots(st, write, read);
+    return 0;
+}
+
+// spsc::Sender::send_from_slice (spsc.rs:27-67): append a prefix of `samples`, report how much fitted
+extern "C" int oddio_hip_stream_write(oddio_hip_stream* st, const float* samples, size_t n_frames, size_t* consumed) {
+    if (!st || (!samples && n_frames)) return fail(ODDIO_HIP_EINVAL, "NULL argument");
+    if (st->hdr->closed) return fail(ODDIO_HIP_ESTATE, "the stream control has been dropped");
+    const uint32_t write = st->hdr->write;
+    const uint32_t read = __atomic_load_n(&st->hdr->read, __ATOMIC_ACQUIRE);
+    const uint32_t C = st->channels;
+    size_t n1_cap, n2_cap;
+    if (write < read) { n1_cap = read - write - 1u; n2_cap = 0; }
+    else if (read >= 1u) { n1_cap = st->size - write; n2_cap = read - 1u; }
+    else { n1_cap = st->size - write - 1u; n2_cap = 0; }
+    const size_t n1 = std::min(n1_cap, n_frames);
+    memcpy(st->data + (size_t)write * C, samples, n1 * C * sizeof(float));
+    const size_t n2 = std::min(n2_cap, n_frames - n1);
+    if (n2) memcpy(st->data, samples + n1 * C, n2 * C * sizeof(float));
+    const size_t n = n1 + n2;
+    __atomic_store_n(&st->hdr->write, (uint32_t)((write + n) % st->size), __ATOMIC_RELEASE);
+    if (consumed) *consumed = n;
+    return 0;
+}
+
+// drop(StreamControl): the receiver sees is_closed (spsc.rs:165-167) and the Stream finishes once it
+// has been drained (stream.rs:71-73, :88-90).  The handle is invalid afterwards.
+extern "C" int oddio_hip_stream_drop(oddio_hip_stream* st) {
+    if (!st) return fail(ODDIO_HIP_EINVAL, "NULL stream");
+    __atomic_store_n(&st->hdr->closed, 1u, __ATOMIC_RELEASE);
+    oddio_hip_frames_release(st->ring);
+    delete st;
     return 0;
 }
 
@@ -663,10 +750,36 @@ extern "C" int oddio_hip_scene_reserve_buffered(oddio_hip_scene* s, uint32_t max
     return ensure_buffered_locked(s, max_buffered);
 }
 
+static int scene_play_buffered_impl(oddio_hip_scene* s, int leaf_kind, oddio_hip_frames* frames, double start_seconds, float phase,
+                                    float freq_hz_or_value, const oddio_hip_filter* filters, int n_filters,
+                                    const float position[3], const float velocity[3], float radius, float max_distance,
+                                    uint32_t rate, float buffer_duration, uint32_t* source_id);
+
 extern "C" int oddio_hip_scene_play_buffered(oddio_hip_scene* s, int leaf_kind, oddio_hip_frames* frames, double start_seconds, float phase,
                                              float freq_hz_or_value, const oddio_hip_filter* filters, int n_filters,
                                              const float position[3], const float velocity[3], float radius, float max_distance,
                                              uint32_t rate, float buffer_duration, uint32_t* source_id) {
+    if (leaf_kind == (int)KIND_STREAM) return fail(ODDIO_HIP_EINVAL, "streams are played with oddio_hip_scene_play_buffered_stream");
+    return scene_play_buffered_impl(s, leaf_kind, frames, start_seconds, phase, freq_hz_or_value, filters, n_filters, position, velocity, radius,
+                                    max_distance, rate, buffer_duration, source_id);
+}
+
+extern "C" int oddio_hip_scene_play_buffered_stream(oddio_hip_scene* s, oddio_hip_stream* stream, const oddio_hip_filter* filters, int n_filters,
+                                                    const float position[3], const float velocity[3], float radius, float max_distance,
+                                                    uint32_t rate, float buffer_duration, uint32_t* source_id) {
+    if (!s || !stream) return fail(ODDIO_HIP_EINVAL, "NULL argument");
+    if (stream->played) return fail(ODDIO_HIP_ESTATE, "a Stream is moved into the scene once (stream.rs:24-34)");
+    if (stream->channels != 1) return fail(ODDIO_HIP_EINVAL, "spatial scenes take mono streams (Frame = Sample, spatial.rs:291)");
+    int rc = scene_play_buffered_impl(s, (int)KIND_STREAM, stream->ring, 0.0, 0.0f, 0.0f, filters, n_filters, position, velocity, radius,
+                                      max_distance, rate, buffer_duration, source_id);
+    if (!rc) stream->played = true;
+    return rc;
+}
+
+static int scene_play_buffered_impl(oddio_hip_scene* s, int leaf_kind, oddio_hip_frames* frames, double start_seconds, float phase,
+                                    float freq_hz_or_value, const oddio_hip_filter* filters, int n_filters,
+                                    const float position[3], const float velocity[3], float radius, float max_distance,
+                                    uint32_t rate, float buffer_duration, uint32_t* source_id) {
     if (!s || !position || !velocity) return fail(ODDIO_HIP_EINVAL, "NULL argument");
     if (n_filters < 0 || n_filters > MAX_WRAP || (n_filters && !filters)) return fail(ODDIO_HIP_EINVAL, "0..%d filters", MAX_WRAP);
     if (rate == 0) return fail(ODDIO_HIP_EINVAL, "rate must be > 0");
@@ -682,6 +795,10 @@ extern "C" int oddio_hip_scene_play_buffered(oddio_hip_scene* s, int leaf_kind, 
         if (!frames || frames->device != s->device || frames->channels != 1) return fail(ODDIO_HIP_EINVAL, "Cycle needs a mono clip on the scene device");
         st.clip = frames->dev; st.clip_len = (uint32_t)frames->len; st.clip_rate = frames->rate;
         d.common.t = 0.0;   // Cycle::new (cycle.rs:17-23)
+    } else if (leaf_kind == (int)KIND_STREAM) {
+        if (!frames || frames->device != s->device) return fail(ODDIO_HIP_EINVAL, "the stream lives on another device");
+        st.clip = frames->dev; st.clip_len = (uint32_t)frames->len; st.clip_rate = frames->rate;   // ring of capacity + 1 slots
+        d.common.phase = 0.0f;   // Stream::t (stream.rs:30)
     } else if (leaf_kind == (int)KIND_SINE) {
         st.freq_or_value = freq_hz_or_value * ODDIO_TAU;   // sine.rs:21
         d.common.phase = phase;

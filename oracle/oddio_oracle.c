@@ -234,7 +234,7 @@ void oo_ring_sample(const oo_ring* r, uint32_t rate, float t, float interval, fl
 
 enum {
     K_FRAMES, K_SINE, K_CONSTANT, K_CYCLE, K_FIXED_GAIN, K_GAIN, K_SPEED, K_MONO_TO_STEREO,
-    K_REINHARD, K_TANH, K_MIXER, K_SCENE, K_COUNTING, K_TIME, K_FINISHED, K_ADAPT, K_DOWNMIX
+    K_REINHARD, K_TANH, K_MIXER, K_SCENE, K_COUNTING, K_TIME, K_FINISHED, K_ADAPT, K_DOWNMIX, K_STREAM
 };
 
 typedef struct { int stop; oo_signal* inner; } mixed_entry; /* mixer.rs:46-49 */
@@ -288,6 +288,8 @@ struct oo_signal {
     float gain;        /* FixedGain.gain */
     float shared;      /* Gain.shared / Speed.speed (atomics in the reference) */
     oo_smoothed smooth;
+    /* K_STREAM, stream.rs:6-13 over spsc.rs (ring of capacity + 1 slots, read/write indices) */
+    float* sbuf; size_t ssize, sread, swrite, slen; int sclosed, sstopping; uint32_t srate; float st;
     /* K_ADAPT, adapt.rs:14-18 + AdaptOptions :36-50 */
     float avg_squared, tau, max_gain, low, high;
     /* fixtures */
@@ -367,6 +369,62 @@ oo_signal* oo_adapt_new(oo_signal* inner, float initial_rms, float tau, float ma
     return s;
 }
 void oo_constant_set(oo_signal* s, float v0, float v1) { s->cval[0] = v0; s->cval[1] = v1; } /* adapt.rs:127 `adapt.inner.0 = ..` */
+oo_signal* oo_stream_new(uint32_t rate, size_t size, int channels) { /* stream.rs:24-34, spsc.rs:11-19 */
+    oo_signal* s = sig_new(K_STREAM, channels);
+    s->ssize = size + 1;
+    s->sbuf = calloc(s->ssize * (size_t)channels, sizeof(float));
+    s->srate = rate;
+    return s;
+}
+size_t oo_stream_free(const oo_signal* s) { /* spsc.rs:75-86 */
+    if (s->swrite < s->sread) return s->sread - s->swrite - 1;
+    if (s->sread >= 1) return s->ssize - s->swrite + (s->sread - 1);
+    return s->ssize - s->swrite - 1;
+}
+size_t oo_stream_write(oo_signal* s, const float* data, size_t n) { /* StreamControl::write -> spsc.rs:27-67 */
+    const size_t C = (size_t)s->channels;
+    size_t cap1, cap2;
+    if (s->swrite < s->sread) { cap1 = s->sread - s->swrite - 1; cap2 = 0; }
+    else if (s->sread >= 1) { cap1 = s->ssize - s->swrite; cap2 = s->sread - 1; }
+    else { cap1 = s->ssize - s->swrite - 1; cap2 = 0; }
+    const size_t n1 = cap1 < n ? cap1 : n;
+    memcpy(s->sbuf + s->swrite * C, data, n1 * C * sizeof(float));
+    const size_t rest = n - n1;
+    const size_t n2 = cap2 < rest ? cap2 : rest;
+    memcpy(s->sbuf, data + n1 * C, n2 * C * sizeof(float));
+    s->swrite = (s->swrite + n1 + n2) % s->ssize;
+    return n1 + n2;
+}
+void oo_stream_close(oo_signal* s) { s->sclosed = 1; } /* drop(StreamControl) */
+static float stream_get(const oo_signal* s, int64_t sample, int ch) { /* stream.rs:37-49 */
+    if (sample < 0) return 0.0f;
+    if ((uint64_t)sample >= s->slen) return 0.0f;
+    return s->sbuf[((s->sread + (size_t)sample) % s->ssize) * (size_t)s->channels + (size_t)ch];
+}
+static void stream_sample(oo_signal* s, float interval, float* out, size_t n) { /* stream.rs:69-85 */
+    const int C = s->channels;
+    s->slen = s->swrite >= s->sread ? s->swrite - s->sread : s->swrite + s->ssize - s->sread; /* update(), spsc.rs:128-132 */
+    if (s->sclosed) s->sstopping = 1;
+    const float s0 = s->st;
+    const float ds = interval * (float)s->srate;
+    for (size_t i = 0; i < n; i++) {
+        const float sv = s0 + ds * (float)i;
+        const float x0f = truncf(sv);
+        const int64_t x0 = f64_as_isize((double)x0f);
+        const float fract = sv - x0f; /* f32::fract */
+        for (int c = 0; c < C; c++) out[i * C + c] = lerp1(stream_get(s, x0, c), stream_get(s, x0 + 1, c), fract);
+    }
+    { /* advance(interval * out.len() as f32), stream.rs:59-64 */
+        const float dt = interval * (float)n;
+        const float next = s->st + dt * (float)s->srate;
+        const float t = f32_min(next, (float)s->slen);
+        size_t rel = f32_as_usize(t);
+        if (rel > s->slen) rel = s->slen;
+        s->sread = (s->sread + rel) % s->ssize; /* release(), spsc.rs:135-142 */
+        s->slen -= rel;
+        s->st = t - truncf(t);
+    }
+}
 oo_signal* oo_downmix_new(oo_signal* inner) { oo_signal* s = sig_new(K_DOWNMIX, 1); s->inner = inner; return s; } /* downmix.rs:10-15 */
 oo_signal* oo_reinhard_new(oo_signal* inner) { oo_signal* s = sig_new(K_REINHARD, inner->channels); s->inner = inner; return s; }
 oo_signal* oo_tanh_new(oo_signal* inner) { oo_signal* s = sig_new(K_TANH, inner->channels); s->inner = inner; return s; }
@@ -405,6 +463,7 @@ void oo_signal_free(oo_signal* s) {
     free(s->set.items); free(s->pending.items); free(s->handles.items);
     free(s->bset.items); free(s->bpending.items);
     free(s->staging);
+    free(s->sbuf);
     if (s->data) oo_frames_release(s->data);
     oo_signal_free(s->inner);
     free(s);
@@ -774,6 +833,7 @@ void oo_sample(oo_signal* s, float interval, float* out, size_t n) {
         oo_sample(s->inner, interval, out, n);
         for (size_t i = 0; i < n * C; i++) out[i] = tanhf(out[i]);
         break;
+    case K_STREAM: stream_sample(s, interval, out, n); break;
     case K_DOWNMIX: { /* downmix.rs:23-33: the inner signal always renders the whole 256-frame buffer */
         const int IC = s->inner->channels;
         float buf[256 * 2];
@@ -839,6 +899,7 @@ int oo_is_finished(const oo_signal* s) {
     case K_FRAMES: /* frames.rs:204-206; (len - 1) is usize arithmetic */
         return s->t >= (double)(uint64_t)((uint64_t)s->data->len - 1) / s->data->rate;
     case K_FINISHED: return 1;
+    case K_STREAM: return s->sstopping && s->st == (float)s->slen; /* stream.rs:88-90 */
     case K_FIXED_GAIN: case K_GAIN: case K_SPEED: case K_MONO_TO_STEREO: case K_REINHARD: case K_TANH: case K_ADAPT: case K_DOWNMIX:
         return oo_is_finished(s->inner);
     default: return 0;

@@ -48,6 +48,10 @@ oo_signal* oo_mono_to_stereo_new(oo_signal* inner);                      /* sign
 oo_signal* oo_adapt_new(oo_signal* inner, float initial_rms, float tau, float max_gain,
                        float low, float high);                          /* adapt.rs:25-31, :36-61 */
 void oo_constant_set(oo_signal* s, float v0, float v1);                  /* test fixture: adapt.rs:127 */
+oo_signal* oo_stream_new(uint32_t rate, size_t size, int channels);      /* stream.rs:24-34 */
+size_t oo_stream_write(oo_signal* s, const float* data, size_t n_frames); /* stream.rs:107-113 */
+size_t oo_stream_free(const oo_signal* s);                               /* stream.rs:101-103 */
+void oo_stream_close(oo_signal* s);                                      /* drop(StreamControl) */
 oo_signal* oo_downmix_new(oo_signal* inner);                             /* downmix.rs:10-15 */
 oo_signal* oo_reinhard_new(oo_signal* inner);                            /* reinhard.rs:16-20 */
 oo_signal* oo_tanh_new(oo_signal* inner);                                /* tanh.rs:10-14 */

@@ -49,6 +49,10 @@ def lib():
             "oo_mono_to_stereo_new": (vp, [vp]),
             "oo_reinhard_new": (vp, [vp]),
             "oo_downmix_new": (vp, [vp]),
+            "oo_stream_new": (vp, [C.c_uint32, C.c_size_t, C.c_int]),
+            "oo_stream_write": (C.c_size_t, [vp, fp, C.c_size_t]),
+            "oo_stream_free": (C.c_size_t, [vp]),
+            "oo_stream_close": (None, [vp]),
             "oo_adapt_new": (vp, [vp, f32, f32, f32, f32, f32]),
             "oo_constant_set": (None, [vp, f32, f32]),
             "oo_tanh_new": (vp, [vp]),
@@ -252,6 +256,25 @@ class Speed(Signal):
 class MonoToStereo(Signal):
     def __init__(self, inner: Signal):
         super().__init__(lib().oo_mono_to_stereo_new(inner._h), inner)
+
+
+class Stream(Signal):
+    """Stream::new(rate, size) (src/stream.rs:24-34); the object is both halves: the signal and its
+    StreamControl (`write`, `free`; `close` = dropping the control)."""
+
+    def __init__(self, rate, size, channels=1):
+        super().__init__(lib().oo_stream_new(int(rate), int(size), int(channels)))
+        self._channels = channels
+
+    def write(self, samples):
+        a = np.ascontiguousarray(np.asarray(samples, dtype=np.float32))
+        return int(lib().oo_stream_write(self._h, _fp(a), a.shape[0]))
+
+    def free(self):
+        return int(lib().oo_stream_free(self._h))
+
+    def close(self):
+        lib().oo_stream_close(self._h)
 
 
 class Downmix(Signal):

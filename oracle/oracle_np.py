@@ -407,6 +407,56 @@ def reinhard(x):
     return (x / (ONE + np.abs(x))).astype(f32)
 
 
+class Stream:
+    """src/stream.rs + src/spsc.rs, second transcription: the receiver's window is a Python list
+    (released items are popped), so none of the ring index arithmetic of the C oracle is shared."""
+
+    def __init__(self, rate, size, channels=1):
+        self.rate, self.capacity, self.channels = int(rate), int(size), channels
+        self.sent = []          # written, not yet seen by update()
+        self.window = []        # Receiver: items [0, len)
+        self.t = f32(0.0)
+        self.closed = self.stopping = False
+
+    def free(self):
+        return self.capacity - len(self.sent) - len(self.window)
+
+    def write(self, samples):
+        x = np.asarray(samples, dtype=f32).reshape(len(samples), -1)
+        n = min(self.free(), len(x))
+        self.sent.extend(x[:n])
+        return n
+
+    def close(self):
+        self.closed = True
+
+    def sample(self, interval, n):
+        interval = f32(interval)
+        self.window.extend(self.sent)      # update()
+        self.sent = []
+        if self.closed:
+            self.stopping = True
+        zero = np.zeros(self.channels, dtype=f32)
+        get = lambda k: self.window[k] if 0 <= k < len(self.window) else zero
+        ds = interval * f32(self.rate)
+        out = np.zeros((n, self.channels), dtype=f32)
+        for i in range(n):
+            sv = self.t + ds * f32(i)
+            x0 = int(np.trunc(sv))
+            fract = sv - np.trunc(sv)
+            a, b = get(x0), get(x0 + 1)
+            out[i] = a + fract * (b - a)
+        nxt = self.t + (interval * f32(n)) * f32(self.rate)
+        t = min(nxt, f32(len(self.window)))
+        rel = int(t)
+        del self.window[:rel]
+        self.t = f32(t - np.trunc(t))
+        return out[:, 0] if self.channels == 1 else out
+
+    def is_finished(self):
+        return bool(self.stopping and self.t == f32(len(self.window)))
+
+
 class Adapt:
     """src/adapt.rs:14-87 as a filter over already-rendered frames x[n] or x[n, C] (second,
     independent transcription: the recurrence runs on numpy scalars, the gain law is vectorised)."""

@@ -317,3 +317,51 @@ def test_downmix_renders_whole_buffers():
     np.testing.assert_array_equal(a, 0.5 * np.arange(300, dtype=np.float32))
     b = sig.sample_n(f32(1.0), 4)
     np.testing.assert_array_equal(b, 0.5 * np.arange(512, 516, dtype=np.float32))
+
+
+# ---- src/stream.rs:118-150 --------------------------------------------------------------------
+def _assert_out(stream, expected):
+    np.testing.assert_array_equal(stream.sample_n(f32(1.0), len(expected)), arr(*expected))
+
+
+def test_stream_smoke_kat():
+    s = oo.Stream(1, 3)
+    assert s.write([1.0, 2.0]) == 2
+    assert s.write([3.0, 4.0]) == 1
+    _assert_out(s, [1.0, 2.0, 3.0, 0.0, 0.0])
+    assert s.write([5.0, 6.0, 7.0, 8.0]) == 3
+    _assert_out(s, [5.0])
+    _assert_out(s, [6.0, 7.0, 0.0, 0.0])
+    _assert_out(s, [0.0, 0.0])
+
+
+def test_stream_cleanup_kat():
+    s = oo.Stream(1, 4)
+    assert s.write([1.0, 2.0]) == 2
+    assert not s.is_finished()
+    s.close()                                             # drop(c)
+    assert not s.is_finished()
+    s.sample_n(f32(1.0), 1)
+    assert not s.is_finished()
+    s.sample_n(f32(1.0), 1)
+    assert s.is_finished()
+    s.sample_n(f32(1.0), 1)
+    assert s.is_finished()
+
+
+def test_stream_c_equals_numpy():
+    from oracle import oracle_np as on
+    rng = np.random.default_rng(3)
+    for channels in (1, 2):
+        a, b = oo.Stream(16000, 700, channels), on.Stream(16000, 700, channels)
+        for step in range(40):
+            n = int(rng.integers(0, 500))
+            x = rng.uniform(-1, 1, size=(n, channels)).astype(np.float32) if channels == 2 else rng.uniform(-1, 1, n).astype(np.float32)
+            assert a.write(x) == b.write(x)
+            assert a.free() == b.free()
+            if step == 33:
+                a.close(); b.close()
+            m = int(rng.choice([1, 64, 300, 1024]))
+            interval = np.float32(1.0) / np.float32(rng.choice([48000, 16000, 11025]))
+            np.testing.assert_array_equal(a.sample_n(interval, m), b.sample(interval, m))
+            assert a.is_finished() == b.is_finished()
