@@ -134,3 +134,37 @@ def test_stream_errors():
         c.write(np.zeros((4, 2), np.float32))
     c.drop(); c2.drop()
     mixer.close(); scene.close()
+
+
+def test_stream_concurrent_producer_keeps_order():
+    # a producer thread pushes the ramp 1, 2, 3, ... while the audio thread renders; with ds == 1 and
+    # t == 0 every rendered sample is a ring item or an underflow zero, so the non-zero outputs must be
+    # exactly the ramp, in order, no gaps, no repeats (spsc.rs's acquire/release protocol across PCIe)
+    import threading
+    import oddio_amd as oa
+    control, mixer = oa.Mixer(max_sources=4, max_frames=512)
+    c, s = oa.Stream.new(48000, 4096)
+    control.play(oa.MonoToStereo(s))
+    total = 200_000
+    done = threading.Event()
+
+    def producer():
+        sent = 0
+        while sent < total:
+            chunk = np.arange(sent + 1, min(sent + 1 + 1500, total + 1), dtype=np.float32)
+            sent += c.write(chunk)
+        done.set()
+    th = threading.Thread(target=producer)
+    th.start()
+    got = []
+    idle = 0
+    while idle < 50:
+        o = mixer.sample_n(INTERVAL, 512)[:, 0]
+        nz = o[o != 0.0]
+        got.append(nz)
+        idle = idle + 1 if (done.is_set() and len(nz) == 0) else 0
+    th.join()
+    seq = np.concatenate(got)
+    np.testing.assert_array_equal(seq, np.arange(1, total + 1, dtype=np.float32))
+    c.drop()
+    mixer.close()
