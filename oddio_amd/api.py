@@ -394,6 +394,10 @@ class _SceneSignal(Signal):
     def is_finished(self):
         return False  # spatial.rs:473-476
 
+    def reserve_buffered(self, max_buffered: int):
+        """Capacity of the buffered set (default 256); call before the first play_buffered."""
+        _lib.check(_lib.lib().oddio_hip_scene_reserve_buffered(self._h, int(max_buffered)))
+
     def set_postfx(self, kind):
         _lib.check(_lib.lib().oddio_hip_scene_set_postfx(self._h, int(kind)))
 
