@@ -267,6 +267,20 @@ int oddio_hip_mixer_play_chain(oddio_hip_mixer* mixer, int leaf_kind, oddio_hip_
                                double start_seconds, float phase, float frequency_hz_or_value,
                                const oddio_hip_filter* filters, int n_filters, uint32_t* source_id);
 /* GainControl / SpeedControl of filter `filter_index` of a mixer source */
+/* MixerControl::play(Fader::new(chain).1) (src/fader.rs:16-28) and FaderControl::fade_to (:83-93): the
+ * source cross-fades (constant power, src/fader.rs:57-60) from its current signal to the given chain
+ * over `duration` seconds; a fade in progress completes first, a waiting command is replaced.  Both
+ * signals must have the same channel count.  Fader::is_finished is always false: the source leaves the
+ * mixer only through oddio_hip_mixer_stop.  At most 256 Fader sources per mixer.  Like the reference,
+ * the outgoing signal renders a whole 1024-frame buffer per call while a fade runs (src/fader.rs:51-53).
+ * Arguments as in oddio_hip_mixer_play_chain. */
+int oddio_hip_mixer_play_fader(oddio_hip_mixer* mixer, int leaf_kind, oddio_hip_frames* frames,
+                               double start_seconds, float phase, float frequency_hz_or_value,
+                               const oddio_hip_filter* filters, int n_filters, uint32_t* source_id);
+int oddio_hip_mixer_fade_to(oddio_hip_mixer* mixer, uint32_t source_id, int leaf_kind,
+                            oddio_hip_frames* frames, double start_seconds, float phase,
+                            float frequency_hz_or_value, const oddio_hip_filter* filters,
+                            int n_filters, float duration);
 /* MixerControl::play(filters(Stream)) (a mono stream is wrapped in MonoToStereo like other mono leaves) */
 int oddio_hip_mixer_play_stream(oddio_hip_mixer* mixer, oddio_hip_stream* stream,
                                 const oddio_hip_filter* filters, int n_filters, uint32_t* source_id);

@@ -674,9 +674,9 @@ class MixerControl:
     def __init__(self, mixer):
         self._m = mixer
 
-    def play(self, signal: Signal) -> Mixed:
-        """MixerControl::play for Mixer<[f32;2]>: any nest of FixedGain / Gain / Speed / MonoToStereo
-        around FramesSignal (mono or stereo clip), Cycle, Sine or Constant whose output is stereo."""
+    @staticmethod
+    def _parse(signal):
+        """-> (leaf, [(kind, param, control)] innermost first) for a stereo-output nest"""
         chain, stereo_seen, sig = [], False, signal
         while isinstance(sig, (FixedGain, Gain, Speed, MonoToStereo)):
             if isinstance(sig, MonoToStereo):
@@ -698,22 +698,73 @@ class MixerControl:
         chain = chain[::-1]
         if len(chain) > 4:
             raise TypeError("at most 4 filters")
-        L, m = _lib.lib(), self._m
-        sid = C.c_uint32()
         filt = (_Filter * max(len(chain), 1))()
         for i, (kind, param, _) in enumerate(chain):
             filt[i].kind, filt[i].param = kind, param
-        if isinstance(sig, Stream):
-            if sig.control._h is None:
-                raise ValueError("the StreamControl has already been dropped")
-            _lib.check(L.oddio_hip_mixer_play_stream(m._h, sig.control._h, C.cast(filt, C.c_void_p), len(chain), C.byref(sid)))
-        else:
+        return sig, chain, filt
+
+    def play(self, signal: Signal) -> Mixed:
+        """MixerControl::play for Mixer<[f32;2]>: any nest of FixedGain / Gain / Speed / MonoToStereo
+        around FramesSignal (mono or stereo clip), Cycle, Sine, Constant or Stream whose output is
+        stereo; or a Fader around such a nest."""
+        L, m = _lib.lib(), self._m
+        sid = C.c_uint32()
+        if isinstance(signal, Fader):
+            sig, chain, filt = self._parse(signal.inner)
+            if isinstance(sig, Stream):
+                raise TypeError("Fader<..Stream..> is not implemented on the device path")
             args = _leaf_args(sig, m._keep)
-            _lib.check(L.oddio_hip_mixer_play_chain(m._h, args[0], args[1], args[2], args[3], args[4], C.cast(filt, C.c_void_p), len(chain), C.byref(sid)))
+            _lib.check(L.oddio_hip_mixer_play_fader(m._h, args[0], args[1], args[2], args[3], args[4], C.cast(filt, C.c_void_p), len(chain), C.byref(sid)))
+            signal.control._bind(self, m, sid.value)
+        else:
+            sig, chain, filt = self._parse(signal)
+            if isinstance(sig, Stream):
+                if sig.control._h is None:
+                    raise ValueError("the StreamControl has already been dropped")
+                _lib.check(L.oddio_hip_mixer_play_stream(m._h, sig.control._h, C.cast(filt, C.c_void_p), len(chain), C.byref(sid)))
+            else:
+                args = _leaf_args(sig, m._keep)
+                _lib.check(L.oddio_hip_mixer_play_chain(m._h, args[0], args[1], args[2], args[3], args[4], C.cast(filt, C.c_void_p), len(chain), C.byref(sid)))
         for i, (_, _, control) in enumerate(chain):
             if control is not None:
                 control._bind(m, sid.value, i)
         return Mixed(m, sid.value)
+
+
+class FaderControl:
+    """src/fader.rs:82-93"""
+
+    def __init__(self):
+        self._target = None
+
+    def _bind(self, mixer_control, mixer, sid):
+        self._target = (mixer_control, mixer, sid)
+
+    def fade_to(self, signal: Signal, duration: float):
+        if self._target is None:
+            raise ValueError("the Fader has not been played yet")
+        mc, m, sid = self._target
+        sig, chain, filt = mc._parse(signal)
+        if isinstance(sig, Stream):
+            raise TypeError("fading to a Stream is not implemented on the device path")
+        args = _leaf_args(sig, m._keep)
+        _lib.check(_lib.lib().oddio_hip_mixer_fade_to(m._h, sid, args[0], args[1], args[2], args[3], args[4], C.cast(filt, C.c_void_p), len(chain),
+                                                      np.float32(duration)))
+
+
+class Fader(Signal):
+    """Fader::new(inner) -> (FaderControl, Fader)  (src/fader.rs:16-28).  Device support: played in a Mixer."""
+    channels = 2
+    seekable = False
+
+    def __init__(self, inner: Signal):
+        self.inner = inner
+        self.control = FaderControl()
+
+    @classmethod
+    def new(cls, inner):
+        f = cls(inner)
+        return f.control, f
 
 
 def Mixer(device: int = 0, max_sources: int = 4096, max_frames: int = 4096):

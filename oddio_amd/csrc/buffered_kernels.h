@@ -33,7 +33,8 @@ struct alignas(16) BufStatic {
     uint32_t wrap_kind[MAX_WRAP];
     float wrap_param[MAX_WRAP];   // FixedGain: linear gain
     uint32_t channels;      // 1 (mono) or 2 (interleaved stereo clip; Mixer general path only)
-    uint32_t pad[2];
+    uint32_t fader;         // Mixer general path: 1 + index of this source's FaderRec (0: not a Fader)
+    uint32_t pad;
 };
 static_assert(sizeof(BufStatic) == 96, "BufStatic layout");
 
@@ -345,6 +346,69 @@ __global__ void apply_buf_moves(const BufMove* __restrict__ mv, uint32_t n, BufS
 __global__ void copy_postfx_kernel(const float* __restrict__ in, float* __restrict__ out, uint32_t n, int postfx) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) out[i] = postfx_apply(in[i], postfx);
+}
+
+// ---- Fader (fader.rs:10-80) around a leaf + filter chain, Mixer general path -------------------
+// `next` is what swap::Receiver::received() holds after a refresh (the signal being faded to, or the
+// retired one after a completed fade); `pend` is the control's flushed, not yet refreshed Command.
+struct alignas(16) FaderPending {
+    BufStatic st; BufDyn dyn;
+    float duration;
+    uint32_t fresh;         // swap.rs FRESH_BIT
+    uint32_t pad[2];
+};
+struct alignas(16) FaderRec {
+    BufStatic next_st; BufDyn next_dyn;
+    float progress;         // Fader::progress, 1.0 when no fade is running (fader.rs:21)
+    float duration;         // Command::duration of `next`
+    uint32_t pad[2];
+    FaderPending pend;
+};
+constexpr uint32_t FADER_BUF = 1024;   // fader.rs:51
+
+// Fader::sample (fader.rs:36-73).  `scratch` holds FADER_BUF frames of the source's channel count.
+__device__ void fader_sample(BufStatic& st, BufDyn& dyn, FaderRec& F, float* scratch, float interval, float* out, uint32_t n) {
+    const uint32_t C = st.channels ? st.channels : 1u;
+    if (F.progress >= 1.0f) {
+        if (F.pend.fresh) {                               // self.next.refresh()
+            F.next_st = F.pend.st; F.next_dyn = F.pend.dyn; F.duration = F.pend.duration;
+            F.pend.fresh = 0u;
+            F.progress = 0.0f;
+        } else {
+            inner_sample(st, dyn, interval, out, n);      // fast path
+            return;
+        }
+    }
+    const float increment = interval / F.duration;
+    BufStatic nst = F.next_st;                            // work on registers / private copies, write back once
+    BufDyn ndyn = F.next_dyn;
+    float progress = F.progress;
+    uint32_t off = 0;
+    while (off < n) {
+        const uint32_t rem = n - off;
+        const uint32_t m = rem < FADER_BUF ? rem : FADER_BUF;
+        inner_sample(st, dyn, interval, scratch, FADER_BUF);                    // the whole buffer, fader.rs:53
+        inner_sample(nst, ndyn, interval, out + (size_t)off * C, rem);          // all that is left, :54
+        for (uint32_t k = 0; k < m; ++k) {
+            const float fade_out = sqrtf(1.0f - progress);
+            const float fade_in = sqrtf(progress);
+            for (uint32_t ch = 0; ch < C; ++ch) {
+                float* o = out + (size_t)(off + k) * C + ch;
+                *o = scratch[k * C + ch] * fade_out + *o * fade_in;             // frame::mix(scale(x), scale(o))
+            }
+            progress = fminf(progress + increment, 1.0f);
+        }
+        off += m;
+    }
+    F.progress = progress;
+    if (progress >= 1.0f) {   // mem::swap(&mut self.inner, &mut next.fade_to): slot-level fields stay with the slot
+        F.next_st = st; F.next_dyn = dyn;
+        nst.fader = st.fader;
+        ndyn.common.id = dyn.common.id; ndyn.common.flags = dyn.common.flags;
+        st = nst; dyn = ndyn;
+    } else {
+        F.next_dyn = ndyn;
+    }
 }
 
 }  // namespace oddio_hip

@@ -281,17 +281,20 @@ __global__ __launch_bounds__(1024) void mixer_reduce(const float* __restrict__ p
 // (mixer.rs:100-117) through the filter chain into the source's own slab; mixer_general_reduce then
 // adds the slabs in reverse slot order (bit-identical sum order).  Correctness first, not tuned.
 __global__ __launch_bounds__(64) void mixer_general_sources(uint32_t n_sources, uint32_t n_frames, float interval,
-                                                            const BufStatic* __restrict__ st, BufDyn* __restrict__ dyn,
+                                                            BufStatic* __restrict__ st, BufDyn* __restrict__ dyn,
                                                             float* __restrict__ slabs, uint32_t* __restrict__ skip,
-                                                            uint32_t* __restrict__ stopped_hdr, uint32_t stopped_cap) {
+                                                            uint32_t* __restrict__ stopped_hdr, uint32_t stopped_cap,
+                                                            FaderRec* __restrict__ faders, float* __restrict__ fader_scratch) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_sources) return;
     BufDyn d = dyn[i];
-    const BufStatic s = st[i];
+    BufStatic s = st[i];
     if (d.common.flags & MIXDYN_STOPPED) { skip[i] = 1; return; }
     bool fin = (d.common.flags & MIXDYN_STOP_REQUESTED) != 0;                                                   // mixer.rs:102
-    if (s.kind == KIND_FRAMES) fin = fin || d.common.t >= (double)(s.clip_len - 1u) / (double)s.clip_rate;      // frames.rs:204-206
-    if (s.kind == KIND_STREAM) fin = fin || (d.stream_stopping && d.common.phase == (float)d.stream_len);       // stream.rs:88-90
+    if (!s.fader) {   // Fader::is_finished is always false (fader.rs:76-79)
+        if (s.kind == KIND_FRAMES) fin = fin || d.common.t >= (double)(s.clip_len - 1u) / (double)s.clip_rate;      // frames.rs:204-206
+        if (s.kind == KIND_STREAM) fin = fin || (d.stream_stopping && d.common.phase == (float)d.stream_len);       // stream.rs:88-90
+    }
     if (fin) {
         d.common.flags |= MIXDYN_STOPPED;
         const uint32_t k = atomicAdd(&stopped_hdr[0], 1u);
@@ -305,9 +308,11 @@ __global__ __launch_bounds__(64) void mixer_general_sources(uint32_t n_sources, 
     float* my = slabs + (size_t)i * 2 * n_frames;
     for (uint32_t done = 0; done < n_frames; done += 1024u) {                                                   // mixer.rs:109-117
         const uint32_t len = (n_frames - done) < 1024u ? (n_frames - done) : 1024u;
-        inner_sample(s, d, interval, my + (size_t)done * C, len);
+        if (s.fader) fader_sample(s, d, faders[s.fader - 1u], fader_scratch + (size_t)(s.fader - 1u) * FADER_BUF * 2u, interval, my + (size_t)done * C, len);
+        else inner_sample(s, d, interval, my + (size_t)done * C, len);
     }
     dyn[i] = d;
+    if (s.fader) st[i] = s;   // a completed fade swapped the signals
 }
 
 __global__ void mixer_general_reduce(const float* __restrict__ slabs, const uint32_t* __restrict__ skip, const BufStatic* __restrict__ st,

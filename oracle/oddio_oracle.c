@@ -234,7 +234,7 @@ void oo_ring_sample(const oo_ring* r, uint32_t rate, float t, float interval, fl
 
 enum {
     K_FRAMES, K_SINE, K_CONSTANT, K_CYCLE, K_FIXED_GAIN, K_GAIN, K_SPEED, K_MONO_TO_STEREO,
-    K_REINHARD, K_TANH, K_MIXER, K_SCENE, K_COUNTING, K_TIME, K_FINISHED, K_ADAPT, K_DOWNMIX, K_STREAM
+    K_REINHARD, K_TANH, K_MIXER, K_SCENE, K_COUNTING, K_TIME, K_FINISHED, K_ADAPT, K_DOWNMIX, K_STREAM, K_FADER
 };
 
 typedef struct { int stop; oo_signal* inner; } mixed_entry; /* mixer.rs:46-49 */
@@ -290,6 +290,8 @@ struct oo_signal {
     oo_smoothed smooth;
     /* K_STREAM, stream.rs:6-13 over spsc.rs (ring of capacity + 1 slots, read/write indices) */
     float* sbuf; size_t ssize, sread, swrite, slen; int sclosed, sstopping; uint32_t srate; float st;
+    /* K_FADER, fader.rs:10-14: inner is `inner`; the swap channel's received / pending Commands */
+    float fprogress; oo_signal* fnext; float fduration; oo_signal* fpend; float fpend_duration; int ffresh;
     /* K_ADAPT, adapt.rs:14-18 + AdaptOptions :36-50 */
     float avg_squared, tau, max_gain, low, high;
     /* fixtures */
@@ -425,6 +427,50 @@ static void stream_sample(oo_signal* s, float interval, float* out, size_t n) { 
         s->st = t - truncf(t);
     }
 }
+oo_signal* oo_fader_new(oo_signal* inner) { /* fader.rs:18-28 */
+    oo_signal* s = sig_new(K_FADER, inner->channels);
+    s->inner = inner;
+    s->fprogress = 1.0f;
+    return s;
+}
+void oo_fader_fade_to(oo_signal* s, oo_signal* signal, float duration) { /* fader.rs:86-92: a waiting command is replaced */
+    if (s->ffresh && s->fpend) oo_signal_free(s->fpend);
+    s->fpend = signal; s->fpend_duration = duration; s->ffresh = 1;
+}
+static void fader_sample(oo_signal* s, float interval, float* out, size_t n) { /* fader.rs:36-73 */
+    const int C = s->channels;
+    if (s->fprogress >= 1.0f) {
+        if (s->ffresh) { /* next.refresh(): the retired signal held by `received` is dropped by the control later */
+            if (s->fnext) oo_signal_free(s->fnext);
+            s->fnext = s->fpend; s->fduration = s->fpend_duration;
+            s->fpend = NULL; s->ffresh = 0;
+            s->fprogress = 0.0f;
+        } else {
+            oo_sample(s->inner, interval, out, n);
+            return;
+        }
+    }
+    const float increment = interval / s->fduration;
+    float buffer[1024 * 2];
+    size_t off = 0;
+    while (off < n) {
+        const size_t rem = n - off;
+        const size_t m = rem < 1024 ? rem : 1024;
+        oo_sample(s->inner, interval, buffer, 1024);          /* the whole buffer, :53 */
+        oo_sample(s->fnext, interval, out + off * C, rem);    /* everything that is left, :54 */
+        for (size_t k = 0; k < m; k++) {
+            const float fade_out = sqrtf(1.0f - s->fprogress);
+            const float fade_in = sqrtf(s->fprogress);
+            for (int c = 0; c < C; c++) {
+                float* o = out + (off + k) * C + c;
+                *o = buffer[k * C + c] * fade_out + *o * fade_in;
+            }
+            s->fprogress = f32_min(s->fprogress + increment, 1.0f);
+        }
+        off += m;
+    }
+    if (s->fprogress >= 1.0f) { oo_signal* t = s->inner; s->inner = s->fnext; s->fnext = t; } /* mem::swap, :70 */
+}
 oo_signal* oo_downmix_new(oo_signal* inner) { oo_signal* s = sig_new(K_DOWNMIX, 1); s->inner = inner; return s; } /* downmix.rs:10-15 */
 oo_signal* oo_reinhard_new(oo_signal* inner) { oo_signal* s = sig_new(K_REINHARD, inner->channels); s->inner = inner; return s; }
 oo_signal* oo_tanh_new(oo_signal* inner) { oo_signal* s = sig_new(K_TANH, inner->channels); s->inner = inner; return s; }
@@ -464,6 +510,8 @@ void oo_signal_free(oo_signal* s) {
     free(s->bset.items); free(s->bpending.items);
     free(s->staging);
     free(s->sbuf);
+    oo_signal_free(s->fnext);
+    oo_signal_free(s->fpend);
     if (s->data) oo_frames_release(s->data);
     oo_signal_free(s->inner);
     free(s);
@@ -834,6 +882,7 @@ void oo_sample(oo_signal* s, float interval, float* out, size_t n) {
         for (size_t i = 0; i < n * C; i++) out[i] = tanhf(out[i]);
         break;
     case K_STREAM: stream_sample(s, interval, out, n); break;
+    case K_FADER: fader_sample(s, interval, out, n); break;
     case K_DOWNMIX: { /* downmix.rs:23-33: the inner signal always renders the whole 256-frame buffer */
         const int IC = s->inner->channels;
         float buf[256 * 2];

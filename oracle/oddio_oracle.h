@@ -52,6 +52,8 @@ oo_signal* oo_stream_new(uint32_t rate, size_t size, int channels);      /* stre
 size_t oo_stream_write(oo_signal* s, const float* data, size_t n_frames); /* stream.rs:107-113 */
 size_t oo_stream_free(const oo_signal* s);                               /* stream.rs:101-103 */
 void oo_stream_close(oo_signal* s);                                      /* drop(StreamControl) */
+oo_signal* oo_fader_new(oo_signal* inner);                               /* fader.rs:18-28 */
+void oo_fader_fade_to(oo_signal* fader, oo_signal* signal, float duration); /* fader.rs:86-92 (takes ownership) */
 oo_signal* oo_downmix_new(oo_signal* inner);                             /* downmix.rs:10-15 */
 oo_signal* oo_reinhard_new(oo_signal* inner);                            /* reinhard.rs:16-20 */
 oo_signal* oo_tanh_new(oo_signal* inner);                                /* tanh.rs:10-14 */

@@ -49,6 +49,8 @@ def lib():
             "oo_mono_to_stereo_new": (vp, [vp]),
             "oo_reinhard_new": (vp, [vp]),
             "oo_downmix_new": (vp, [vp]),
+            "oo_fader_new": (vp, [vp]),
+            "oo_fader_fade_to": (None, [vp, vp, f32]),
             "oo_stream_new": (vp, [C.c_uint32, C.c_size_t, C.c_int]),
             "oo_stream_write": (C.c_size_t, [vp, fp, C.c_size_t]),
             "oo_stream_free": (C.c_size_t, [vp]),
@@ -275,6 +277,19 @@ class Stream(Signal):
 
     def close(self):
         lib().oo_stream_close(self._h)
+
+
+class Fader(Signal):
+    """Fader::new(inner) (src/fader.rs:16-28); the object is also its FaderControl (`fade_to`)."""
+
+    def __init__(self, inner: Signal):
+        super().__init__(lib().oo_fader_new(inner._h), inner)
+        self._faded = []
+
+    def fade_to(self, signal: Signal, duration):
+        signal._owned = False
+        self._faded.append(signal)
+        lib().oo_fader_fade_to(self._h, signal._h, np.float32(duration))
 
 
 class Downmix(Signal):

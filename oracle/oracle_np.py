@@ -457,6 +457,57 @@ class Stream:
         return bool(self.stopping and self.t == f32(len(self.window)))
 
 
+class Fader:
+    """src/fader.rs:10-93, second transcription.  Signals are objects with `sample(interval, n)` that
+    return float32 [n] or [n, C] and advance their own state (e.g. `SrcSignal` below)."""
+
+    def __init__(self, inner):
+        self.inner, self.progress = inner, ONE
+        self.received = None          # (signal, duration) held by the swap receiver
+        self.pending = None           # flushed by fade_to, not yet refreshed
+
+    def fade_to(self, signal, duration):
+        self.pending = (signal, f32(duration))
+
+    def sample(self, interval, n):
+        interval = f32(interval)
+        if self.progress >= ONE:
+            if self.pending is not None:
+                self.received, self.pending = self.pending, None
+                self.progress = ZERO
+            else:
+                return self.inner.sample(interval, n)
+        nxt, duration = self.received
+        increment = interval / duration
+        pieces = []
+        remaining = n
+        out_tail = None
+        while remaining > 0:
+            m = min(1024, remaining)
+            buffer = self.inner.sample(interval, 1024)            # the whole buffer every time
+            out_tail = np.array(nxt.sample(interval, remaining))  # everything that is left, again
+            for k in range(m):
+                fade_out = np.sqrt(ONE - self.progress)
+                fade_in = np.sqrt(self.progress)
+                out_tail[k] = buffer[k] * fade_out + out_tail[k] * fade_in
+                self.progress = min(self.progress + increment, ONE)
+            pieces.append(out_tail[:m])
+            remaining -= m
+        if self.progress >= ONE:
+            self.inner, self.received = nxt, (self.inner, duration)
+        return np.concatenate(pieces).astype(f32)
+
+
+class SrcSignal:
+    """Adapter: a source dict of this module (frames / sine / constant / cycle / downmix) as an object."""
+
+    def __init__(self, src):
+        self.src = src
+
+    def sample(self, interval, n):
+        return src_sample(self.src, interval, n)
+
+
 class Adapt:
     """src/adapt.rs:14-87 as a filter over already-rendered frames x[n] or x[n, C] (second,
     independent transcription: the recurrence runs on numpy scalars, the gain law is vectorised)."""
