@@ -848,9 +848,24 @@ __global__ __launch_bounds__(256) void reduce_stage1(const float* __restrict__ p
     }
 }
 
+// The callback's list of stopped sources goes straight into pinned host memory (no memcpy packet) and
+// the device counter is re-armed for the ring slot's next use (no memset packet).  One block.
+__device__ __forceinline__ void publish_stopped_block(uint32_t* __restrict__ dev_hdr, uint32_t* __restrict__ host_hdr, uint32_t cap) {
+    const uint32_t count = dev_hdr[0];
+    const uint32_t n = count < cap ? count : cap;
+    for (uint32_t k = threadIdx.x; k < n; k += blockDim.x) host_hdr[1 + k] = dev_hdr[1 + k];
+    __syncthreads();
+    if (threadIdx.x == 0) { host_hdr[0] = count; dev_hdr[0] = 0u; }
+}
+__global__ __launch_bounds__(256) void publish_stopped(uint32_t* __restrict__ dev_hdr, uint32_t* __restrict__ host_hdr, uint32_t cap) {
+    publish_stopped_block(dev_hdr, host_hdr, cap);
+}
+
 // stage 2: out[o] = stage1[0][o] + stage1[1][o] + ... (fixed order), then Reinhard / Tanh
 __global__ __launch_bounds__(256) void reduce_stage2(const float* __restrict__ stage1, float* __restrict__ out,
-                                                     uint32_t n_wgs, uint32_t n_frames, int postfx) {
+                                                     uint32_t n_wgs, uint32_t n_frames, int postfx,
+                                                     uint32_t* __restrict__ stopped_dev, uint32_t* __restrict__ stopped_host, uint32_t stopped_cap) {
+    if (blockIdx.x == gridDim.x - 1) publish_stopped_block(stopped_dev, stopped_host, stopped_cap);   // after every producer of the list
     const uint32_t o = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t n_out = 2 * n_frames;
     if (o >= n_out) return;

@@ -352,6 +352,7 @@ struct oddio_hip_scene {
     SlotMove* d_moves = nullptr;
     // pinned staging
     uint32_t* h_stopped[RING] = {nullptr, nullptr};
+    uint32_t* hd_stopped[RING] = {nullptr, nullptr};   // the same pinned buffers as the device addresses them
     float* h_out = nullptr;
     hipEvent_t ev_stopped[RING] = {nullptr, nullptr};
     bool ring_busy[RING] = {false, false};
@@ -438,7 +439,10 @@ extern "C" int oddio_hip_scene_create(int device, uint32_t max_sources, uint32_t
     SC_TRY(hipHostMalloc(&s->h_out, (size_t)2 * max_frames * sizeof(float), hipHostMallocDefault));
     for (int r = 0; r < RING; ++r) {
         SC_TRY(hipMalloc(&s->d_stopped[r], (1 + STOPPED_CAP) * sizeof(uint32_t)));
-        SC_TRY(hipHostMalloc(&s->h_stopped[r], (1 + STOPPED_CAP) * sizeof(uint32_t), hipHostMallocDefault));
+        SC_TRY(hipHostMalloc(&s->h_stopped[r], (1 + STOPPED_CAP) * sizeof(uint32_t), hipHostMallocMapped));
+        SC_TRY(hipHostGetDevicePointer((void**)&s->hd_stopped[r], s->h_stopped[r], 0));
+        SC_TRY(hipMemsetAsync(s->d_stopped[r], 0, sizeof(uint32_t), s->stream));
+        s->h_stopped[r][0] = 0;
         SC_TRY(hipEventCreateWithFlags(&s->ev_stopped[r], hipEventDisableTiming));
     }
     SC_TRY(hipMemsetAsync(s->d_pend, 0, cap * sizeof(SrcPending), s->stream));
@@ -1115,7 +1119,6 @@ static int scene_sample_impl(oddio_hip_scene* s, float interval, float* host_out
     float* out_dev = dev_out ? dev_out : s->d_out;
     const bool prof = s->profiling && !s->ev_prof.empty();
     hipEvent_t* pev = prof ? &s->ev_prof[(s->prof_calls % oddio_hip_scene::PROF_RING) * 4] : nullptr;
-    HIP_TRY(hipMemsetAsync(s->d_stopped[r], 0, sizeof(uint32_t), s->stream));
     if (prof) HIP_TRY(hipEventRecord(pev[0], s->stream));
     if (s->len > 0) {
         hipLaunchKernelGGL(spatial_prepass, dim3((s->len + 255) / 256), dim3(256), 0, s->stream, P, s->d_static, s->d_dyn, s->d_pend,
@@ -1157,6 +1160,7 @@ static int scene_sample_impl(oddio_hip_scene* s, float interval, float* host_out
         HIP_TRY(hipGetLastError());
     }
     if (prof) HIP_TRY(hipEventRecord(pev[2], s->stream));
+    bool stopped_published = false;
     if (n_frames > 0) {
         const uint32_t n_out = 2u * (uint32_t)n_frames;
         const int fused_postfx = s->adapt.on ? 0 : s->postfx;   // with Adapt the filter order is Reinhard(Adapt(scene))
@@ -1164,7 +1168,8 @@ static int scene_sample_impl(oddio_hip_scene* s, float interval, float* host_out
             hipLaunchKernelGGL(reduce_stage1, dim3(((uint32_t)n_frames + 31) / 32, RED_SPLIT), dim3(256), 0, s->stream, s->d_partials, s->d_stage1,
                                n_wgs, (uint32_t)n_frames);
             hipLaunchKernelGGL(reduce_stage2, dim3((n_out + 255) / 256), dim3(256), 0, s->stream, s->d_stage1, out_dev, n_wgs,
-                               (uint32_t)n_frames, fused_postfx);
+                               (uint32_t)n_frames, fused_postfx, s->d_stopped[r], s->hd_stopped[r], STOPPED_CAP);
+            stopped_published = true;
         } else if (init) {
             hipLaunchKernelGGL(copy_postfx_kernel, dim3((n_out + 255) / 256), dim3(256), 0, s->stream, init, out_dev, n_out, fused_postfx);
         } else {
@@ -1176,7 +1181,10 @@ static int scene_sample_impl(oddio_hip_scene* s, float interval, float* host_out
     if (prof) { HIP_TRY(hipEventRecord(pev[3], s->stream)); s->prof_calls++; }
 
     // ---- results back ----
-    HIP_TRY(hipMemcpyAsync(s->h_stopped[r], s->d_stopped[r], (1 + STOPPED_CAP) * sizeof(uint32_t), hipMemcpyDeviceToHost, s->stream));
+    if (!stopped_published) {   // paths without a reduce (empty Seek set, zero frames)
+        hipLaunchKernelGGL(publish_stopped, dim3(1), dim3(256), 0, s->stream, s->d_stopped[r], s->hd_stopped[r], STOPPED_CAP);
+        HIP_TRY(hipGetLastError());
+    }
     HIP_TRY(hipEventRecord(s->ev_stopped[r], s->stream));
     s->ring_busy[r] = true;
     s->ring_nsrc[r] = s->len;
