@@ -206,3 +206,56 @@ def test_mixer_random_operations_bit_exact(seed):
         assert [e[0].is_stopped() for e in live] == [e[1].is_stopped() for e in live]
     assert clip_no >= 15 and stops >= 3
     mixer.close()
+
+
+def test_control_thread_races_with_audio_thread():
+    # SpatialSceneControl / Spatial handles are Send and used from another thread while the audio thread
+    # renders (src/spatial.rs:267-350, src/set.rs:125-126): hammer the C ABI's control calls concurrently
+    # with sample(); nothing may fail, output stays finite, and every source played is accounted for.
+    import threading
+    import oddio_amd as oa
+    control, scene = oa.SpatialScene(max_sources=2048, max_frames=1024)
+    clips = [oa.Frames.from_slice(48000, synth.noise_clip(5, i, 4000 + 500 * i)) for i in range(8)]
+    stop = threading.Event()
+    errors, played = [], []
+
+    def controller(seed):
+        rng = np.random.default_rng(seed)
+        mine = []
+        try:
+            while not stop.is_set():
+                op = rng.integers(0, 4)
+                if op == 0 and len(mine) < 400:
+                    h = control.play(oa.FramesSignal(clips[int(rng.integers(0, 8))], float(rng.uniform(0, 0.02))),
+                                     oa.SpatialOptions(_vec(rng, 10.0), _vec(rng, 20.0), 0.1))
+                    mine.append(h)
+                elif op == 1 and mine:
+                    mine[int(rng.integers(0, len(mine)))].set_motion(_vec(rng, 10.0), _vec(rng, 20.0), bool(rng.random() < 0.2))
+                elif op == 2:
+                    q = rng.normal(size=4).astype(np.float32)
+                    control.set_listener_rotation((q / np.linalg.norm(q)).astype(np.float32))
+                elif mine:
+                    mine[int(rng.integers(0, len(mine)))].is_finished()
+        except Exception as e:     # noqa: BLE001
+            errors.append(e)
+        played.append(mine)
+
+    threads = [threading.Thread(target=controller, args=(s,)) for s in (1, 2, 3)]
+    for t in threads:
+        t.start()
+    try:
+        for cb in range(300):
+            out = scene.sample_n(INTERVAL, int((1024, 256, 700)[cb % 3]))
+            assert np.isfinite(out).all()
+    finally:
+        stop.set()
+        for t in threads:
+            t.join()
+    assert not errors, errors
+    handles = [h for mine in played for h in mine]
+    assert len(handles) > 50
+    for _ in range(40):                      # clips are <= 0.16 s: everything finishes and is removed
+        scene.sample_n(INTERVAL, 1024)
+    assert len(scene) == 0
+    assert all(h.is_finished() for h in handles)
+    scene.close()
