@@ -415,7 +415,7 @@ extern "C" int oddio_hip_scene_create(int device, uint32_t max_sources, uint32_t
     s->device = device; s->max_sources = max_sources; s->max_frames = max_frames;
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) != hipSuccess) { delete s; return fail(ODDIO_HIP_ENODEV, "hipGetDeviceProperties failed"); }
-    {   // mix-kernel waves per CU (one wave = one 64-thread workgroup); tunable for experiments
+    {   // resident mix-kernel waves per CU, summed over the tiles of a callback; tunable for experiments
         uint32_t per_cu = MIX_WAVES_PER_CU;
         if (const char* e = getenv("ODDIO_HIP_WAVES_PER_CU")) { int v = atoi(e); if (v > 0 && v <= 64) per_cu = (uint32_t)v; }
         s->waves_cap = (uint32_t)prop.multiProcessorCount * per_cu;
@@ -1147,7 +1147,10 @@ static int scene_sample_impl(oddio_hip_scene* s, float interval, float* host_out
     const uint32_t n_tiles = ((uint32_t)n_frames + TILE_FRAMES - 1) / TILE_FRAMES;
     if (n_frames > 0 && s->len > 0) {
         const uint32_t n_groups = (s->len + MIX_GROUP - 1) / MIX_GROUP;
-        uint32_t waves = s->mode == ODDIO_HIP_MODE_ORDERED ? 1u : std::min(n_groups, s->waves_cap);
+        // one round of workgroups: the waves of ALL tiles together fill the chip once (waves_cap resident
+        // waves); more, shorter workgroups only add partial tiles and per-workgroup overhead
+        const uint32_t cap_tile = std::max<uint32_t>(MIX_WG_WAVES, s->waves_cap / std::max(1u, n_tiles));
+        uint32_t waves = s->mode == ODDIO_HIP_MODE_ORDERED ? 1u : std::min(n_groups, cap_tile);
         const uint32_t gpw = (n_groups + waves - 1) / waves;
         waves = (n_groups + gpw - 1) / gpw;
         // whole workgroups of MIX_WG_WAVES independent waves (trailing waves get an empty range)
