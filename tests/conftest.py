@@ -26,6 +26,18 @@ def pytest_configure(config):
             pass
 
 
+def pytest_sessionstart(session):
+    # A fresh checkout has no built artefacts (they are git-ignored): build the product library once so
+    # the symbol-export tests (CPU) and the parity tests (GPU) can load it.  The library itself never
+    # builds or falls back on its own: oddio_amd._lib raises if libodd_hip.so is missing.
+    try:
+        from oddio_amd import _lib
+        if not os.path.exists(_lib.SO_PATH):
+            _lib.build()
+    except Exception as e:     # noqa: BLE001 -- let the tests that need it report the failure
+        print(f"[conftest] could not build libodd_hip.so: {e}", file=sys.stderr)
+
+
 def pytest_collection_modifyitems(config, items):
     if _gpu_present():
         return
