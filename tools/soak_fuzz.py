@@ -1,0 +1,18 @@
+#!/usr/bin/env python
+"""Extended soak: the randomised scene and mixer tests of tests/test_hip_fuzz.py over many more seeds
+(GPU box).  usage: python tools/soak_fuzz.py [first_seed [n_seeds]]"""
+import sys
+sys.path.insert(0, "tests"); sys.path.insert(0, ".")
+import test_hip_fuzz as t
+import numpy as np
+fails = 0
+first = int(sys.argv[1]) if len(sys.argv) > 1 else 100
+count = int(sys.argv[2]) if len(sys.argv) > 2 else 60
+for seed in range(first, first + count):
+    try:
+        t.test_random_operations_bit_exact(seed)
+        t.test_mixer_random_operations_bit_exact(seed)
+    except AssertionError as e:
+        fails += 1
+        print("seed", seed, "FAILED", str(e)[:300])
+print("soak done, failures:", fails)
