@@ -220,6 +220,20 @@ int oddio_hip_scene_kernel_ms_history(oddio_hip_scene* scene, float* ms, size_t 
 int oddio_hip_debug_mix_occupancy(int device, int* blocks_per_cu, int* num_cus, int* vgprs,
                                   int* lds_bytes);
 
+/* SpatialSceneControl::play_buffered(Fader::new(chain).1, ..) (src/fader.rs:16-28) and
+ * FaderControl::fade_to (:83-93) for that source: see oddio_hip_mixer_play_fader for the semantics.
+ * Arguments as in oddio_hip_scene_play_buffered; at most 256 Fader sources per scene. */
+int oddio_hip_scene_play_buffered_fader(oddio_hip_scene* scene, int leaf_kind, oddio_hip_frames* frames,
+                                        double start_seconds, float phase, float frequency_hz_or_value,
+                                        const oddio_hip_filter* filters, int n_filters,
+                                        const float position[3], const float velocity[3], float radius,
+                                        float max_distance, uint32_t rate, float buffer_duration,
+                                        uint32_t* source_id);
+int oddio_hip_source_fade_to(oddio_hip_scene* scene, uint32_t source_id, int leaf_kind,
+                             oddio_hip_frames* frames, double start_seconds, float phase,
+                             float frequency_hz_or_value, const oddio_hip_filter* filters,
+                             int n_filters, float duration);
+
 /* ---- Stream (src/stream.rs) ------------------------------------------------------------------
  * Stream::new(rate, size) -> (StreamControl, Stream) (src/stream.rs:24-34): dynamic audio pushed by
  * another thread.  The SPSC ring (src/spsc.rs) lives in pinned, GPU-visible host memory: `write` is a

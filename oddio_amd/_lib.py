@@ -82,6 +82,8 @@ def lib():
         "oddio_hip_stream_free": (i32, [vp, C.POINTER(C.c_size_t)]),
         "oddio_hip_stream_drop": (i32, [vp]),
         "oddio_hip_scene_play_buffered_stream": (i32, [vp, vp, vp, i32, fp, fp, f32, f32, u32, f32, u32p]),
+        "oddio_hip_scene_play_buffered_fader": (i32, [vp, i32, vp, f64, f32, f32, vp, i32, fp, fp, f32, f32, u32, f32, u32p]),
+        "oddio_hip_source_fade_to": (i32, [vp, u32, i32, vp, f64, f32, f32, vp, i32, f32]),
         "oddio_hip_mixer_play_fader": (i32, [vp, i32, vp, f64, f32, f32, vp, i32, u32p]),
         "oddio_hip_mixer_fade_to": (i32, [vp, u32, i32, vp, f64, f32, f32, vp, i32, f32]),
         "oddio_hip_mixer_play_stream": (i32, [vp, vp, vp, i32, u32p]),

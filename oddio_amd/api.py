@@ -480,14 +480,23 @@ class SpatialSceneControl:
         """SpatialSceneControl::play_buffered (src/spatial.rs:314-340)."""
         if signal.channels != 1:
             raise TypeError("signals in a spatial scene must be single-channel")
-        leaf, chain = _unwrap_chain(signal)
+        fader = signal if isinstance(signal, Fader) else None
+        leaf, chain = _unwrap_chain(signal.inner if fader else signal)
         L, s = _lib.lib(), self._scene
         sid = C.c_uint32()
         pos, vel = _vec3(options.position), _vec3(options.velocity)
         filt = (_Filter * max(len(chain), 1))()
         for i, (kind, param, _) in enumerate(chain):
             filt[i].kind, filt[i].param = kind, param
-        if isinstance(leaf, Stream):
+        if fader is not None:
+            if isinstance(leaf, Stream):
+                raise TypeError("Fader<..Stream..> is not implemented on the device path")
+            args = _leaf_args(leaf, s._keep)
+            _lib.check(L.oddio_hip_scene_play_buffered_fader(s._h, args[0], args[1], args[2], args[3], args[4], C.cast(filt, C.c_void_p), len(chain),
+                                                             _fp(pos), _fp(vel), np.float32(options.radius), np.float32(max_distance), int(rate),
+                                                             np.float32(buffer_duration), C.byref(sid)))
+            fader.control._bind_scene(s, sid.value)
+        elif isinstance(leaf, Stream):
             if leaf.control._h is None:
                 raise ValueError("the StreamControl has already been dropped")
             _lib.check(L.oddio_hip_scene_play_buffered_stream(s._h, leaf.control._h, C.cast(filt, C.c_void_p), len(chain), _fp(pos), _fp(vel),
@@ -740,10 +749,24 @@ class FaderControl:
     def _bind(self, mixer_control, mixer, sid):
         self._target = (mixer_control, mixer, sid)
 
+    def _bind_scene(self, scene, sid):
+        self._target = (None, scene, sid)
+
     def fade_to(self, signal: Signal, duration: float):
         if self._target is None:
             raise ValueError("the Fader has not been played yet")
         mc, m, sid = self._target
+        if mc is None:      # a buffered source of a spatial scene
+            leaf, chain = _unwrap_chain(signal)
+            if isinstance(leaf, Stream):
+                raise TypeError("fading to a Stream is not implemented on the device path")
+            filt = (_Filter * max(len(chain), 1))()
+            for i, (kind, param, _) in enumerate(chain):
+                filt[i].kind, filt[i].param = kind, param
+            args = _leaf_args(leaf, m._keep)
+            _lib.check(_lib.lib().oddio_hip_source_fade_to(m._h, sid, args[0], args[1], args[2], args[3], args[4], C.cast(filt, C.c_void_p),
+                                                           len(chain), np.float32(duration)))
+            return
         sig, chain, filt = mc._parse(signal)
         if isinstance(sig, Stream):
             raise TypeError("fading to a Stream is not implemented on the device path")
@@ -753,12 +776,13 @@ class FaderControl:
 
 
 class Fader(Signal):
-    """Fader::new(inner) -> (FaderControl, Fader)  (src/fader.rs:16-28).  Device support: played in a Mixer."""
-    channels = 2
+    """Fader::new(inner) -> (FaderControl, Fader)  (src/fader.rs:16-28).  Device support: played in a
+    Mixer, or as a buffered source of a spatial scene."""
     seekable = False
 
     def __init__(self, inner: Signal):
         self.inner = inner
+        self.channels = inner.channels
         self.control = FaderControl()
 
     @classmethod

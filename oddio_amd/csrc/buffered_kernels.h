@@ -199,16 +199,95 @@ __device__ void inner_sample(const BufStatic& s, BufDyn& d, float interval, floa
     }
 }
 
+// ---- Fader (fader.rs:10-93) around a leaf + filter chain (general, thread-per-source paths) -----
+// `next` is what swap::Receiver::received() holds after a refresh (the signal being faded to, or the
+// retired one after a completed fade); `pend` is the control's flushed, not yet refreshed Command.
+// Only the SIGNAL part of a BufStatic / BufDyn pair takes part (leaf, filters, clocks, smoothers);
+// the slot's own state (ring, motion, flags, ids) stays where it is.
+struct alignas(16) FaderPending {
+    BufStatic st; BufDyn dyn;
+    float duration;
+    uint32_t fresh;         // swap.rs FRESH_BIT
+    uint32_t pad[2];
+};
+struct alignas(16) FaderRec {
+    BufStatic next_st; BufDyn next_dyn;
+    float progress;         // Fader::progress, 1.0 when no fade is running (fader.rs:21)
+    float duration;         // Command::duration of `next`
+    uint32_t pad[2];
+    FaderPending pend;
+};
+constexpr uint32_t FADER_BUF = 1024;   // fader.rs:51
+
+__device__ __forceinline__ void signal_assign(BufStatic& st, BufDyn& dyn, const BufStatic& from_st, const BufDyn& from_dyn) {
+    st.clip = from_st.clip; st.clip_len = from_st.clip_len; st.clip_rate = from_st.clip_rate;
+    st.freq_or_value = from_st.freq_or_value; st.kind = from_st.kind; st.channels = from_st.channels;
+    st.n_wrap = from_st.n_wrap;
+    for (int w = 0; w < MAX_WRAP; ++w) {
+        st.wrap_kind[w] = from_st.wrap_kind[w]; st.wrap_param[w] = from_st.wrap_param[w];
+        dyn.shared[w] = from_dyn.shared[w]; dyn.sm_prev[w] = from_dyn.sm_prev[w];
+        dyn.sm_next[w] = from_dyn.sm_next[w]; dyn.sm_progress[w] = from_dyn.sm_progress[w];
+    }
+    dyn.common.t = from_dyn.common.t; dyn.common.phase = from_dyn.common.phase;
+    dyn.stream_len = from_dyn.stream_len; dyn.stream_stopping = from_dyn.stream_stopping;
+}
+
+// Fader::sample (fader.rs:36-73).  `scratch` holds FADER_BUF frames of the source's channel count.
+__device__ void fader_sample(BufStatic& st, BufDyn& dyn, FaderRec& F, float* scratch, float interval, float* out, uint32_t n) {
+    const uint32_t C = st.channels ? st.channels : 1u;
+    if (F.progress >= 1.0f) {
+        if (F.pend.fresh) {                               // self.next.refresh()
+            F.next_st = F.pend.st; F.next_dyn = F.pend.dyn; F.duration = F.pend.duration;
+            F.pend.fresh = 0u;
+            F.progress = 0.0f;
+        } else {
+            inner_sample(st, dyn, interval, out, n);      // fast path
+            return;
+        }
+    }
+    const float increment = interval / F.duration;
+    BufStatic nst = F.next_st;                            // private copies, written back once
+    BufDyn ndyn = F.next_dyn;
+    float progress = F.progress;
+    uint32_t off = 0;
+    while (off < n) {
+        const uint32_t rem = n - off;
+        const uint32_t m = rem < FADER_BUF ? rem : FADER_BUF;
+        inner_sample(st, dyn, interval, scratch, FADER_BUF);                    // the whole buffer, fader.rs:53
+        inner_sample(nst, ndyn, interval, out + (size_t)off * C, rem);          // all that is left, :54
+        for (uint32_t k = 0; k < m; ++k) {
+            const float fade_out = sqrtf(1.0f - progress);
+            const float fade_in = sqrtf(progress);
+            for (uint32_t ch = 0; ch < C; ++ch) {
+                float* o = out + (size_t)(off + k) * C + ch;
+                *o = scratch[k * C + ch] * fade_out + *o * fade_in;             // frame::mix(scale(x), scale(o))
+            }
+            progress = fminf(progress + increment, 1.0f);
+        }
+        off += m;
+    }
+    F.progress = progress;
+    if (progress >= 1.0f) {   // mem::swap(&mut self.inner, &mut next.fade_to)
+        const BufStatic old_st = st;
+        const BufDyn old_dyn = dyn;
+        signal_assign(st, dyn, nst, ndyn);
+        signal_assign(F.next_st, F.next_dyn, old_st, old_dyn);
+    } else {
+        F.next_dyn = ndyn;
+    }
+}
+
 // One thread per buffered slot: walk_set (spatial.rs:191-265) + the buffered mix closure
 // (spatial.rs:402-431).  contrib is [slot][n_frames][2]; skip[slot] != 0 means "not mixed".
-__global__ __launch_bounds__(64) void buffered_sources(SceneParams P, uint32_t n_buffered, const BufStatic* __restrict__ st,
+__global__ __launch_bounds__(64) void buffered_sources(SceneParams P, uint32_t n_buffered, BufStatic* __restrict__ st,
                                                        BufDyn* __restrict__ dyn, SrcPending* __restrict__ pend,
                                                        float* __restrict__ contrib, uint32_t* __restrict__ skip,
-                                                       uint32_t* __restrict__ stopped_hdr, uint32_t stopped_cap) {
+                                                       uint32_t* __restrict__ stopped_hdr, uint32_t stopped_cap,
+                                                       FaderRec* __restrict__ faders, float* __restrict__ fader_scratch) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_buffered) return;
     BufDyn d = dyn[i];
-    const BufStatic s = st[i];
+    BufStatic s = st[i];
     SrcDyn& c = d.common;
     if (c.flags & DYN_STOPPED) { skip[i] = 1; return; }
     const float elapsed = P.elapsed;
@@ -241,8 +320,10 @@ __global__ __launch_bounds__(64) void buffered_sources(SceneParams P, uint32_t n
         else c.finished_for = c.finished_for + elapsed;
     } else {
         bool fin = false;
-        if (s.kind == KIND_FRAMES) fin = c.t >= (double)(s.clip_len - 1u) / (double)s.clip_rate;   // is_finished passes through the filters
-        if (s.kind == KIND_STREAM) fin = d.stream_stopping && c.phase == (float)d.stream_len;       // stream.rs:88-90
+        if (!s.fader) {   // Fader::is_finished is always false (fader.rs:76-79)
+            if (s.kind == KIND_FRAMES) fin = c.t >= (double)(s.clip_len - 1u) / (double)s.clip_rate;   // is_finished passes through the filters
+            if (s.kind == KIND_STREAM) fin = d.stream_stopping && c.phase == (float)d.stream_len;       // stream.rs:88-90
+        }
         if (fin) { c.flags |= DYN_HAS_FINISHED_FOR; c.finished_for = elapsed; }
     }
     if (c.flags & DYN_STOPPED) {
@@ -260,12 +341,21 @@ __global__ __launch_bounds__(64) void buffered_sources(SceneParams P, uint32_t n
         const size_t start_idx = f32_as_usize(ceilf(d.ring_write));
         const size_t end_idx = f32_as_usize(ceilf(end));
         const float interval = 1.0f / (float)s.rate;
+        FaderRec* F = s.fader ? &faders[s.fader - 1u] : nullptr;
+        float* fscr = s.fader ? fader_scratch + (size_t)(s.fader - 1u) * FADER_BUF : nullptr;
         if (end_idx > start_idx) {
-            inner_sample(s, d, interval, ring + start_idx, (uint32_t)(end_idx - start_idx));
+            if (F) fader_sample(s, d, *F, fscr, interval, ring + start_idx, (uint32_t)(end_idx - start_idx));
+            else inner_sample(s, d, interval, ring + start_idx, (uint32_t)(end_idx - start_idx));
         } else {
-            inner_sample(s, d, interval, ring + start_idx, (uint32_t)(len - start_idx));
-            inner_sample(s, d, interval, ring, (uint32_t)end_idx);
+            if (F) {
+                fader_sample(s, d, *F, fscr, interval, ring + start_idx, (uint32_t)(len - start_idx));
+                fader_sample(s, d, *F, fscr, interval, ring, (uint32_t)end_idx);
+            } else {
+                inner_sample(s, d, interval, ring + start_idx, (uint32_t)(len - start_idx));
+                inner_sample(s, d, interval, ring, (uint32_t)end_idx);
+            }
         }
+        if (F) st[i] = s;   // a completed fade swapped the signals
         d.ring_write = end;
     }
     __threadfence_block();
@@ -346,69 +436,6 @@ __global__ void apply_buf_moves(const BufMove* __restrict__ mv, uint32_t n, BufS
 __global__ void copy_postfx_kernel(const float* __restrict__ in, float* __restrict__ out, uint32_t n, int postfx) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) out[i] = postfx_apply(in[i], postfx);
-}
-
-// ---- Fader (fader.rs:10-80) around a leaf + filter chain, Mixer general path -------------------
-// `next` is what swap::Receiver::received() holds after a refresh (the signal being faded to, or the
-// retired one after a completed fade); `pend` is the control's flushed, not yet refreshed Command.
-struct alignas(16) FaderPending {
-    BufStatic st; BufDyn dyn;
-    float duration;
-    uint32_t fresh;         // swap.rs FRESH_BIT
-    uint32_t pad[2];
-};
-struct alignas(16) FaderRec {
-    BufStatic next_st; BufDyn next_dyn;
-    float progress;         // Fader::progress, 1.0 when no fade is running (fader.rs:21)
-    float duration;         // Command::duration of `next`
-    uint32_t pad[2];
-    FaderPending pend;
-};
-constexpr uint32_t FADER_BUF = 1024;   // fader.rs:51
-
-// Fader::sample (fader.rs:36-73).  `scratch` holds FADER_BUF frames of the source's channel count.
-__device__ void fader_sample(BufStatic& st, BufDyn& dyn, FaderRec& F, float* scratch, float interval, float* out, uint32_t n) {
-    const uint32_t C = st.channels ? st.channels : 1u;
-    if (F.progress >= 1.0f) {
-        if (F.pend.fresh) {                               // self.next.refresh()
-            F.next_st = F.pend.st; F.next_dyn = F.pend.dyn; F.duration = F.pend.duration;
-            F.pend.fresh = 0u;
-            F.progress = 0.0f;
-        } else {
-            inner_sample(st, dyn, interval, out, n);      // fast path
-            return;
-        }
-    }
-    const float increment = interval / F.duration;
-    BufStatic nst = F.next_st;                            // work on registers / private copies, write back once
-    BufDyn ndyn = F.next_dyn;
-    float progress = F.progress;
-    uint32_t off = 0;
-    while (off < n) {
-        const uint32_t rem = n - off;
-        const uint32_t m = rem < FADER_BUF ? rem : FADER_BUF;
-        inner_sample(st, dyn, interval, scratch, FADER_BUF);                    // the whole buffer, fader.rs:53
-        inner_sample(nst, ndyn, interval, out + (size_t)off * C, rem);          // all that is left, :54
-        for (uint32_t k = 0; k < m; ++k) {
-            const float fade_out = sqrtf(1.0f - progress);
-            const float fade_in = sqrtf(progress);
-            for (uint32_t ch = 0; ch < C; ++ch) {
-                float* o = out + (size_t)(off + k) * C + ch;
-                *o = scratch[k * C + ch] * fade_out + *o * fade_in;             // frame::mix(scale(x), scale(o))
-            }
-            progress = fminf(progress + increment, 1.0f);
-        }
-        off += m;
-    }
-    F.progress = progress;
-    if (progress >= 1.0f) {   // mem::swap(&mut self.inner, &mut next.fade_to): slot-level fields stay with the slot
-        F.next_st = st; F.next_dyn = dyn;
-        nst.fader = st.fader;
-        ndyn.common.id = dyn.common.id; ndyn.common.flags = dyn.common.flags;
-        st = nst; dyn = ndyn;
-    } else {
-        F.next_dyn = ndyn;
-    }
 }
 
 }  // namespace oddio_hip

@@ -267,6 +267,8 @@ struct HandleRec {
     float* ring = nullptr;         // device Ring of a buffered source
     uint64_t motion_epoch = 0;     // dedupe stamp for set_motion
     oddio_hip_frames* frames = nullptr;
+    uint32_t fader = 0;                          // 1 + FaderRec index of a buffered Fader source
+    std::vector<oddio_hip_frames*> fade_frames;  // clips of the signals handed to fade_to
 };
 
 struct PendingPlay { uint32_t id; SrcStatic st; SrcDyn dyn; };
@@ -274,6 +276,7 @@ struct PendingMotion { uint32_t id; float pos[3]; float vel[3]; uint32_t disc; }
 struct PendingPlayB { uint32_t id; BufStatic st; BufDyn dyn; };
 struct PendingControl { uint32_t id; uint32_t index; float value; };
 
+constexpr uint32_t SCENE_FADER_CAP = 256;   // Fader sources per scene
 constexpr uint32_t STOPPED_CAP = 4096;   // ids returned inline with each callback; more => second fetch
 constexpr int RING = 2;
 
@@ -348,6 +351,11 @@ struct oddio_hip_scene {
     std::vector<uint32_t> cycle_free;      // rows of removed sources
     uint32_t cycle_live = 0;               // Cycle sources in the Seek set (audio thread)
     AdaptHost adapt;
+    // Fader sources in the buffered set (fader.rs): records + 1024-frame scratch, allocated by the control thread
+    FaderRec* d_faders = nullptr;
+    float* d_fader_scratch = nullptr;
+    uint32_t fader_count = 0;
+    std::vector<std::pair<uint32_t, FaderPending>> pending_fades;   // (1 + record index, command)
     MotionUpdate* d_motion = nullptr;
     SlotMove* d_moves = nullptr;
     // pinned staging
@@ -387,7 +395,8 @@ static int scene_free(oddio_hip_scene* s) {
     (void)hipFree(s->d_static); (void)hipFree(s->d_dyn); (void)hipFree(s->d_pend); (void)hipFree(s->d_ear);
     (void)hipFree(s->d_partials); (void)hipFree(s->d_out); (void)hipFree(s->d_stage1);
     (void)hipFree(s->d_bstatic); (void)hipFree(s->d_bdyn); (void)hipFree(s->d_bpend); (void)hipFree(s->d_contrib); (void)hipFree(s->d_bskip);
-    (void)hipFree(s->d_outb); (void)hipFree(s->d_bmoves); (void)hipFree(s->d_ctrl); (void)hipFree(s->d_cycle_rows); (void)hipFree(s->adapt.d_state);
+    (void)hipFree(s->d_outb); (void)hipFree(s->d_bmoves); (void)hipFree(s->d_ctrl); (void)hipFree(s->d_cycle_rows); (void)hipFree(s->adapt.d_state); (void)hipFree(s->d_faders); (void)hipFree(s->d_fader_scratch);
+    for (auto& h : s->handles) { for (auto* f : h.fade_frames) oddio_hip_frames_release(f); h.fade_frames.clear(); }
     for (auto& h : s->handles) if (h.ring) { (void)hipFree(h.ring); h.ring = nullptr; }
     for (float* r : s->ring_garbage) (void)hipFree(r); (void)hipFree(s->d_motion); (void)hipFree(s->d_moves);
     for (int r = 0; r < RING; ++r) {
@@ -757,7 +766,7 @@ extern "C" int oddio_hip_scene_reserve_buffered(oddio_hip_scene* s, uint32_t max
 static int scene_play_buffered_impl(oddio_hip_scene* s, int leaf_kind, oddio_hip_frames* frames, double start_seconds, float phase,
                                     float freq_hz_or_value, const oddio_hip_filter* filters, int n_filters,
                                     const float position[3], const float velocity[3], float radius, float max_distance,
-                                    uint32_t rate, float buffer_duration, uint32_t* source_id);
+                                    uint32_t rate, float buffer_duration, uint32_t* source_id, bool fader = false);
 
 extern "C" int oddio_hip_scene_play_buffered(oddio_hip_scene* s, int leaf_kind, oddio_hip_frames* frames, double start_seconds, float phase,
                                              float freq_hz_or_value, const oddio_hip_filter* filters, int n_filters,
@@ -780,15 +789,42 @@ extern "C" int oddio_hip_scene_play_buffered_stream(oddio_hip_scene* s, oddio_hi
     return rc;
 }
 
-static int scene_play_buffered_impl(oddio_hip_scene* s, int leaf_kind, oddio_hip_frames* frames, double start_seconds, float phase,
-                                    float freq_hz_or_value, const oddio_hip_filter* filters, int n_filters,
-                                    const float position[3], const float velocity[3], float radius, float max_distance,
-                                    uint32_t rate, float buffer_duration, uint32_t* source_id) {
-    if (!s || !position || !velocity) return fail(ODDIO_HIP_EINVAL, "NULL argument");
+// play_buffered(Fader::new(chain).1, ..) (fader.rs:16-28) and FaderControl::fade_to (:83-93) for a buffered source
+extern "C" int oddio_hip_scene_play_buffered_fader(oddio_hip_scene* s, int leaf_kind, oddio_hip_frames* frames, double start_seconds, float phase,
+                                                   float freq_hz_or_value, const oddio_hip_filter* filters, int n_filters,
+                                                   const float position[3], const float velocity[3], float radius, float max_distance,
+                                                   uint32_t rate, float buffer_duration, uint32_t* source_id) {
+    if (leaf_kind == (int)KIND_STREAM) return fail(ODDIO_HIP_EINVAL, "Fader<..Stream..> is not implemented");
+    return scene_play_buffered_impl(s, leaf_kind, frames, start_seconds, phase, freq_hz_or_value, filters, n_filters, position, velocity, radius,
+                                    max_distance, rate, buffer_duration, source_id, true);
+}
+
+static int scene_build_signal(oddio_hip_scene* s, int leaf_kind, oddio_hip_frames*& frames, double start_seconds, float phase,
+                              float freq_hz_or_value, const oddio_hip_filter* filters, int n_filters, BufStatic& st, BufDyn& d);
+
+extern "C" int oddio_hip_source_fade_to(oddio_hip_scene* s, uint32_t id, int leaf_kind, oddio_hip_frames* frames, double start_seconds, float phase,
+                                        float freq_hz_or_value, const oddio_hip_filter* filters, int n_filters, float duration) {
+    if (!s) return fail(ODDIO_HIP_EINVAL, "NULL scene");
+    if (leaf_kind == (int)KIND_STREAM) return fail(ODDIO_HIP_EINVAL, "fading to a Stream is not implemented");
+    if (!(duration > 0.0f)) return fail(ODDIO_HIP_EINVAL, "fade_to: duration must be > 0");
+    FaderPending cmd = {};
+    int rc = scene_build_signal(s, leaf_kind, frames, start_seconds, phase, freq_hz_or_value, filters, n_filters, cmd.st, cmd.dyn);
+    if (rc) return rc;
+    cmd.duration = duration;
+    cmd.fresh = 1u;
+    std::lock_guard<std::mutex> lk(s->mu);
+    if (id >= s->handles.size() || !s->handles[id].fader) return fail(ODDIO_HIP_ESTATE, "source %u is not a Fader", id);
+    if (frames) { oddio_hip_frames_retain(frames); s->handles[id].fade_frames.push_back(frames); }
+    s->pending_fades.emplace_back(s->handles[id].fader, cmd);
+    return 0;
+}
+
+// leaf + filters (innermost first) of a mono signal for the thread-per-source paths of a scene
+static int scene_build_signal(oddio_hip_scene* s, int leaf_kind, oddio_hip_frames*& frames, double start_seconds, float phase,
+                              float freq_hz_or_value, const oddio_hip_filter* filters, int n_filters, BufStatic& st, BufDyn& d) {
     if (n_filters < 0 || n_filters > MAX_WRAP || (n_filters && !filters)) return fail(ODDIO_HIP_EINVAL, "0..%d filters", MAX_WRAP);
-    if (rate == 0) return fail(ODDIO_HIP_EINVAL, "rate must be > 0");
-    BufStatic st = {};
-    BufDyn d = {};
+    st = BufStatic{};
+    d = BufDyn{};
     if (leaf_kind == (int)KIND_FRAMES) {
         if (!frames) return fail(ODDIO_HIP_EINVAL, "frames is NULL");
         if (frames->device != s->device) return fail(ODDIO_HIP_EINVAL, "frames live on another device");
@@ -826,6 +862,19 @@ static int scene_play_buffered_impl(oddio_hip_scene* s, int leaf_kind, oddio_hip
         default: return fail(ODDIO_HIP_EINVAL, "unknown filter kind %d", filters[w].kind);
         }
     }
+    return 0;
+}
+
+static int scene_play_buffered_impl(oddio_hip_scene* s, int leaf_kind, oddio_hip_frames* frames, double start_seconds, float phase,
+                                    float freq_hz_or_value, const oddio_hip_filter* filters, int n_filters,
+                                    const float position[3], const float velocity[3], float radius, float max_distance,
+                                    uint32_t rate, float buffer_duration, uint32_t* source_id, bool fader) {
+    if (!s || !position || !velocity) return fail(ODDIO_HIP_EINVAL, "NULL argument");
+    if (rate == 0) return fail(ODDIO_HIP_EINVAL, "rate must be > 0");
+    BufStatic st;
+    BufDyn d;
+    int brc = scene_build_signal(s, leaf_kind, frames, start_seconds, phase, freq_hz_or_value, filters, n_filters, st, d);
+    if (brc) return brc;
     // SpatialSignalBuffered::new (spatial.rs:31-56)
     const float max_delay = max_distance / ODDIO_SPEED_OF_SOUND + buffer_duration;
     const float cap_f = ceilf(max_delay * (float)rate);
@@ -853,10 +902,27 @@ static int scene_play_buffered_impl(oddio_hip_scene* s, int leaf_kind, oddio_hip
         e = hipMemset(st.ring, 0, (size_t)ring_len * sizeof(float));
         if (e != hipSuccess) { (void)hipFree(st.ring); return fail((int)e, "hipMemset(ring): %s", hipGetErrorString(e)); }
     }
+    uint32_t fader_tag = 0;
+    if (fader) {   // Fader::new(signal): record with progress 1.0 (fader.rs:21); control thread, never inside sample()
+        DeviceGuard g(s->device);
+        if (!s->d_faders) {
+            hipError_t e = hipMalloc(&s->d_faders, SCENE_FADER_CAP * sizeof(FaderRec));
+            if (e == hipSuccess) e = hipMalloc(&s->d_fader_scratch, (size_t)SCENE_FADER_CAP * FADER_BUF * sizeof(float));
+            if (e != hipSuccess) { (void)hipFree(s->d_faders); s->d_faders = nullptr; (void)hipFree(st.ring); return fail(ODDIO_HIP_ENOMEM, "hipMalloc(fader records): %s", hipGetErrorString(e)); }
+        }
+        if (s->fader_count >= SCENE_FADER_CAP) { (void)hipFree(st.ring); return fail(ODDIO_HIP_ENOMEM, "a scene holds at most %u Fader sources", SCENE_FADER_CAP); }
+        FaderRec rec = {};
+        rec.progress = 1.0f;
+        hipError_t e = hipMemcpy(s->d_faders + s->fader_count, &rec, sizeof(rec), hipMemcpyHostToDevice);   // not referenced by any slot yet
+        if (e != hipSuccess) { (void)hipFree(st.ring); return fail((int)e, "hipMemcpy(fader record): %s", hipGetErrorString(e)); }
+        fader_tag = ++s->fader_count;
+        st.fader = fader_tag;
+    }
     s->live_count_b++;
     const uint32_t id = alloc_id_locked(s);
     d.common.id = id;
     HandleRec& h = s->handles[id];
+    h.fader = fader_tag;
     h.queued = true; h.buffered = true; h.frames = frames; h.ring = st.ring;
     if (frames) oddio_hip_frames_retain(frames);
     s->pending_plays_b.push_back({id, st, d});
@@ -1067,6 +1133,19 @@ static int scene_sample_impl(oddio_hip_scene* s, float interval, float* host_out
             HIP_TRY(hipGetLastError());
         }
     }
+    {   // FaderControl::fade_to commands: swap.rs keeps only the latest flushed one per Fader
+        std::vector<std::pair<uint32_t, FaderPending>> fades;
+        { std::lock_guard<std::mutex> lk(s->mu); fades.swap(s->pending_fades); }
+        if (!fades.empty()) {
+            for (size_t i = 0; i < fades.size(); ++i) {
+                bool superseded = false;
+                for (size_t j = i + 1; j < fades.size(); ++j) superseded = superseded || fades[j].first == fades[i].first;
+                if (superseded) continue;
+                HIP_TRY(hipMemcpyAsync(&s->d_faders[fades[i].first - 1u].pend, &fades[i].second, sizeof(FaderPending), hipMemcpyHostToDevice, s->stream));
+            }
+            HIP_TRY(hipStreamSynchronize(s->stream));   // `fades` is pageable host memory
+        }
+    }
     if (!motions.empty()) {
         // swap.rs semantics: only the latest value per source survives until refresh()
         std::vector<MotionUpdate> ups, ups_b;
@@ -1132,7 +1211,7 @@ static int scene_sample_impl(oddio_hip_scene* s, float interval, float* host_out
     const float* init = nullptr;
     if (s->len_b > 0) {
         hipLaunchKernelGGL(buffered_sources, dim3((s->len_b + 63) / 64), dim3(64), 0, s->stream, P, s->len_b, s->d_bstatic, s->d_bdyn, s->d_bpend,
-                           s->d_contrib, s->d_bskip, s->d_stopped[r], STOPPED_CAP);
+                           s->d_contrib, s->d_bskip, s->d_stopped[r], STOPPED_CAP, s->d_faders, s->d_fader_scratch);
         HIP_TRY(hipGetLastError());
         if (n_frames > 0) {
             const uint32_t n_out = 2u * (uint32_t)n_frames;

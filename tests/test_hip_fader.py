@@ -83,3 +83,49 @@ def test_fader_errors():
         fc.fade_to(oa.MonoToStereo(oa.Constant(0.0)), 0.0)
     assert np.isfinite(mixer.sample_n(INTERVAL, 64)).all()
     mixer.close()
+
+
+def test_fader_as_buffered_spatial_source():
+    # play_buffered(Fader<FixedGain<FramesSignal>>) with fades while the source moves; a Gain-wrapped
+    # target, a Cycle target, a queued command that is replaced; plus a plain seekable neighbour
+    import oddio_amd as oa
+    control, scene = oa.SpatialScene(max_sources=16, max_frames=2048)
+    scene.set_mode(oa.MODE_ORDERED)
+    ref = oc.SpatialScene()
+    clips = [synth.noise_clip(90, i, 70000) for i in range(5)]
+
+    def chain(mod, i, rate=48000, start=0.0, db=None, cycle=False, gain=False):
+        data = clips[i][:700] if cycle else clips[i]
+        fr = mod.Frames.from_slice(rate, data) if mod is not oc else oc.Frames(rate, data)
+        s = mod.Cycle(fr) if cycle else mod.FramesSignal(fr, start)
+        if db is not None:
+            s = mod.FixedGain(s, db)
+        if gain:
+            s = mod.Gain.new(s)[1] if mod is not oc else oc.Gain(s)
+        return s
+
+    fc, f_h = oa.Fader.new(chain(oa, 0, db=-2.0))
+    f_o = oc.Fader(chain(oc, 0, db=-2.0))
+    pos, vel = np.float32([6.0, 1.0, -3.0]), np.float32([-9.0, 0.0, 2.0])
+    h_h = control.play_buffered(f_h, oa.SpatialOptions(pos, vel, 0.1), 120.0, 48000, 0.1)
+    h_o = ref.play_buffered(f_o, oc.SpatialOptions(pos, vel, 0.1), 120.0, 48000, 0.1)
+    control.play(chain(oa, 4), oa.SpatialOptions([2.0, 2.0, 2.0], [1.0, 0.0, 0.0]))
+    ref.play(chain(oc, 4), oc.SpatialOptions([2.0, 2.0, 2.0], [1.0, 0.0, 0.0]))
+    plan = {1: dict(i=1, rate=44100, dur=0.05),
+            2: dict(i=2, gain=True, dur=0.4),            # waits, then is replaced by ...
+            3: dict(i=3, cycle=True, db=3.0, dur=0.03),   # ... this one
+            8: dict(i=1, start=0.2, dur=0.08)}
+    for cb in range(13):
+        if cb in plan:
+            a = dict(plan[cb]); dur = a.pop("dur")
+            fc.fade_to(chain(oa, **a), dur)
+            f_o.fade_to(chain(oc, **a), dur)
+        if cb == 5:
+            p2, v2 = np.float32([-3.0, 2.0, 4.0]), np.float32([5.0, 1.0, -1.0])
+            h_h.set_motion(p2, v2, False); h_o.set_motion(p2, v2, False)
+        n = (1024, 1024, 2048, 300, 1024, 1024, 700, 1024, 1024, 2048, 1024, 1, 1024)[cb]
+        ra = ref.sample_n(INTERVAL, n)
+        rb = scene.sample_n(INTERVAL, n)
+        np.testing.assert_array_equal(rb, ra, err_msg=f"callback {cb}")
+        assert scene.len_buffered() == ref.len_buffered() == 1
+    scene.close()
