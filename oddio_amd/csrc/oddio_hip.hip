@@ -357,6 +357,11 @@ struct oddio_hip_scene {
     uint32_t fader_count = 0;
     std::vector<std::pair<uint32_t, FaderPending>> pending_fades;   // (1 + record index, command)
     MotionUpdate* d_motion = nullptr;
+    MotionUpdate* d_bmotion = nullptr;     // staging for buffered sources' motion updates (max_buffered entries)
+    MotionUpdate* h_motion = nullptr;      // pinned staging for set_motion batches (max_sources entries)
+    hipEvent_t ev_motion = nullptr;        // its last H2D copy
+    bool motion_copy_pending = false;
+    std::vector<PendingMotion> motion_scratch;   // reused capacity: no per-callback heap churn for large batches
     SlotMove* d_moves = nullptr;
     // pinned staging
     uint32_t* h_stopped[RING] = {nullptr, nullptr};
@@ -395,7 +400,7 @@ static int scene_free(oddio_hip_scene* s) {
     (void)hipFree(s->d_static); (void)hipFree(s->d_dyn); (void)hipFree(s->d_pend); (void)hipFree(s->d_ear);
     (void)hipFree(s->d_partials); (void)hipFree(s->d_out); (void)hipFree(s->d_stage1);
     (void)hipFree(s->d_bstatic); (void)hipFree(s->d_bdyn); (void)hipFree(s->d_bpend); (void)hipFree(s->d_contrib); (void)hipFree(s->d_bskip);
-    (void)hipFree(s->d_outb); (void)hipFree(s->d_bmoves); (void)hipFree(s->d_ctrl); (void)hipFree(s->d_cycle_rows); (void)hipFree(s->adapt.d_state); (void)hipFree(s->d_faders); (void)hipFree(s->d_fader_scratch);
+    (void)hipFree(s->d_outb); (void)hipFree(s->d_bmoves); (void)hipFree(s->d_bmotion); (void)hipFree(s->d_ctrl); (void)hipFree(s->d_cycle_rows); (void)hipFree(s->adapt.d_state); (void)hipFree(s->d_faders); (void)hipFree(s->d_fader_scratch);
     for (auto& h : s->handles) { for (auto* f : h.fade_frames) oddio_hip_frames_release(f); h.fade_frames.clear(); }
     for (auto& h : s->handles) if (h.ring) { (void)hipFree(h.ring); h.ring = nullptr; }
     for (float* r : s->ring_garbage) (void)hipFree(r); (void)hipFree(s->d_motion); (void)hipFree(s->d_moves);
@@ -405,6 +410,8 @@ static int scene_free(oddio_hip_scene* s) {
         if (s->ev_stopped[r]) (void)hipEventDestroy(s->ev_stopped[r]);
     }
     if (s->h_out) (void)hipHostFree(s->h_out);
+    if (s->h_motion) (void)hipHostFree(s->h_motion);
+    if (s->ev_motion) (void)hipEventDestroy(s->ev_motion);
     for (auto& e : s->ev_prof) if (e) (void)hipEventDestroy(e);
     if (s->stream && s->owns_stream) (void)hipStreamDestroy(s->stream);
     delete s;
@@ -444,6 +451,8 @@ extern "C" int oddio_hip_scene_create(int device, uint32_t max_sources, uint32_t
     SC_TRY(hipMalloc(&s->d_out, (size_t)s->tiles_max * 2 * TILE_FRAMES * sizeof(float)));
     SC_TRY(hipMalloc(&s->d_stage1, (size_t)RED_SPLIT * s->tiles_max * 2 * TILE_FRAMES * sizeof(float)));
     SC_TRY(hipMalloc(&s->d_motion, cap * sizeof(MotionUpdate)));
+    SC_TRY(hipHostMalloc(&s->h_motion, cap * sizeof(MotionUpdate), hipHostMallocDefault));
+    SC_TRY(hipEventCreateWithFlags(&s->ev_motion, hipEventDisableTiming));
     SC_TRY(hipMalloc(&s->d_moves, cap * sizeof(SlotMove)));
     SC_TRY(hipHostMalloc(&s->h_out, (size_t)2 * max_frames * sizeof(float), hipHostMallocDefault));
     for (int r = 0; r < RING; ++r) {
@@ -748,6 +757,7 @@ static int ensure_buffered_locked(oddio_hip_scene* s, uint32_t want) {
     BF_TRY(hipMalloc(&s->d_bskip, cap * sizeof(uint32_t)));
     BF_TRY(hipMalloc(&s->d_outb, n_out * sizeof(float)));
     BF_TRY(hipMalloc(&s->d_bmoves, cap * sizeof(BufMove)));
+    BF_TRY(hipMalloc(&s->d_bmotion, cap * sizeof(MotionUpdate)));
     BF_TRY(hipMalloc(&s->d_ctrl, 4096 * sizeof(ControlUpdate)));
     BF_TRY(hipMemset(s->d_bpend, 0, cap * sizeof(SrcPending)));
 #undef BF_TRY
@@ -1056,7 +1066,8 @@ static int scene_sample_impl(oddio_hip_scene* s, float interval, float* host_out
     std::vector<PendingPlay> plays;
     std::vector<PendingPlayB> plays_b;
     std::vector<PendingControl> controls;
-    std::vector<PendingMotion> motions;
+    std::vector<PendingMotion>& motions = s->motion_scratch;
+    motions.clear();
     bool rot_fresh;
     float rot_new[4];
     {
@@ -1147,8 +1158,12 @@ static int scene_sample_impl(oddio_hip_scene* s, float interval, float* host_out
         }
     }
     if (!motions.empty()) {
-        // swap.rs semantics: only the latest value per source survives until refresh()
-        std::vector<MotionUpdate> ups, ups_b;
+        // swap.rs semantics: only the latest value per source survives until refresh().  Seekable
+        // sources' updates are written straight into the pinned staging buffer (front), buffered
+        // ones behind them (back), and go to the device with asynchronous copies.
+        if (s->motion_copy_pending) { HIP_TRY(hipEventSynchronize(s->ev_motion)); s->motion_copy_pending = false; }
+        size_t n_seek = 0;
+        std::vector<MotionUpdate> ups_b;                     // buffered sources: few, keep the simple path
         {
             std::lock_guard<std::mutex> lk(s->mu);
             s->motion_epoch++;
@@ -1157,28 +1172,29 @@ static int scene_sample_impl(oddio_hip_scene* s, float interval, float* host_out
                 if (h.motion_epoch == s->motion_epoch) continue;
                 h.motion_epoch = s->motion_epoch;
                 if (!h.in_set) continue;
-                MotionUpdate u;
+                MotionUpdate tmp;
+                MotionUpdate& u = h.buffered ? tmp : s->h_motion[n_seek++];   // distinct seekable handles <= max_sources
                 u.slot = h.slot;
                 for (int c = 0; c < 3; ++c) { u.pos[c] = motions[i].pos[c]; u.vel[c] = motions[i].vel[c]; }
                 u.discontinuity = motions[i].disc;
-                (h.buffered ? ups_b : ups).push_back(u);
+                if (h.buffered) ups_b.push_back(tmp);
             }
         }
         if (!ups_b.empty()) {
-            // d_motion is sized for max_sources >= max_buffered; reuse it before the seekable batch
-            HIP_TRY(hipMemcpyAsync(s->d_motion, ups_b.data(), ups_b.size() * sizeof(MotionUpdate), hipMemcpyHostToDevice, s->stream));
-            HIP_TRY(hipStreamSynchronize(s->stream));
             const uint32_t n = (uint32_t)ups_b.size();
-            hipLaunchKernelGGL(apply_motion_updates, dim3((n + 255) / 256), dim3(256), 0, s->stream, s->d_motion, n, s->d_bpend);
+            HIP_TRY(hipMemcpyAsync(s->d_bmotion, ups_b.data(), ups_b.size() * sizeof(MotionUpdate), hipMemcpyHostToDevice, s->stream));
+            HIP_TRY(hipStreamSynchronize(s->stream));        // pageable source
+            hipLaunchKernelGGL(apply_motion_updates, dim3((n + 255) / 256), dim3(256), 0, s->stream, s->d_bmotion, n, s->d_bpend);
             HIP_TRY(hipGetLastError());
         }
-        if (!ups.empty()) {
+        if (n_seek) {
             motion_applied = true;
-            HIP_TRY(hipMemcpyAsync(s->d_motion, ups.data(), ups.size() * sizeof(MotionUpdate), hipMemcpyHostToDevice, s->stream));
-            HIP_TRY(hipStreamSynchronize(s->stream));
-            const uint32_t n = (uint32_t)ups.size();
+            const uint32_t n = (uint32_t)n_seek;
+            HIP_TRY(hipMemcpyAsync(s->d_motion, s->h_motion, n_seek * sizeof(MotionUpdate), hipMemcpyHostToDevice, s->stream));
             hipLaunchKernelGGL(apply_motion_updates, dim3((n + 255) / 256), dim3(256), 0, s->stream, s->d_motion, n, s->d_pend);
             HIP_TRY(hipGetLastError());
+            HIP_TRY(hipEventRecord(s->ev_motion, s->stream));
+            s->motion_copy_pending = true;
         }
     }
 
