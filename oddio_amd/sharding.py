@@ -42,16 +42,6 @@ def reduce_stereo(partial, dist=None, group=None, dst: int | None = 0):
     return partial
 
 
-def apply_postfx_numpy(x: np.ndarray, postfx: int) -> np.ndarray:
-    """Host-side Reinhard (exact IEEE ops, src/reinhard.rs:32) for CPU-side checks of a reduced buffer."""
-    if postfx == 1:
-        x = x.astype(np.float32)
-        return (x / (np.float32(1.0) + np.abs(x))).astype(np.float32)
-    if postfx == 0:
-        return x
-    raise ValueError("only Reinhard has an exact host form here")
-
-
 class ShardedSpatialScene:
     """One logical SpatialScene whose sources are split into contiguous index shards, one per rank.
 

@@ -15,6 +15,16 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+
+def apply_postfx_numpy(x, postfx):
+    """Host-side Reinhard (exact IEEE ops, src/reinhard.rs:32) for the CPU-side check of a reduced buffer."""
+    if postfx == 1:
+        x = x.astype(np.float32)
+        return (x / (np.float32(1.0) + np.abs(x))).astype(np.float32)
+    assert postfx == 0
+    return x
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -43,7 +53,7 @@ def _worker(rank, world, port, seed, n_src, n_frames, n_cb, postfx, q):
     for cb in range(n_cb):
         part = torch.from_numpy(ob.sample(interval, n_frames).copy())
         sharding.reduce_stereo(part, dist, dst=None)        # all_reduce: every rank gets the mix
-        outs.append(sharding.apply_postfx_numpy(part.numpy(), postfx))
+        outs.append(apply_postfx_numpy(part.numpy(), postfx))
     q.put((rank, lo, hi, np.stack(outs)))
     dist.barrier()
     dist.destroy_process_group()
@@ -75,7 +85,7 @@ def test_sharded_scene_reduce_gloo(world, n_src, postfx):
     spec = scenario.random_spec(seed, n_src, clip_len=9000, cube=10.0, start=0.06)
     ob = scenario.play_all(scenario.OracleBackend(), spec)
     interval = np.float32(1.0) / np.float32(48000)
-    ref = np.stack([sharding.apply_postfx_numpy(ob.sample(interval, n_frames).copy(), postfx) for _ in range(n_cb)])
+    ref = np.stack([apply_postfx_numpy(ob.sample(interval, n_frames).copy(), postfx) for _ in range(n_cb)])
     for rank, lo, hi, got in results:
         assert np.abs(got - ref).max() <= 1e-5 * np.abs(ref).max()
     np.testing.assert_array_equal(results[0][3], results[1][3])   # all_reduce: identical on every rank
