@@ -55,15 +55,8 @@ def build_gpu_scene(device: int, n_sources: int, clip_len: int, seed: int, start
     dev = torch.device("cuda", device)
     n_clips = n_sources if n_clips <= 0 else min(n_clips, n_sources)   # < n_sources: clips are shared, scattered
     clips = torch.empty((n_clips, clip_len), dtype=torch.float32, device=dev)
-    freq = torch.from_numpy(sc["freq_hz"][:n_clips]).to(dev).double()
-    n = torch.arange(clip_len, device=dev, dtype=torch.float64)
-    chunk = max(1, (1 << 28) // clip_len)
-    for s0 in range(0, n_clips, chunk):
-        s1 = min(n_clips, s0 + chunk)
-        ph = (2.0 * np.pi / RATE) * freq[s0:s1, None] * n[None, :]
-        clips[s0:s1] = torch.sin(ph).float()
-        del ph
-    torch.cuda.synchronize(dev)
+    # Host-side set-up first (handles, the set insertion), the GPU-side clip synthesis last: the timed
+    # callbacks then follow seconds of GPU load instead of seconds of idling (clock ramp).
     control, scene = oa.SpatialScene(device=device, max_sources=n_sources, max_frames=N_FRAMES)
     base = clips.data_ptr()
     frames = [oa.Frames.from_device_ptr(RATE, base + 4 * clip_len * i, clip_len, device=device, copy=False) for i in range(n_clips)]
@@ -74,6 +67,19 @@ def build_gpu_scene(device: int, n_sources: int, clip_len: int, seed: int, start
     handles = control.play_frames_batch(frames if n_clips == n_sources else [frames[int(k)] for k in pick],
                                         np.full(n_sources, start_seconds), sc["position"], sc["velocity"], sc["radius"])
     ids = np.array([h.id for h in handles], dtype=np.uint32)
+    # a zero-frame callback is `sample(interval, &mut [])`: set.update() inserts the sources, no time passes
+    prime = torch.zeros((1, 2), dtype=torch.float32, device=dev)
+    scene.sample_device(np.float32(1.0) / np.float32(RATE), prime.data_ptr(), 0)
+    scene.synchronize()
+    freq = torch.from_numpy(sc["freq_hz"][:n_clips]).to(dev).double()
+    n = torch.arange(clip_len, device=dev, dtype=torch.float64)
+    chunk = max(1, (1 << 28) // clip_len)
+    for s0 in range(0, n_clips, chunk):
+        s1 = min(n_clips, s0 + chunk)
+        ph = (2.0 * np.pi / RATE) * freq[s0:s1, None] * n[None, :]
+        clips[s0:s1] = torch.sin(ph).float()
+        del ph
+    torch.cuda.synchronize(dev)
     return {"control": control, "scene": scene, "clips": clips, "frames": frames, "handles": handles, "ids": ids, "spec": sc}
 
 
