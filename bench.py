@@ -1,29 +1,37 @@
 #!/usr/bin/env python
 """bench.py -- mixed source-frames/sec of the SpatialScene hot path on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W          (N > 1 spawns its own N ranks)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 A "step" is one SpatialScene callback: every source of the scene resampled (Doppler + propagation
 delay), gain-ramped, panned and summed into one 1024-frame 48 kHz stereo buffer that stays in HBM.
 Workload at N=1 = BASELINE.json configs[2] (the configuration the metric's roofline target is
 quoted on): one SpatialScene with 262 144 moving FramesSignal sources, each with its own
-65 536-sample clip (64 GiB of clips, generated on the GPU).  At N>1 every rank renders its own
-independent scene of the same size (BASELINE configs[3] pattern: scene-parallel, no data-path
-collective) => weak scaling; `value` is the whole-job aggregate.
+65 536-sample clip (64 GiB of clips, generated on the GPU).
+N>1, default (`--mode scenes`): every rank renders its own independent scene of the SAME size
+(BASELINE configs[3] pattern: scene-parallel, no data-path collective; per-GPU work is fixed across
+N, so the driver's scaling efficiency compares like with like; `--sources 65536` gives configs[3]'s
+literal 8 x 65 536).  `--mode sharded`: ONE seeded scene of N * sources split into contiguous index
+shards (BASELINE configs[4]); the partial stereo buffers are summed by the library's RCCL
+all-reduce on the kernels' stream.  `value` is the whole-job aggregate in both modes.
 
 Prints ONE JSON line (rank 0).  Extra objects:
   roofline     achieved = algorithmic bytes per mix launch / average mix-kernel duration measured
-               with hipEvents on the scene's stream over the timed region
-  cpu_baseline the C restatement of the reference algorithm (oracle/, kind "port"), single thread
-               (the reference's execution model), on a bounded slice of the same workload
+               with hipEvents on the scene's stream over the timed region; frac_callback = the same
+               bytes / the whole callback's wall time (prepass, reduce and launch gaps included)
+  cpu_baseline the C restatement of the reference algorithm (oracle/, kind "port") on this box's
+               host cores: one thread (the reference's execution model) and all cores
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
+import threading
 import time
 
 import numpy as np
@@ -34,7 +42,7 @@ if ROOT not in sys.path:
 
 RATE = 48000
 N_FRAMES = 1024
-HBM_PEAK_GBPS = 8000.0   # MI355X spec (MI355X_MICROARCH.md); ~6300 is what a float4 copy reaches
+HBM_PEAK_GBPS = 8000.0   # MI355X spec (MI355X_MICROARCH.md); a float4 copy reaches ~6300-6650
 PARAM_BYTES = 128        # per-source parameter/state budget P of SURVEY.md section 8(d)
 
 
@@ -43,21 +51,26 @@ def algorithmic_bytes(n_sources: int, n_frames: int) -> float:
     return n_sources * (4.0 * (n_frames + 32) + PARAM_BYTES) + 8.0 * n_frames
 
 
-def build_gpu_scene(device: int, n_sources: int, clip_len: int, seed: int, start_seconds: float, n_clips: int = 0):
+def build_gpu_scene(device: int, n_sources: int, clip_len: int, seed: int, start_seconds: float, n_clips: int = 0,
+                    first_index: int = 0, scene_factory=None):
     """Clips are synthesised on the GPU (A*sin(2*pi*f*n/48000), f from the shared generator) and
-    borrowed zero-copy as oddio Frames; scene parameters come from oddio_amd.synth."""
+    borrowed zero-copy as oddio Frames; scene parameters come from oddio_amd.synth (`first_index`:
+    this rank's offset into the one seeded source list of a sharded scene)."""
     import torch
 
     import oddio_amd as oa
     from oddio_amd import synth
 
-    sc = synth.make_scene(seed, n_sources)
+    sc = synth.make_scene(seed, n_sources, first_index=first_index)
     dev = torch.device("cuda", device)
     n_clips = n_sources if n_clips <= 0 else min(n_clips, n_sources)   # < n_sources: clips are shared, scattered
     clips = torch.empty((n_clips, clip_len), dtype=torch.float32, device=dev)
     # Host-side set-up first (handles, the set insertion), the GPU-side clip synthesis last: the timed
-    # callbacks then follow seconds of GPU load instead of seconds of idling (clock ramp, DESIGN.md section 5).
-    control, scene = oa.SpatialScene(device=device, max_sources=n_sources, max_frames=N_FRAMES)
+    # callbacks then follow seconds of GPU load instead of seconds of idling (DESIGN.md section 5).
+    if scene_factory is None:
+        control, scene = oa.SpatialScene(device=device, max_sources=n_sources, max_frames=N_FRAMES)
+    else:
+        control, scene = scene_factory()
     base = clips.data_ptr()
     frames = [oa.Frames.from_device_ptr(RATE, base + 4 * clip_len * i, clip_len, device=device, copy=False) for i in range(n_clips)]
     if n_clips < n_sources:
@@ -83,37 +96,146 @@ def build_gpu_scene(device: int, n_sources: int, clip_len: int, seed: int, start
     return {"control": control, "scene": scene, "clips": clips, "frames": frames, "handles": handles, "ids": ids, "spec": sc}
 
 
-def cpu_baseline(seed: int, budget_s: float = 12.0) -> dict:
-    """Single-thread C oracle on a 4096-source slice of the same workload (same generator)."""
-    from oddio_amd import synth
-    from oracle import oracle_c as oc
+# ---------------------------------------------------------------------------------------------------
+# CPU baseline: the C restatement (oracle/oddio_oracle.c) on the host cores of this box
+# ---------------------------------------------------------------------------------------------------
+def _cpu_model() -> str:
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
 
-    n_src, clip_len, start = 4096, 40960, 0.6
-    sc = synth.make_scene(seed, n_src)
-    frames = [oc.Frames(RATE, synth.sine_clip(sc["freq_hz"][i], clip_len, RATE)) for i in range(n_src)]
-    cb_per_round = (clip_len - int(start * RATE)) // N_FRAMES - 1
+
+def _oracle_scene(oc, clips, first, n_src, seed, start):
+    """An oracle SpatialScene of sources [first, first + n_src) of the bench generator; source i plays
+    clip i % len(clips) (borrowed)."""
+    from oddio_amd import synth
+    sc = synth.make_scene(seed, n_src, first_index=first)
+    idx = (np.arange(first, first + n_src) % clips.shape[0]).astype(np.uint32)
+    scene = oc.SpatialScene()
+    scene.play_frames_bulk(RATE, clips, start, sc["position"], sc["velocity"], sc["radius"], clip_of=idx)
+    return scene
+
+
+def _time_scene(oc, make_scene, cb_per_round, budget_s):
     out = np.zeros((N_FRAMES, 2), dtype=np.float32)
     total_cb, t_total = 0, 0.0
     while t_total < budget_s:
-        scene = oc.SpatialScene()
-        for i in range(n_src):
-            scene.play(oc.FramesSignal(frames[i], start), oc.SpatialOptions(sc["position"][i], sc["velocity"][i], sc["radius"][i]))
+        scene = make_scene()
         oc.run(scene, RATE, out)   # first callback also drains the insert queue: untimed
         t0 = time.perf_counter()
         for _ in range(cb_per_round):
             oc.run(scene, RATE, out)
         t_total += time.perf_counter() - t0
         total_cb += cb_per_round
-        assert len(scene) == n_src
         del scene
-    sfps = n_src * N_FRAMES * total_cb / t_total
+    return total_cb, t_total
+
+
+def cpu_baseline(seed: int, budget_s: float = 20.0) -> dict:
+    """single thread (the reference's execution model: one audio thread) on configs 1, 2
+    and a 16 384-source slice of config 3, then ALL host cores by scene sharding (T independent partial
+    scenes, partial buffers summed at the end -- what a user of the reference would have to do)."""
+    from oddio_amd import synth
+    from oracle import oracle_c as oc
+
+    clip_len, start, n_bank = 40960, 0.6, 4096
+    cb_per_round = (clip_len - int(start * RATE)) // N_FRAMES - 1
+    sc = synth.make_scene(seed, n_bank)
+    n = np.arange(clip_len, dtype=np.float64)
+    bank = np.empty((n_bank, clip_len), dtype=np.float32)
+    for s0 in range(0, n_bank, 256):
+        bank[s0:s0 + 256] = np.sin((2.0 * np.pi / RATE) * sc["freq_hz"][s0:s0 + 256, None].astype(np.float64) * n[None, :]).astype(np.float32)
+    legs = {}
+    share = budget_s / 4.0
+
+    # config 1: Mixer of 64 MonoToStereo<Sine> (examples/simple.rs style), plumbing
+    def mixer64():
+        m = oc.Mixer(channels=2)
+        for k in range(64):
+            m.play(oc.MonoToStereo(oc.Sine(float(sc["phase"][k]), 110.0 * 2.0 ** (k / 12.0))))
+        return m
+    out = np.zeros((N_FRAMES, 2), dtype=np.float32)
+    m = mixer64()
+    oc.run(m, RATE, out)
+    t0, cbs = time.perf_counter(), 0
+    while time.perf_counter() - t0 < min(share, 2.0):
+        oc.run(m, RATE, out)
+        cbs += 1
+    legs["config1_mixer_64_sines_1_thread"] = 64 * N_FRAMES * cbs / (time.perf_counter() - t0)
+
+    # config 2 shape, one thread (own clip per source)
+    cb, t = _time_scene(oc, lambda: _oracle_scene(oc, bank, 0, 4096, seed, start), cb_per_round, share)
+    single = 4096 * N_FRAMES * cb / t
+    legs["config2_4096_sources_1_thread"] = single
+    # 16 384-source slice of config 3, one thread (clips shared 4 ways: flatters the CPU's caches, never the GPU)
+    cb, t = _time_scene(oc, lambda: _oracle_scene(oc, bank, 0, 16384, seed, start), cb_per_round, share)
+    legs["config3_slice_16384_sources_1_thread"] = 16384 * N_FRAMES * cb / t
+
+    # all cores: T threads, each with its own partial scene of 1024 sources (ctypes releases the GIL)
+    T = os.cpu_count() or 1
+    per = 1024
+    scenes = [_oracle_scene(oc, bank, t_ * per, per, seed, start) for t_ in range(T)]
+    outs = [np.zeros((N_FRAMES, 2), dtype=np.float32) for _ in range(T)]
+    for sc_, o in zip(scenes, outs):
+        oc.run(sc_, RATE, o)                                   # insert queue drained, untimed
+    n_cb = max(2, min(cb_per_round, int(share / (per * 5.5e-6)) or 2))
+    barrier = threading.Barrier(T + 1)
+
+    def work(i):
+        barrier.wait()
+        for _ in range(n_cb):
+            oc.run(scenes[i], RATE, outs[i])
+        barrier.wait()
+    threads = [threading.Thread(target=work, args=(i,)) for i in range(T)]
+    for th in threads:
+        th.start()
+    barrier.wait()
+    t0 = time.perf_counter()
+    barrier.wait()
+    mix = np.sum(np.stack(outs), axis=0, dtype=np.float32)     # the partial buffers of the last callback, summed
+    t_all = time.perf_counter() - t0
+    for th in threads:
+        th.join()
+    assert np.isfinite(mix).all()
+    all_cores = T * per * N_FRAMES * n_cb / t_all
+    legs[f"all_cores_{T}_threads_x_{per}_sources"] = all_cores
     return {
-        "value": sfps, "unit": "source-frames/s", "cores": 1, "kind": "port",
-        "sample": f"{n_src}-source slice of the workload (same generator), {total_cb} callbacks of {N_FRAMES} frames, "
-                  f"C restatement of the reference (oracle/oddio_oracle.c, -O2 -ffp-contract=off), single thread = the reference's one audio thread",
+        "value": single, "unit": "source-frames/s", "cores": 1, "kind": "port",
+        "sample": f"4096-source slice of the workload (same generator), {cb_per_round}-callback rounds of {N_FRAMES} frames, "
+                  f"C restatement of the reference (oracle/oddio_oracle.c, -O2 -ffp-contract=off, not rustc output), "
+                  f"single thread = the reference's one audio thread",
+        "all_cores": {"value": all_cores, "cores": T, "sample": f"{T} threads x {per}-source partial scenes, {n_cb} callbacks, partial buffers summed"},
+        "legs": legs,
+        "cpu_model": _cpu_model(),
         "host_cores_available": os.cpu_count(),
-        "max_realtime_sources_per_core": sfps / RATE,
+        "max_realtime_sources_per_core": single / RATE,
+        "max_realtime_sources_all_cores": all_cores / RATE,
     }
+
+
+# ---------------------------------------------------------------------------------------------------
+def _free_port() -> int:
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def self_launch(n: int) -> int:
+    """`python bench.py --gpus N` without a launcher: spawn the N ranks ourselves (one per GPU)."""
+    port = _free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rcs = [p.wait() for p in procs]
+    return max(abs(rc) for rc in rcs)
 
 
 def main():
@@ -132,35 +254,58 @@ def main():
     ap.add_argument("--seed", type=int, default=2024)
     ap.add_argument("--mode", choices=["scenes", "sharded"], default="scenes",
                     help="N>1: 'scenes' = one independent scene per GPU (configs[3] pattern, no collective); "
-                         "'sharded' = ONE scene of N*sources split into contiguous index shards with an RCCL sum-reduce "
+                         "'sharded' = ONE scene of N*sources split into contiguous index shards with an RCCL all-reduce "
                          "of the 8 KiB stereo buffer per callback (configs[4] pattern)")
+    ap.add_argument("--share-devices", action="store_true", help="smoke-testing on a box with fewer GPUs than ranks: rank r uses device r %% count")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-budget", type=float, default=12.0)
+    ap.add_argument("--cpu-budget", type=float, default=20.0)
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args.gpus))
 
     import torch
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus > 1 and world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with --nproc-per-node {args.gpus} (WORLD_SIZE={world})")
+    if args.gpus != world:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (torch.cuda.is_available() is False); there is no CPU fallback")
-    device = local_rank if world > 1 else 0
+    n_dev = torch.cuda.device_count()
+    if world > n_dev and not args.share_devices:
+        raise SystemExit(f"--gpus {world} but only {n_dev} device(s) visible (use --share-devices for a smoke run)")
+    device = local_rank % n_dev
     torch.cuda.set_device(device)
     dist = None
     if world > 1:
+        # the process group only carries the timing barrier / max and the reduce group's id: CPU tensors
+        # over gloo.  The data path's one collective (sharded mode) is the library's own RCCL all-reduce.
         import torch.distributed as dist_mod
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist_mod.init_process_group(backend="nccl", device_id=torch.device("cuda", device))
+        os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
+        dist_mod.init_process_group(backend="gloo", rank=rank, world_size=world)
         dist = dist_mod
 
     S, L = args.sources, args.clip_len
+    sharded = args.mode == "sharded" and world > 1
     # clips start 1.0 s in: the propagation delay (<= 0.25 s at set-up) may grow by the drift of the
     # constant-velocity sources (<= 34.6 m/s) for `reset_every` callbacks without reading before the clip
     start_seconds = 1.0
-    g = build_gpu_scene(device, S, L, args.seed + rank, start_seconds, args.clips)
+    if sharded:
+        # ONE seeded scene of world * S sources; this rank owns the contiguous index shard [lo, hi)
+        from oddio_amd import sharding
+        uid = sharding.exchange_unique_id(dist)
+        lo, hi = sharding.shard_range(world * S, world, rank)
+        holder = {}
+
+        def factory():
+            holder["sh"] = sharding.ShardedSpatialScene(device, world * S, N_FRAMES, rank, world, uid)
+            return holder["sh"].control, holder["sh"].scene
+        g = build_gpu_scene(device, hi - lo, L, args.seed, start_seconds, args.clips, first_index=lo, scene_factory=factory)
+    else:
+        g = build_gpu_scene(device, S, L, args.seed + rank, start_seconds, args.clips)
     scene, control = g["scene"], g["control"]
     out = torch.zeros((N_FRAMES, 2), dtype=torch.float32, device=torch.device("cuda", device))
     interval = np.float32(1.0) / np.float32(RATE)
@@ -171,63 +316,79 @@ def main():
 
     step_no = 0
 
-    sharded = args.mode == "sharded" and dist is not None
-    if sharded:
-        # one logical scene: this rank's scene IS its contiguous shard (seed + rank streams); the
-        # partial stereo buffers are summed over RCCL on the same stream as the kernels
-        from oddio_amd import sharding
-        scene.set_stream(torch.cuda.current_stream(device).cuda_stream)
-
     def one_step():
         nonlocal step_no
         if step_no and step_no % span == 0:
             scene.seek_all(rewind_seconds)              # Seek::seek on every source (a tiny kernel, timed)
         if step_no and step_no % reset_every == 0:
             control.set_motion_batch(g["ids"], g["spec"]["position"], g["spec"]["velocity"], True)
-        scene.sample_device(interval, out.data_ptr(), N_FRAMES)
-        if sharded:
-            sharding.reduce_stereo(out, dist, dst=0)    # 2048 floats, sum, to rank 0
+        scene.sample_device(interval, out.data_ptr(), N_FRAMES)   # sharded: includes the RCCL all-reduce
         step_no += 1
+
+    def sync_all():
+        scene.synchronize()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        scene.synchronize()
+        torch.cuda.synchronize()
 
     for _ in range(args.warmup):
         one_step()
     scene.set_profiling(True)
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
+    sync_all()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         one_step()
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
+    sync_all()
     elapsed = time.perf_counter() - t0
     hist = scene.kernel_ms_history(min(args.steps, 512))
-    assert len(scene) == S, "sources finished inside the timed region"
+    scene.set_profiling(False)
+    assert len(scene) == len(g["ids"]), "sources finished inside the timed region"
     assert bool(torch.isfinite(out).all()) and float(out.abs().max()) > 0.0
 
+    # the reference's boundary hands a host slice (oddio::run): same callbacks through oddio_hip_scene_sample
+    # (8 KiB D2H + a stream sync per callback), untimed by `value`, reported next to it
+    host_buf = np.zeros((N_FRAMES, 2), dtype=np.float32)
+    n_host = min(20, max(1, span - (step_no % span) - 1))
+    scene.synchronize()
+    th0 = time.perf_counter()
+    for _ in range(n_host):
+        scene.sample(interval, host_buf)
+        step_no += 1
+    host_ms = (time.perf_counter() - th0) / n_host * 1e3
+
+    ranks_seen = 1
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=torch.device("cuda", device))
+        t = torch.tensor([elapsed], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+        ranks_seen = dist.get_world_size()
 
     if rank == 0:
         total_units = float(S) * N_FRAMES * args.steps * world
         value = total_units / elapsed
+        ms_per_step = elapsed / args.steps * 1e3
         mix_ms = float(hist[:, 1].mean())
-        b_alg = algorithmic_bytes(S, N_FRAMES)
+        b_alg = algorithmic_bytes(len(g["ids"]), N_FRAMES)
         achieved = b_alg / (mix_ms * 1e-3) / 1e9
-        traffic = None
+        traffic, traffic_source = None, None
         pmc = os.path.join(ROOT, "profiles", "pmc_latest.json")
         if os.path.exists(pmc):
             try:
                 j = json.load(open(pmc))
                 if j.get("sources") == S and j.get("kernel", "").startswith("spatial_mix"):
                     traffic = j.get("hbm_bytes_per_launch")
+                    traffic_source = "profiles/pmc_latest.json (rocprofv3 --pmc passes of this kernel, not measured in this run)"
             except Exception:
                 traffic = None
+        if world == 1:
+            shape = (f"BASELINE configs[2]: SpatialScene, {S} moving FramesSignal sources (own {L}-sample clip each), " if args.clips <= 0 or args.clips >= S
+                     else f"real-time confirmation run: SpatialScene, {S} moving FramesSignal sources sharing {args.clips} clips of {L} samples, ")
+        elif sharded:
+            shape = f"BASELINE configs[4] pattern: ONE SpatialScene of {world * S} moving FramesSignal sources in {world} contiguous index shards + RCCL all-reduce of the stereo buffer, "
+        else:
+            shape = f"BASELINE configs[3] pattern: {world} independent SpatialScenes, one per GPU, {S} moving FramesSignal sources each (per-GPU work as at N=1), "
         line = {
             "metric": "mixed source-frames/sec (48 kHz stereo)",
             "value": value,
@@ -235,34 +396,34 @@ def main():
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3,
+            "ms_per_step": ms_per_step,
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
             "config": {
-                "workload": ((f"BASELINE configs[2]: SpatialScene, {S} moving FramesSignal sources (own {L}-sample clip each), " if args.clips <= 0 or args.clips >= S
-                              else f"real-time confirmation run: SpatialScene, {S} moving FramesSignal sources sharing {args.clips} clips of {L} samples, ")
-                             +
-                             f"Doppler + propagation delay, 48 kHz stereo, {N_FRAMES}-frame callbacks"
-                             + ("" if world == 1 else (f"; ONE scene of {world * S} sources in {world} index shards + RCCL reduce (configs[4] pattern)" if sharded
-                                                      else f"; {world} independent scenes, one per GPU (configs[3] pattern)"))),
+                "workload": shape + f"Doppler + propagation delay, 48 kHz stereo, {N_FRAMES}-frame callbacks",
                 "sources_per_gpu": S, "frames_per_callback": N_FRAMES, "sample_rate": RATE, "clip_len": L,
-                "parallelism": ("single-gpu" if world == 1 else ("source-sharded scene + RCCL stereo-buffer reduce" if sharded else "scene-parallel")),
+                "parallelism": ("single-gpu" if world == 1 else ("source-sharded scene + RCCL stereo-buffer all-reduce" if sharded else "scene-parallel")),
+                "ranks_seen": ranks_seen,
             },
             "max_realtime_sources": value / RATE,
             "realtime_factor_per_gpu": (N_FRAMES / RATE) / (elapsed / args.steps),
+            "host_output_ms_per_step": host_ms,
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
-                "traffic": traffic,
+                "traffic": traffic, "traffic_source": traffic_source,
                 "kernel": "spatial_mix", "avg_kernel_ms": mix_ms, "algorithmic_bytes_per_launch": b_alg,
-                "prepass_ms": float(hist[:, 0].mean()), "reduce_ms": float(hist[:, 2].mean()),
+                "frac_callback": b_alg / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                "prepass_ms": float(hist[:, 0].mean()),
+                ("reduce_incl_collective_ms" if sharded else "reduce_ms"): float(hist[:, 2].mean()),
             },
         }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args.seed, args.cpu_budget)
             line["cpu_baseline"]["gpu_over_cpu"] = value / line["cpu_baseline"]["value"]
+            line["cpu_baseline"]["gpu_over_cpu_all_cores"] = value / line["cpu_baseline"]["all_cores"]["value"]
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.barrier()

@@ -194,6 +194,21 @@ int oddio_hip_scene_sample_device(oddio_hip_scene* scene, float interval, float*
 /* Renders the post-mix filter only (Reinhard/Tanh) over a device buffer of 2*n_frames floats;
  * used after the cross-GPU sum of partial stereo buffers (sharded scenes). */
 int oddio_hip_postfx_device(int device, int postfx, float* dev_buf, size_t n_frames, void* hip_stream);
+/* ---- one logical scene sharded over the GPUs of a node (BASELINE configs[4]) ----
+ * The reference has no multi-device code; its per-frame sum over sources (src/spatial.rs:456-463) is
+ * what gets split: every rank owns a contiguous index shard of the sources in its own scene, and after
+ * oddio_hip_scene_reduce_init every *_sample* call of that scene sums the ranks' partial stereo
+ * buffers with ONE RCCL all-reduce (2*n_frames f32, sum) enqueued on the scene's stream between the
+ * shard's own reduction and the post-mix filter (Reinhard/Tanh/Adapt wrap the *scene*, so they run
+ * after the sum, on every rank).  All ranks must call *_sample* with the same n_frames.
+ *   rank 0:    oddio_hip_reduce_unique_id(id)   (ncclGetUniqueId) -> hand `id` to the other ranks
+ *   all ranks: oddio_hip_scene_reduce_init(scene, rank, world, id, ODDIO_HIP_UNIQUE_ID_BYTES)
+ * RCCL (librccl.so.1) is loaded on first use; a process that never shards does not need it. */
+#define ODDIO_HIP_UNIQUE_ID_BYTES 128
+int oddio_hip_reduce_unique_id(void* unique_id, size_t unique_id_bytes);
+int oddio_hip_scene_reduce_init(oddio_hip_scene* scene, int rank, int world, const void* unique_id,
+                                size_t unique_id_bytes);
+int oddio_hip_scene_reduce_destroy(oddio_hip_scene* scene);
 /* Block until everything enqueued on the scene's stream has finished. */
 int oddio_hip_scene_synchronize(oddio_hip_scene* scene);
 /* Make the scene enqueue on a caller-owned hipStream_t (e.g. the stream a framework's collectives

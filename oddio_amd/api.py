@@ -391,6 +391,15 @@ class _SceneSignal(Signal):
     def seek_all(self, seconds):
         _lib.check(_lib.lib().oddio_hip_scene_seek_all(self._h, np.float32(seconds)))
 
+    def reduce_init(self, rank: int, world: int, unique_id: bytes):
+        """Join the stereo-buffer all-reduce of a scene sharded over `world` GPUs: from now on every
+        sample call sums the ranks' partial buffers over RCCL before the post-mix filter."""
+        buf = C.create_string_buffer(bytes(unique_id), len(unique_id))
+        _lib.check(_lib.lib().oddio_hip_scene_reduce_init(self._h, int(rank), int(world), buf, len(unique_id)))
+
+    def reduce_destroy(self):
+        _lib.check(_lib.lib().oddio_hip_scene_reduce_destroy(self._h))
+
     def is_finished(self):
         return False  # spatial.rs:473-476
 
@@ -545,6 +554,17 @@ class SpatialSceneControl:
     def set_listener_rotation(self, rotation_sxyz):
         q = np.ascontiguousarray(np.asarray(rotation_sxyz, dtype=np.float32).reshape(4))
         _lib.check(_lib.lib().oddio_hip_scene_set_listener_rotation(self._scene._h, _fp(q)))
+
+
+UNIQUE_ID_BYTES = 128
+
+
+def reduce_unique_id() -> bytes:
+    """`ncclGetUniqueId` for a sharded scene's reduce group: rank 0 makes it, every rank passes it to
+    `scene.reduce_init` (hand it over with whatever the host program uses: a file, MPI, torch.distributed)."""
+    buf = C.create_string_buffer(UNIQUE_ID_BYTES)
+    _lib.check(_lib.lib().oddio_hip_reduce_unique_id(buf, UNIQUE_ID_BYTES))
+    return buf.raw
 
 
 def SpatialScene(device: int = 0, max_sources: int = 4096, max_frames: int = 4096):

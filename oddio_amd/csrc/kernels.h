@@ -391,22 +391,14 @@ __device__ __forceinline__ void window_load(u32x4 (&pre)[WIN_VECS], const float*
 #pragma unroll
     for (int k = 0; k < WIN_VECS; ++k) {
         // negative offsets wrap to huge unsigned values: out of range -> 0
-#if defined(ODDIO_EXP) && ODDIO_EXP == 3
-        pre[k] = u32x4{(unsigned)lane, 0u, 1u, 2u};             // EXPERIMENT: no window loads (wrong data)
-#else
         pre[k] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, neg4 + 16 * lane + 1024 * k, 0, 0);
-#endif
     }
 }
 // registers -> LDS.  Plain layout: one aligned 16-byte store per float4.
 __device__ __forceinline__ void window_store_plain(unsigned char* smem, const u32x4 (&pre)[WIN_VECS], int nvec, int lane) {
 #pragma unroll
     for (int k = 0; k < WIN_VECS; ++k) {
-#if defined(ODDIO_EXP) && (ODDIO_EXP == 4 || ODDIO_EXP == 6)
-        if (lane + 64 * k < nvec && pre[k].x == 0x12345u) *reinterpret_cast<u32x4*>(smem + LDS_WIN + 16 * lane + 1024 * k) = pre[k];   // EXPERIMENT: (almost) no LDS stores
-#else
         if (lane + 64 * k < nvec) *reinterpret_cast<u32x4*>(smem + LDS_WIN + 16 * lane + 1024 * k) = pre[k];
-#endif
     }
 }
 // Padded layout: slot(s) = s + s/16; the pad slot repeats the following sample, so that a pair
@@ -466,15 +458,8 @@ __device__ __forceinline__ void mix_source_lds(const unsigned char* smem, int la
             fr[k] = NONNEG ? __builtin_amdgcn_fractf(x) : x - (float)tr;  // frames.rs:192
             int w = wrel + tr;
             if (PAD) w = w + (w >> 4);
-#if defined(ODDIO_EXP) && ODDIO_EXP == 1
-            w = (w & 1) + 2 * (b + 16 * (la & 3)) + 128 * k;    // EXPERIMENT: conflict-free addresses (wrong data)
-#endif
-#if defined(ODDIO_EXP) && (ODDIO_EXP == 2 || ODDIO_EXP == 6)
-            a[k] = x; bb[k] = fr[k];                            // EXPERIMENT: no LDS reads (wrong data)
-#else
             a[k] = win[w];                                                // one ds_read2_b32
             bb[k] = win[w + 1];
-#endif
             x = x + ds;                                                   // frames.rs:194
         }
 #pragma unroll
@@ -644,9 +629,6 @@ __global__ __launch_bounds__(64 * MIX_WG_WAVES, MIX_WAVES_PER_SIMD) void spatial
         {
             float* ck = &ckpt[lane * 16];
             const int sw = lane & 15;
-#if defined(ODDIO_EXP) && ODDIO_EXP == 5
-            if (ds == 123.0f)   // EXPERIMENT: no cursor scan (wrong data)
-#endif
 #pragma unroll 1
             for (int b = 0; b < 15; ++b) {
                 ck[b ^ sw] = x;

@@ -4,6 +4,8 @@
 // hand-off for Motion / listener rotation (src/swap.rs:36-64), and SpatialScene::sample's
 // prologue (src/spatial.rs:376-394).
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
+#include <rccl/rccl.h>   // types only: the functions are resolved with dlopen on first use
 
 #include <algorithm>
 #include <atomic>
@@ -252,6 +254,35 @@ extern "C" int oddio_hip_device_count(int* count) {
     return 0;
 }
 
+// RCCL entry points of the sharded-scene reduce, resolved at first use (include/oddio_hip.h)
+namespace {
+struct RcclApi {
+    void* handle = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
+    bool ok() const { return GetUniqueId && CommInitRank && CommDestroy && AllReduce && GetErrorString; }
+};
+RcclApi* rccl_api() {
+    static RcclApi api;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        // a host process that already uses RCCL (e.g. through PyTorch) has librccl.so.1 mapped: share it
+        api.handle = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+        if (!api.handle) api.handle = dlopen("/opt/rocm/lib/librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+        if (!api.handle) return;
+        api.GetUniqueId = reinterpret_cast<decltype(api.GetUniqueId)>(dlsym(api.handle, "ncclGetUniqueId"));
+        api.CommInitRank = reinterpret_cast<decltype(api.CommInitRank)>(dlsym(api.handle, "ncclCommInitRank"));
+        api.CommDestroy = reinterpret_cast<decltype(api.CommDestroy)>(dlsym(api.handle, "ncclCommDestroy"));
+        api.AllReduce = reinterpret_cast<decltype(api.AllReduce)>(dlsym(api.handle, "ncclAllReduce"));
+        api.GetErrorString = reinterpret_cast<decltype(api.GetErrorString)>(dlsym(api.handle, "ncclGetErrorString"));
+    });
+    return &api;
+}
+}  // namespace
+
 // ---------------------------------------------------------------------------------------------
 // SpatialScene
 // ---------------------------------------------------------------------------------------------
@@ -386,6 +417,8 @@ struct oddio_hip_scene {
     uint32_t len = 0;                      // live slots
     std::vector<uint32_t> id_of_slot;
     int postfx = 0, mode = 0;
+    ncclComm_t comm = nullptr;             // sharded scene: RCCL communicator of the stereo-buffer reduce
+    int comm_world = 1;
     bool profiling = false;
     static constexpr int PROF_RING = 512;
     std::vector<hipEvent_t> ev_prof;       // PROF_RING x 4 events, created on first use
@@ -395,6 +428,7 @@ struct oddio_hip_scene {
 static int scene_free(oddio_hip_scene* s) {
     DeviceGuard g(s->device);
     if (s->stream) (void)hipStreamSynchronize(s->stream);
+    if (s->comm) { (void)rccl_api()->CommDestroy(s->comm); s->comm = nullptr; }
     for (auto& h : s->handles) if (h.frames) { oddio_hip_frames_release(h.frames); h.frames = nullptr; }
     for (auto& p : s->pending_plays) (void)p;
     (void)hipFree(s->d_static); (void)hipFree(s->d_dyn); (void)hipFree(s->d_pend); (void)hipFree(s->d_ear);
@@ -740,6 +774,49 @@ extern "C" int oddio_hip_scene_set_stream(oddio_hip_scene* s, void* stream) {
 extern "C" int oddio_hip_scene_stream(oddio_hip_scene* s, void** stream) {
     if (!s || !stream) return fail(ODDIO_HIP_EINVAL, "NULL argument");
     *stream = (void*)s->stream;
+    return 0;
+}
+
+// ---- sharded scene: stereo-buffer all-reduce over RCCL (include/oddio_hip.h) -------------------
+
+extern "C" int oddio_hip_reduce_unique_id(void* unique_id, size_t unique_id_bytes) {
+    if (!unique_id || unique_id_bytes < sizeof(ncclUniqueId)) return fail(ODDIO_HIP_EINVAL, "unique_id needs %zu bytes", sizeof(ncclUniqueId));
+    static_assert(sizeof(ncclUniqueId) == ODDIO_HIP_UNIQUE_ID_BYTES, "ODDIO_HIP_UNIQUE_ID_BYTES == sizeof(ncclUniqueId)");
+    RcclApi* R = rccl_api();
+    if (!R->ok()) return fail(ODDIO_HIP_ENODEV, "librccl.so.1 could not be loaded: %s", dlerror());
+    ncclUniqueId id;
+    const ncclResult_t r = R->GetUniqueId(&id);
+    if (r != ncclSuccess) return fail(ODDIO_HIP_ENODEV, "ncclGetUniqueId: %s", R->GetErrorString(r));
+    memcpy(unique_id, &id, sizeof(id));
+    return 0;
+}
+
+extern "C" int oddio_hip_scene_reduce_init(oddio_hip_scene* s, int rank, int world, const void* unique_id, size_t unique_id_bytes) {
+    if (!s || !unique_id || unique_id_bytes < sizeof(ncclUniqueId)) return fail(ODDIO_HIP_EINVAL, "bad argument");
+    if (world < 1 || rank < 0 || rank >= world) return fail(ODDIO_HIP_EINVAL, "rank %d of %d", rank, world);
+    if (s->comm) return fail(ODDIO_HIP_ESTATE, "the scene already belongs to a reduce group");
+    RcclApi* R = rccl_api();
+    if (!R->ok()) return fail(ODDIO_HIP_ENODEV, "librccl.so.1 could not be loaded: %s", dlerror());
+    DeviceGuard g(s->device);
+    if (!g.ok) return fail(ODDIO_HIP_ENODEV, "hipSetDevice(%d) failed", s->device);
+    ncclUniqueId id;
+    memcpy(&id, unique_id, sizeof(id));
+    ncclComm_t comm = nullptr;
+    const ncclResult_t r = R->CommInitRank(&comm, world, id, rank);
+    if (r != ncclSuccess) return fail(ODDIO_HIP_ENODEV, "ncclCommInitRank(rank %d of %d): %s", rank, world, R->GetErrorString(r));
+    s->comm = comm;
+    s->comm_world = world;
+    return 0;
+}
+
+extern "C" int oddio_hip_scene_reduce_destroy(oddio_hip_scene* s) {
+    if (!s) return fail(ODDIO_HIP_EINVAL, "NULL scene");
+    if (!s->comm) return 0;
+    DeviceGuard g(s->device);
+    (void)hipStreamSynchronize(s->stream);
+    (void)rccl_api()->CommDestroy(s->comm);
+    s->comm = nullptr;
+    s->comm_world = 1;
     return 0;
 }
 
@@ -1261,7 +1338,8 @@ static int scene_sample_impl(oddio_hip_scene* s, float interval, float* host_out
     bool stopped_published = false;
     if (n_frames > 0) {
         const uint32_t n_out = 2u * (uint32_t)n_frames;
-        const int fused_postfx = s->adapt.on ? 0 : s->postfx;   // with Adapt the filter order is Reinhard(Adapt(scene))
+        // with Adapt the filter order is Reinhard(Adapt(scene)); in a sharded scene the filters follow the cross-GPU sum
+        const int fused_postfx = (s->adapt.on || s->comm) ? 0 : s->postfx;
         if (n_wgs > 0) {
             hipLaunchKernelGGL(reduce_stage1, dim3(((uint32_t)n_frames + 31) / 32, RED_SPLIT), dim3(256), 0, s->stream, s->d_partials, s->d_stage1,
                                n_wgs, (uint32_t)n_frames);
@@ -1274,6 +1352,15 @@ static int scene_sample_impl(oddio_hip_scene* s, float interval, float* host_out
             hipLaunchKernelGGL(zero_kernel, dim3((n_out + 255) / 256), dim3(256), 0, s->stream, out_dev, n_out);   // spatial.rs:389-391
         }
         HIP_TRY(hipGetLastError());
+        if (s->comm) {
+            // the shard's partial buffer -> the scene's mix: one 8 KiB sum over xGMI, same stream, no host sync
+            const ncclResult_t nr = rccl_api()->AllReduce(out_dev, out_dev, n_out, ncclFloat32, ncclSum, s->comm, s->stream);
+            if (nr != ncclSuccess) return fail(ODDIO_HIP_ENODEV, "ncclAllReduce: %s", rccl_api()->GetErrorString(nr));
+            if (!s->adapt.on && s->postfx) {
+                hipLaunchKernelGGL(postfx_kernel, dim3((n_out + 255) / 256), dim3(256), 0, s->stream, out_dev, n_out, s->postfx);
+                HIP_TRY(hipGetLastError());
+            }
+        }
         if (s->adapt.on) { rc = adapt_launch(s->adapt, s->stream, interval, out_dev, n_frames, s->postfx); if (rc) return rc; }
     }
     if (prof) { HIP_TRY(hipEventRecord(pev[3], s->stream)); s->prof_calls++; }

@@ -1,5 +1,4 @@
-"""Multi-GPU for the hot path: one process per GPU over torch.distributed (backend "nccl" == RCCL
-over xGMI on MI355X; "gloo" in the CPU tests).
+"""Multi-GPU for the hot path: one process per GPU.
 
 The path shards naturally: sources are independent until the final
 per-frame sum (src/spatial.rs:460), independent scenes share nothing.
@@ -8,10 +7,15 @@ per-frame sum (src/spatial.rs:460), independent scenes share nothing.
     nothing here is needed except `shard_range` to split a list of scenes.
   * one huge scene (BASELINE configs[4]): contiguous source-index shards (keeps the reference's
     reverse walk order inside a shard); every rank renders a partial 2*N-float stereo buffer; ONE
-    sum-reduce of that 8 KiB buffer per callback (latency bound, ring vs tree is irrelevant at
-    this size); the post-mix soft clip (Reinhard/Tanh wraps the *scene*, src/reinhard.rs:7-10)
-    runs after the reduce.  The summation order differs from the single sequential f32 sum of the
-    reference, so the result is within the tolerance policy of SURVEY.md H2, not bit-identical.
+    all-reduce (sum) of that 8 KiB buffer per callback, issued by libodd_hip.so itself on the
+    scene's stream (`oddio_hip_scene_reduce_init`, RCCL over xGMI; latency bound, ring vs tree is
+    irrelevant at this size); the post-mix soft clip (Reinhard/Tanh wraps the *scene*,
+    src/reinhard.rs:7-10) runs after the sum.  The summation order differs from the single
+    sequential f32 sum of the reference, so the result is within the tolerance policy of
+    SURVEY.md H2, not bit-identical.
+
+`reduce_stereo` is the same reduction through torch.distributed (used by the gloo CPU tests, where
+there is no RCCL).
 """
 from __future__ import annotations
 
@@ -42,44 +46,48 @@ def reduce_stereo(partial, dist=None, group=None, dst: int | None = 0):
     return partial
 
 
+def exchange_unique_id(dist=None, src: int = 0) -> bytes:
+    """Rank `src` makes the reduce group's id (ncclGetUniqueId through the C ABI) and hands it to the
+    other ranks over the process group the host program already has (any backend)."""
+    from . import api
+    if dist is None:
+        import torch.distributed as dist
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return api.reduce_unique_id()
+    box = [api.reduce_unique_id() if dist.get_rank() == src else None]
+    dist.broadcast_object_list(box, src=src)
+    return box[0]
+
+
 class ShardedSpatialScene:
     """One logical SpatialScene whose sources are split into contiguous index shards, one per rank.
 
-    `play_frames_batch` is called with the FULL source list on every rank; each rank keeps only
-    its shard.  `sample_device` renders the shard on the HIP path into a torch tensor, reduces it
-    over RCCL on the same stream, then applies the scene-level post filter."""
+    `play_frames_batch` is called with the rank's OWN shard (`self.shard` = [lo, hi) of the global
+    source index); `sample_device` renders it on the HIP path, the library all-reduces the partial
+    stereo buffers over RCCL on the scene's stream and then applies the scene-level post filter, so
+    every rank ends up with the scene's mix."""
 
-    def __init__(self, device: int, max_sources_total: int, max_frames: int, postfx: int = 0, dst: int | None = 0):
-        import torch
-        import torch.distributed as dist
-
+    def __init__(self, device: int, n_sources_total: int, max_frames: int, rank: int, world: int, unique_id: bytes | None,
+                 postfx: int = 0):
         import oddio_amd as oa
-        self.torch, self.dist = torch, dist
-        self.rank = dist.get_rank() if dist.is_initialized() else 0
-        self.world = dist.get_world_size() if dist.is_initialized() else 1
-        self.device = device
-        self.postfx = postfx
-        self.dst = dst
-        lo, hi = shard_range(max_sources_total, self.world, self.rank)
+        self.rank, self.world, self.device = rank, world, device
+        self.shard = shard_range(n_sources_total, world, rank)
+        lo, hi = self.shard
         self.control, self.scene = oa.SpatialScene(device=device, max_sources=max(hi - lo, 1), max_frames=max_frames)
-        # collectives and kernels on one stream: the reduce is ordered after the mix without host syncs
-        self.scene.set_stream(torch.cuda.current_stream(device).cuda_stream)
-        self.out = torch.zeros((max_frames, 2), dtype=torch.float32, device=torch.device("cuda", device))
+        if postfx:
+            self.scene.set_postfx(postfx)
+        if unique_id is not None:
+            self.scene.reduce_init(rank, world, unique_id)
 
     def play_frames_batch(self, frames_list, start_seconds, positions, velocities, radii):
-        lo, hi = shard_range(len(frames_list), self.world, self.rank)
-        self.shard = (lo, hi)
-        if hi > lo:
-            return self.control.play_frames_batch(frames_list[lo:hi], np.asarray(start_seconds)[lo:hi], np.asarray(positions)[lo:hi],
-                                                  np.asarray(velocities)[lo:hi], np.asarray(radii)[lo:hi])
-        return []
+        assert len(frames_list) == self.shard[1] - self.shard[0], "pass this rank's shard of the source list"
+        if not frames_list:
+            return []
+        return self.control.play_frames_batch(frames_list, np.asarray(start_seconds), np.asarray(positions), np.asarray(velocities),
+                                              np.asarray(radii))
 
-    def sample_device(self, interval, n_frames: int):
-        from . import _lib
-        out = self.out[:n_frames]
-        self.scene.sample_device(interval, out.data_ptr(), n_frames)
-        reduce_stereo(out, self.dist, dst=self.dst)
-        if self.postfx and (self.dst is None or self.rank == self.dst):
-            stream = self.torch.cuda.current_stream(self.device).cuda_stream
-            _lib.check(_lib.lib().oddio_hip_postfx_device(self.device, self.postfx, out.data_ptr(), n_frames, stream))
-        return out
+    def sample_device(self, interval, dev_ptr: int, n_frames: int):
+        self.scene.sample_device(interval, dev_ptr, n_frames)
+
+    def sample(self, interval, out: np.ndarray):
+        return self.scene.sample(interval, out)

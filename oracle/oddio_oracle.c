@@ -141,6 +141,7 @@ struct oo_frames {
     size_t len;     /* frames */
     int channels;   /* 1: Frames<f32>, 2: Frames<[f32;2]> */
     int refcount;   /* Arc */
+    int borrowed;   /* samples belong to the caller (oo_frames_borrow): not freed */
     float* samples; /* len*channels */
 };
 
@@ -154,9 +155,21 @@ oo_frames* oo_frames_from_slice(uint32_t rate, const float* samples, size_t len,
     if (len) memcpy(f->samples, samples, sizeof(float) * len * channels);
     return f;
 }
+/* Harness helper for large scenes: the clip memory stays with the caller (which must outlive the
+ * frames); get_pair never reads past samples[len * channels - 1]. */
+oo_frames* oo_frames_borrow(uint32_t rate, const float* samples, size_t len, int channels) {
+    oo_frames* f = (oo_frames*)calloc(1, sizeof(*f));
+    f->rate = (double)rate;
+    f->len = len;
+    f->channels = channels;
+    f->refcount = 1;
+    f->borrowed = 1;
+    f->samples = (float*)samples;
+    return f;
+}
 void oo_frames_retain(oo_frames* f) { f->refcount++; }
 void oo_frames_release(oo_frames* f) {
-    if (--f->refcount == 0) { free(f->samples); free(f); }
+    if (--f->refcount == 0) { if (!f->borrowed) free(f->samples); free(f); }
 }
 
 /* frames.rs:105-123 get_pair, one channel `ch`.  Note `len - 1` is usize arithmetic: for an empty
@@ -808,6 +821,19 @@ int oo_scene_play(oo_signal* scene, oo_signal* signal, const float pos[3], const
     spatial_entry* e = spatial_entry_new(scene, signal, pos, vel, radius);
     pv_push(&scene->pending, e);
     return (int)scene->handles.len - 1;
+}
+/* Harness helper: n x `scene.play(FramesSignal::new(frames_i, start_i), SpatialOptions{..})` with
+ * frames_i = the mono clip at clips + (clip_of ? clip_of[i] : i) * clip_stride (borrowed, see oo_frames_borrow).  Same calls
+ * as the one-at-a-time path, made from C so that 10^5..10^6-source scenes set up in seconds. */
+void oo_scene_play_frames_bulk(oo_signal* scene, size_t n, uint32_t rate, const float* clips, size_t clip_len, size_t clip_stride,
+                               const uint32_t* clip_of, const double* start_seconds, const float* positions, const float* velocities,
+                               const float* radii) {
+    for (size_t i = 0; i < n; ++i) {
+        oo_frames* f = oo_frames_borrow(rate, clips + (clip_of ? (size_t)clip_of[i] : i) * clip_stride, clip_len, 1);
+        oo_signal* sig = oo_frames_signal_new(f, start_seconds[i]);
+        oo_frames_release(f);   /* the signal holds the Arc now */
+        (void)oo_scene_play(scene, sig, positions + 3 * i, velocities + 3 * i, radii[i]);
+    }
 }
 int oo_scene_play_buffered(oo_signal* scene, oo_signal* signal, const float pos[3], const float vel[3],
                            float radius, float max_distance, uint32_t rate, float buffer_duration) {

@@ -33,6 +33,7 @@ typedef struct oo_signal oo_signal;
 
 /* ---- Frames<T> (src/frames.rs:19-47) ---- */
 oo_frames* oo_frames_from_slice(uint32_t rate, const float* samples, size_t len, int channels);
+oo_frames* oo_frames_borrow(uint32_t rate, const float* samples, size_t len, int channels); /* harness: no copy */
 void oo_frames_retain(oo_frames* f);
 void oo_frames_release(oo_frames* f);
 
@@ -91,6 +92,9 @@ int  oo_mixer_is_stopped(const oo_signal* mixer, int handle);
 size_t oo_mixer_len(const oo_signal* mixer);
 
 /* SpatialScene (spatial.rs:289-349).  Returns a handle index valid for the scene's lifetime. */
+void oo_scene_play_frames_bulk(oo_signal* scene, size_t n, uint32_t rate, const float* clips, size_t clip_len, size_t clip_stride,
+                               const uint32_t* clip_of /* NULL: source i plays clip i */, const double* start_seconds,
+                               const float* positions, const float* velocities, const float* radii); /* harness: n x play(FramesSignal::new(..)), clips borrowed */
 int  oo_scene_play(oo_signal* scene, oo_signal* signal, const float pos[3], const float vel[3],
                    float radius);
 int  oo_scene_play_buffered(oo_signal* scene, oo_signal* signal, const float pos[3],

@@ -83,6 +83,7 @@ def lib():
             "oo_mixer_is_stopped": (i32, [vp, i32]),
             "oo_mixer_len": (sz, [vp]),
             "oo_scene_play": (i32, [vp, vp, fp, fp, f32]),
+            "oo_scene_play_frames_bulk": (None, [vp, sz, u32, fp, sz, sz, C.POINTER(C.c_uint32), C.POINTER(C.c_double), fp, fp, fp]),
             "oo_scene_play_buffered": (i32, [vp, vp, fp, fp, f32, f32, u32, f32]),
             "oo_scene_set_motion": (None, [vp, i32, fp, fp, i32]),
             "oo_scene_is_finished": (i32, [vp, i32]),
@@ -407,6 +408,22 @@ class SpatialScene(Signal):
         h = lib().oo_scene_play_buffered(self._h, signal._h, _fp(_vec3(options.position)), _fp(_vec3(options.velocity)),
                                          np.float32(options.radius), np.float32(max_distance), int(rate), np.float32(buffer_duration))
         return Spatial(self, h)
+
+    def play_frames_bulk(self, rate, clips, start_seconds, positions, velocities, radii, clip_of=None):
+        """n x `play(FramesSignal::new(Frames(rate, clips[k]), start[i]), SpatialOptions{..})` from C, k = i or
+        clip_of[i].  `clips` is a [*, clip_len] float32 array that is BORROWED (kept alive by this scene)."""
+        clips = np.ascontiguousarray(clips, dtype=np.float32)
+        clip_len = clips.shape[1]
+        n = clips.shape[0] if clip_of is None else len(clip_of)
+        cof = None if clip_of is None else np.ascontiguousarray(np.asarray(clip_of, dtype=np.uint32))
+        st = np.ascontiguousarray(np.broadcast_to(np.asarray(start_seconds, dtype=np.float64), (n,)))
+        pos = np.ascontiguousarray(np.asarray(positions, dtype=np.float32).reshape(n, 3))
+        vel = np.ascontiguousarray(np.asarray(velocities, dtype=np.float32).reshape(n, 3))
+        rad = np.ascontiguousarray(np.broadcast_to(np.asarray(radii, dtype=np.float32), (n,)))
+        self._kids.append(clips)
+        lib().oo_scene_play_frames_bulk(self._h, n, int(rate), _fp(clips), clip_len, clip_len,
+                                        None if cof is None else cof.ctypes.data_as(C.POINTER(C.c_uint32)),
+                                        st.ctypes.data_as(C.POINTER(C.c_double)), _fp(pos), _fp(vel), _fp(rad))
 
     def set_listener_rotation(self, q_sxyz):
         q = np.ascontiguousarray(np.asarray(q_sxyz, dtype=np.float32).reshape(4))

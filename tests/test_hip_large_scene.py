@@ -1,0 +1,248 @@
+"""Parity at the size the metric is quoted on (BASELINE configs[2]: 262 144 moving FramesSignal
+sources in ONE SpatialScene) and for the sharded pattern of configs[3]/[4], all through the C ABI.
+
+The oracle renders the same scene on the host (clips borrowed, set up from C): its sequential f32
+sum in the reference's order (src/spatial.rs:204,456-463) and an f64-accumulated sum of the same
+contributions.  Own white-noise clips of 8 192 samples per source (8 GiB) keep host RAM bounded;
+positions in a +-10 m cube so that the propagation delay (<= 50 ms) stays inside the clip.
+"""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import scenario  # noqa: F401  (puts tests/ helpers on the path the same way the other GPU tests do)
+from oddio_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+RATE = 48000
+INTERVAL = np.float32(1.0) / np.float32(RATE)
+N = 1024
+S_BIG = 262144
+CLIP = 8192
+START = 0.06
+SEED = 4242
+
+
+def gpu_noise_clips(seed, n, length, device):
+    """synth.noise_clip for clips [0, n) at once, on the GPU (SplitMix64 in wrapping int64 arithmetic)."""
+    import torch
+    G, M1, M2 = -7046029254386353131, -4658895280553007687, -7723592293110705685   # the u64 constants as i64
+
+    def lsr(x, k):
+        return (x >> k) & ((1 << (64 - k)) - 1)
+    idx = torch.arange(n, dtype=torch.int64, device=device)
+    state0 = torch.tensor((seed ^ 0x5EED), dtype=torch.int64, device=device) ^ (idx * G)
+    out = torch.empty((n, length), dtype=torch.float32, device=device)
+    steps = torch.arange(1, length + 1, dtype=torch.int64, device=device) * G
+    rows = max(1, (1 << 26) // length)
+    for r0 in range(0, n, rows):
+        z = state0[r0:r0 + rows, None] + steps[None, :]
+        z = (z ^ lsr(z, 30)) * M1
+        z = (z ^ lsr(z, 27)) * M2
+        z = z ^ lsr(z, 31)
+        out[r0:r0 + rows] = lsr(z, 40).to(torch.float32) * (2.0 ** -24) * 2.0 - 1.0
+    return out
+
+
+@pytest.fixture(scope="module")
+def big():
+    """Clips on the GPU and on the host, scene parameters, and the oracle's outputs for 2 callbacks."""
+    import torch
+
+    from oracle import oracle_c as oc
+    dev = torch.device("cuda", 0)
+    clips = gpu_noise_clips(SEED, S_BIG, CLIP, dev)
+    host = clips.cpu().numpy()
+    for i in (0, 1, 77777, S_BIG - 1):   # the GPU generator is the numpy one
+        np.testing.assert_array_equal(host[i], synth.noise_clip(SEED, i, CLIP))
+    sc = synth.make_scene(SEED, S_BIG, cube=10.0)
+    # every 4th source gets a new Motion before the second callback (exercises spatial.rs:217-224)
+    moved = np.arange(0, S_BIG, 4)
+    new_pos = sc["position"][moved] + np.float32(0.02) * sc["velocity"][moved]
+    new_vel = (-sc["velocity"][moved]).astype(np.float32)
+    ref32, ref64 = [], []
+    for acc64 in (False, True):
+        scene = oc.SpatialScene()
+        scene.play_frames_bulk(RATE, host, START, sc["position"], sc["velocity"], sc["radius"])
+        handles = None
+        for cb in range(2):
+            if cb == 1:
+                from oracle.oracle_c import lib, _fp, _vec3
+                for k, i in enumerate(moved):
+                    lib().oo_scene_set_motion(scene._h, int(i), _fp(_vec3(new_pos[k])), _fp(_vec3(new_vel[k])), 0)
+            if acc64:
+                ref64.append(scene.sample_f64acc(INTERVAL, N))
+            else:
+                out = np.zeros((N, 2), dtype=np.float32)
+                oc.run(scene, RATE, out)
+                ref32.append(out)
+        del scene, handles
+    return {"clips": clips, "host": host, "sc": sc, "moved": moved, "new_pos": new_pos, "new_vel": new_vel,
+            "ref32": ref32, "ref64": ref64}
+
+
+def play_shard(big, lo, hi, mode=0, postfx=0):
+    import oddio_amd as oa
+    control, scene = oa.SpatialScene(device=0, max_sources=hi - lo, max_frames=N)
+    scene.set_mode(mode)
+    if postfx:
+        scene.set_postfx(postfx)
+    base = big["clips"].data_ptr()
+    frames = [oa.Frames.from_device_ptr(RATE, base + 4 * CLIP * i, CLIP, device=0, copy=False) for i in range(lo, hi)]
+    sc = big["sc"]
+    handles = control.play_frames_batch(frames, np.full(hi - lo, START), sc["position"][lo:hi], sc["velocity"][lo:hi], sc["radius"][lo:hi])
+    return control, scene, handles, frames
+
+
+def apply_motion(big, control, handles, lo, hi):
+    sel = (big["moved"] >= lo) & (big["moved"] < hi)
+    ids = np.array([handles[i - lo].id for i in big["moved"][sel]], dtype=np.uint32)
+    if len(ids):
+        control.set_motion_batch(ids, big["new_pos"][sel], big["new_vel"][sel], False)
+
+
+def test_config3_fast_mode_vs_sequential_and_f64_oracle(big):
+    """262 144 sources, FAST mode (deterministic tree sum over waves / workgroups)."""
+    control, scene, handles, frames = play_shard(big, 0, S_BIG)
+    report = []
+    for cb in range(2):
+        if cb == 1:
+            apply_motion(big, control, handles, 0, S_BIG)
+        got = scene.sample_n(INTERVAL, N)
+        ref, ref64 = big["ref32"][cb], big["ref64"][cb]
+        scale = float(np.abs(ref).max())
+        d_ref = float(np.abs(got - ref).max())
+        err_gpu = float(np.abs(got.astype(np.float64) - ref64).max())
+        err_ref = float(np.abs(ref.astype(np.float64) - ref64).max())
+        report.append((scale, d_ref / scale, err_gpu / scale, err_ref / scale))
+        assert scale > 0
+        # (ii) never further from the exactly accumulated sum than 4x the reference's own rounding error
+        assert err_gpu <= 4 * err_ref + 1e-7 * scale, report
+        # (i) north_star: 1e-5 relative to the reference CPU result.  The reference's own sequential f32 sum is
+        # ~sqrt(S) * eps away from the exact sum, so where THAT distance exceeds 1e-5 no sum
+        # order other than the reference's can meet (i); the bound then is the triangle inequality through the
+        # exact sum (|gpu - ref| <= err_gpu + err_ref).  ORDERED mode (next test) is the bit-exact statement.
+        assert d_ref <= max(1e-5 * scale, err_gpu + err_ref + 1e-7 * scale), report
+    print("config3 FAST: (max|ref|, |gpu-ref|/s, |gpu-f64|/s, |ref-f64|/s) per callback:", report)
+    assert len(scene) == S_BIG
+
+
+def test_config3_ordered_mode_is_bit_exact(big):
+    """The same scene summed in the reference's order by one wavefront: identical bits at full size."""
+    control, scene, handles, frames = play_shard(big, 0, S_BIG, mode=1)
+    for cb in range(2):
+        if cb == 1:
+            apply_motion(big, control, handles, 0, S_BIG)
+        got = scene.sample_n(INTERVAL, N)
+        np.testing.assert_array_equal(got, big["ref32"][cb])
+
+
+@pytest.mark.parametrize("world", [2, 8])
+def test_sharded_partials_equal_unsharded_hip(big, world):
+    """configs[3]/[4] arithmetic on the HIP path: contiguous index shards rendered as separate scenes (what
+    each rank does), partial buffers summed in rank order, Reinhard after the sum -- against the unsharded HIP
+    scene and the oracle.  (The transport, RCCL, is covered by the world-1 test below and the 2-GPU test.)"""
+    from oddio_amd.sharding import shard_range
+    S = 65536                       # 8 x 8192 / 2 x 32768: keeps the test short
+    control, scene, handles, frames = play_shard(big, 0, S)
+    whole = [scene.sample_n(INTERVAL, N).copy() for _ in range(2)]
+    parts = []
+    for r in range(world):
+        lo, hi = shard_range(S, world, r)
+        c, s, h, f = play_shard(big, lo, hi)
+        parts.append([s.sample_n(INTERVAL, N).copy() for _ in range(2)])
+    for cb in range(2):
+        total = np.zeros((N, 2), dtype=np.float32)
+        for r in range(world):
+            total = total + parts[r][cb]
+        scale = np.abs(whole[cb]).max()
+        assert scale > 0
+        assert np.abs(total - whole[cb]).max() <= 2e-6 * scale      # both are tree sums of the same contributions
+        clipped = total / (np.float32(1.0) + np.abs(total))         # Reinhard after the reduce (src/reinhard.rs:32)
+        ref = whole[cb] / (np.float32(1.0) + np.abs(whole[cb]))
+        assert np.abs(clipped - ref).max() <= 2e-6 * np.abs(ref).max()
+
+
+def test_rccl_reduce_world_1(big):
+    """The C ABI's collective entry points on one GPU: unique id, communicator, an all-reduce per callback on
+    the scene's stream, the post filter after it."""
+    import oddio_amd as oa
+    from oddio_amd import api
+    S = 4096
+    control, scene, handles, frames = play_shard(big, 0, S, postfx=oa.POSTFX_REINHARD)
+    plain = [scene.sample_n(INTERVAL, N).copy() for _ in range(2)]
+    control2, scene2, handles2, frames2 = play_shard(big, 0, S, postfx=oa.POSTFX_REINHARD)
+    scene2.reduce_init(0, 1, api.reduce_unique_id())
+    for cb in range(2):
+        got = scene2.sample_n(INTERVAL, N)
+        np.testing.assert_array_equal(got, plain[cb])     # a world of one: the sum of one partial, then Reinhard
+    scene2.reduce_destroy()
+
+
+_WORKER = r"""
+import os, sys
+import numpy as np
+sys.path.insert(0, {root!r}); sys.path.insert(0, os.path.join({root!r}, "tests"))
+import torch, torch.distributed as dist
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+torch.cuda.set_device(rank)
+os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
+dist.init_process_group("gloo", rank=rank, world_size=world)
+import oddio_amd as oa
+from oddio_amd import sharding, synth
+S, CLIP, N, RATE, START, SEED = 8192, 8192, 1024, 48000, 0.06, 99
+uid = sharding.exchange_unique_id(dist)
+sh = sharding.ShardedSpatialScene(rank, S, N, rank, world, uid, postfx=oa.POSTFX_REINHARD)
+lo, hi = sh.shard
+sc = synth.make_scene(SEED, S, cube=10.0)
+frames = [oa.Frames.from_slice(RATE, synth.noise_clip(SEED, i, CLIP), device=rank) for i in range(lo, hi)]
+sh.play_frames_batch(frames, np.full(hi - lo, START), sc["position"][lo:hi], sc["velocity"][lo:hi], sc["radius"][lo:hi])
+outs = [sh.sample(np.float32(1.0) / np.float32(RATE), np.zeros((N, 2), np.float32)).copy() for _ in range(2)]
+np.save(os.path.join({tmp!r}, f"rank{{rank}}.npy"), np.stack(outs))
+dist.barrier(); dist.destroy_process_group()
+"""
+
+
+def test_sharded_scene_two_gpus_rccl(tmp_path):
+    """One seeded scene on 2 GPUs through the library's RCCL all-reduce vs the same scene on one GPU."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs 2 GPUs (the driver's multi-GPU box); the 1-GPU box covers the arithmetic and world=1")
+    import oddio_amd as oa
+    S, CLIP2, SEED2 = 8192, 8192, 99
+    script = tmp_path / "worker.py"
+    script.write_text(_WORKER.format(root=ROOT, tmp=str(tmp_path)))
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    procs = [subprocess.Popen([sys.executable, str(script)],
+                              env=dict(os.environ, RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port)))
+             for r in range(2)]
+    assert [p.wait(timeout=600) for p in procs] == [0, 0]
+    got = [np.load(tmp_path / f"rank{r}.npy") for r in range(2)]
+    np.testing.assert_array_equal(got[0], got[1])            # all-reduce: every rank holds the mix
+    control, scene = oa.SpatialScene(device=0, max_sources=S, max_frames=N)
+    scene.set_postfx(oa.POSTFX_REINHARD)
+    sc = synth.make_scene(SEED2, S, cube=10.0)
+    frames = [oa.Frames.from_slice(RATE, synth.noise_clip(SEED2, i, CLIP2), device=0) for i in range(S)]
+    control.play_frames_batch(frames, np.full(S, START), sc["position"], sc["velocity"], sc["radius"])
+    for cb in range(2):
+        ref = scene.sample_n(INTERVAL, N)
+        assert np.abs(got[0][cb] - ref).max() <= 2e-6 * np.abs(ref).max()
+
+
+def test_bench_self_launch_two_ranks():
+    """`python bench.py --gpus 2` spawns its own ranks (here both on device 0) and prints one JSON line."""
+    import json
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--share-devices", "--sources", "4096", "--clip-len", "65536",
+                        "--steps", "4", "--warmup", "2", "--no-cpu-baseline"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["ranks_seen"] == 2 and d["value"] > 0
+    assert d["roofline"]["frac"] > 0 and d["roofline"]["frac_callback"] > 0

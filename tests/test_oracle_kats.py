@@ -111,9 +111,21 @@ def test_mono_to_stereo():
 
 # ---- src/math/mod.rs:101-129 --------------------------------------------------------------
 
+import ctypes as _C
+import ctypes.util as _Cu
+
+_libm = _C.CDLL(_Cu.find_library("m") or "libm.so.6")
+_libm.sinf.restype = _C.c_float
+_libm.sinf.argtypes = [_C.c_float]
+_libm.cosf.restype = _C.c_float
+_libm.cosf.argtypes = [_C.c_float]
+
+
 def axis_angle(axis, angle):
+    """math/mod.rs:131-142: `half.cos()` / `half.sin()` are f32 calls (Rust std -> the platform's
+    cosf / sinf), so the quaternion is built with libm's f32 functions, not from f64 values."""
     half = f32(angle) * f32(0.5)
-    s, c = f32(math.sin(half)), f32(math.cos(half))
+    s, c = f32(_libm.sinf(float(half))), f32(_libm.cosf(float(half)))
     return arr(c, f32(axis[0]) * s, f32(axis[1]) * s, f32(axis[2]) * s)
 
 
@@ -122,23 +134,23 @@ PI = f32(math.pi)
 
 def test_rotate_x():
     r = oo.rotate(axis_angle([1, 0, 0], PI / f32(2)), [0.0, 0.0, -1.0])
-    assert r[0] == 0.0
+    assert r[0] == 0.0                      # assert_eq!(r.x, 0.0)
     assert abs(r[1] - 1.0) < 1e-3
-    assert r[2] == 0.0 or abs(r[2]) < 1e-6  # reference asserts == 0.0 with std cos/sin of f32 PI/4
+    assert r[2] == 0.0                      # assert_eq!(r.z, 0.0)
 
 
 def test_rotate_y():
     r = oo.rotate(axis_angle([0, 1, 0], PI / f32(2)), [1.0, 0.0, 0.0])
+    assert r[0] == 0.0
     assert r[1] == 0.0
     assert abs(r[2] + 1.0) < 1e-3
-    assert r[0] == 0.0 or abs(r[0]) < 1e-6
 
 
 def test_rotate_z():
     r = oo.rotate(axis_angle([0, 0, 1], PI / f32(2)), [0.0, 1.0, 0.0])
-    assert r[2] == 0.0
+    assert r[1] == 0.0
     assert abs(r[0] + 1.0) < 1e-3
-    assert r[1] == 0.0 or abs(r[1]) < 1e-6
+    assert r[2] == 0.0
 
 
 # ---- src/mixer.rs:130-147 -----------------------------------------------------------------
