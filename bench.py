@@ -257,6 +257,11 @@ def main():
                          "'sharded' = ONE scene of N*sources split into contiguous index shards with an RCCL all-reduce "
                          "of the 8 KiB stereo buffer per callback (configs[4] pattern)")
     ap.add_argument("--share-devices", action="store_true", help="smoke-testing on a box with fewer GPUs than ranks: rank r uses device r %% count")
+    ap.add_argument("--reset-every", type=int, default=320, help="callbacks between host-side motion resets of all sources")
+    ap.add_argument("--precondition-ms", type=float, default=150.0,
+                    help="GPU clock pre-conditioning before the warm-up steps: this many ms of elementwise f32 work on a scratch "
+                         "tensor (not callbacks), so that a short warm-up starts from loaded clocks instead of the idle state the "
+                         "host-side set-up leaves behind (DESIGN.md section 5); 0 disables it")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=20.0)
     args = ap.parse_args()
@@ -312,7 +317,7 @@ def main():
     # callbacks a clip lasts before sources would run off its end; rewind before that
     span = max(1, (L - int(start_seconds * RATE)) // N_FRAMES - 8)
     rewind_seconds = -float(span * N_FRAMES) / RATE
-    reset_every = 320   # callbacks; bounds the drift of the constant-velocity sources (a host-side batch set_motion)
+    reset_every = args.reset_every   # callbacks; bounds the drift of the constant-velocity sources (a host-side batch set_motion)
 
     step_no = 0
 
@@ -333,6 +338,19 @@ def main():
         scene.synchronize()
         torch.cuda.synchronize()
 
+    if args.precondition_ms > 0:
+        # DVFS: after seconds of host-side set-up the chip sits in a low clock state and needs ~30 ms of load to
+        # leave it; the mix kernel is LDS/VALU-side bound enough to feel that (tools/ramp_probe.py).  Untimed, and
+        # not the hot path: plain elementwise work on a scratch tensor.
+        scratch = torch.rand((1 << 28,), dtype=torch.float32, device=torch.device("cuda", device))
+        t_pre = time.perf_counter()
+        k = 0
+        while (time.perf_counter() - t_pre) * 1e3 < args.precondition_ms:
+            torch.sin(scratch)
+            k += 1
+            if k % 8 == 0:
+                torch.cuda.synchronize()
+        del scratch
     for _ in range(args.warmup):
         one_step()
     scene.set_profiling(True)
@@ -411,6 +429,7 @@ def main():
             "max_realtime_sources": value / RATE,
             "realtime_factor_per_gpu": (N_FRAMES / RATE) / (elapsed / args.steps),
             "host_output_ms_per_step": host_ms,
+            "precondition_ms": args.precondition_ms,
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
                 "traffic": traffic, "traffic_source": traffic_source,

@@ -292,18 +292,22 @@ __global__ __launch_bounds__(64) void cycle_sources(SceneParams P, const SrcStat
 // ---------------------------------------------------------------------------------------------
 // mix kernel
 // ---------------------------------------------------------------------------------------------
-// Shape (measured on MI355X, tools/ubench/valu_cost.hip and the PMC passes under profiles/):
-// one wave issues a VALU op only every ~5 cycles, a SIMD needs >= 4 resident waves to saturate,
-// v_pk_*_f32 costs two scalar ops, and the kernel is VALU-issue bound (LDS ~1/3 busy).  So it is
-// built for 16 waves per CU (<= 128 VGPRs, <= 10 KB LDS per wave) and for the fewest VALU
-// instructions per output sample (11 in the common path):
+// Shape (measured on MI355X: tools/ubench/valu_rate.hip, hbm_ceiling.hip and the PMC passes under
+// profiles/): one wave issues a VALU op every ~4.6 cycles and two always-ready waves saturate a
+// SIMD (~2.4 cycles per wave64 op); v_pk_*_f32 costs two scalar ops; the LDS serves a 32-lane
+// group with ~2-way bank conflicts whatever the layout when the lanes' runs are 16*ds samples
+// apart; HBM delivers ~5.6 TB/s for 2.3 KB windows at random places.  All three are within ~25 %
+// of each other for this loop, so the kernel is built to keep all of them busy at once:
 //   * a wave renders a 512-frame tile (2 chunks of 256, spatial.rs:393) of its sources: lanes
 //     0-31 are the left ear, 32-63 the right ear; lane (e, c, b) owns the 16 consecutive frames
 //     256c+16b.. of ear e => 16 register accumulators;
 //   * phase A handles 16 sources at a time: lane (j, e, c) runs the exact f32 cursor scan of
 //     source j / ear e / chunk c and leaves 16 checkpoints in LDS;
-//   * the source's sample window is fetched with bounds-checked buffer loads (hardware zero fill
-//     == frames.rs:105-123 out-of-range rule), one source ahead, and staged in LDS once;
+//   * the source's sample window goes HBM -> LDS directly (buffer_load ... lds, 16 B per lane,
+//     bounds-checked descriptor: hardware zero fill == frames.rs:105-123 out-of-range rule) into
+//     one of two window buffers, one source ahead of the compute, with no register staging;
+//   * the per-sample LDS pair reads are software-pipelined by hand (MIX_DEPTH samples in flight),
+//     so a wave computes on sample i while the pairs of samples i+1.. are on their way;
 //   * workgroups are MIX_WG_WAVES independent waves (own LDS slice, wave-local ordering only);
 //     their accumulators are summed through LDS in fixed order before one partial tile is written.
 #ifndef ODDIO_MIX_WG_WAVES
@@ -312,18 +316,18 @@ __global__ __launch_bounds__(64) void cycle_sources(SceneParams P, const SrcStat
 #ifndef ODDIO_MIX_WAVES
 #define ODDIO_MIX_WAVES 4
 #endif
-#ifndef ODDIO_MIX_BATCH
-#define ODDIO_MIX_BATCH 2
+#ifndef ODDIO_MIX_DEPTH
+#define ODDIO_MIX_DEPTH 1
 #endif
 constexpr int MIX_WG_WAVES = ODDIO_MIX_WG_WAVES;       // waves per workgroup
 constexpr int MIX_WAVES_PER_SIMD = ODDIO_MIX_WAVES;    // register budget: 512 / this
-constexpr int MIX_BATCH = ODDIO_MIX_BATCH;             // frames whose LDS reads are in flight together
+constexpr int MIX_DEPTH = ODDIO_MIX_DEPTH;             // samples whose LDS pair reads are in flight together
 constexpr int MIX_WAVES_PER_CU = 16;                   // default grid size (waves per CU)
 constexpr int MIX_GROUP = 16;                // sources per phase-A step (16 x 2 ears x 2 chunks = 64 lanes)
 constexpr int TILE_FRAMES = 512;             // frames per (wave, tile) pass
 constexpr int TILE_CHUNKS = TILE_FRAMES / 256;
-constexpr int WIN_CAP = 768;                 // samples staged per source and tile (ds <= ~1.43)
-constexpr int WIN_VECS = WIN_CAP / 256;      // float4 loads per lane covering WIN_CAP
+constexpr int WIN_CAP = 608;                 // samples staged per source and tile (ds <= ~1.11)
+constexpr int WIN_PIECES = (WIN_CAP * 4 + 1023) / 1024;   // 1 KiB DMA pieces covering a window buffer
 #ifndef ODDIO_PAD_EPS
 #define ODDIO_PAD_EPS 0.004f
 #endif
@@ -332,26 +336,29 @@ constexpr float PAD_EPS = ODDIO_PAD_EPS;           // |ds - 1| below this: lanes
 enum : int { PATH_SKIP = 0, PATH_LDS = 1, PATH_GENERIC = 2, PATH_SINE = 3, PATH_CONST = 4, PATH_ROW = 5 };
 
 // LDS map of one wave (bytes)
-//   WIN   the source's sample window, one copy.  General sources: plain (sample s at 4*s), pairs
-//         read with ds_read2_b32.  Sources whose resample ratio is within PAD_EPS of 1 (and the
-//         |ds-1| <= EPSILON fast path): one pad float per 16 samples (slot s + s/16; the pad repeats
-//         the next sample), otherwise the lanes' 16-frame runs, 16 samples apart, would all hit
-//         two banks.
-//   CKPT  64 phase-A lanes x 16 cursor checkpoints, xor-swizzled
-//   CINFO per phase-A lane {wrel, frac bits};  EPAR per (source, ear) {g0, dg, ds, fixed_gain}
-//   SINFO per source {ws, count, path, flags}
-constexpr int LDS_WIN = 0;
-constexpr int WIN_SLOTS = 1024;              // >= WIN_CAP*17/16 + 1; 4 KB so the region can also park 16 accumulators x 64 lanes
-constexpr int LDS_CKPT = ((WIN_SLOTS * 4 + 15) / 16) * 16;
+//   WIN0/WIN1 two window buffers.  General sources: plain (sample s at 4*s), pairs read with
+//         ds_read2_b32.  Sources whose resample ratio is within PAD_EPS of 1 (and the
+//         |ds-1| <= EPSILON fast path) are re-laid in place with one pad float per 16 samples
+//         (slot s + s/16; the pad repeats the next sample), otherwise the lanes' 16-frame runs,
+//         16 samples apart, would all hit two banks.
+//   CKPT  64 phase-A lanes x 16 cursor checkpoints, xor-swizzled (checkpoint 0 == the chunk's
+//         start offset frac0)
+//   CINFO per phase-A lane: window-relative base index
+//   EPAR  per (source, ear) {g0, dg, ds, -}
+//   SINFO per source {ws, count, path, flags, clip lo, clip hi, clip_len4, fixed_gain}
+constexpr int LDS_WIN0 = 0;
+constexpr int WIN_BYTES = WIN_CAP * 4;
+constexpr int LDS_WIN1 = LDS_WIN0 + WIN_BYTES;
+constexpr int LDS_CKPT = LDS_WIN1 + WIN_BYTES;
 constexpr int LDS_CINFO = LDS_CKPT + 64 * 16 * 4;
-constexpr int LDS_EPAR = LDS_CINFO + 64 * 2 * 4;
+constexpr int LDS_EPAR = LDS_CINFO + 64 * 4;
 constexpr int LDS_SINFO = LDS_EPAR + MIX_GROUP * 2 * 16;
-constexpr int LDS_TOTAL = LDS_SINFO + MIX_GROUP * 4 * 4;
+constexpr int LDS_TOTAL = LDS_SINFO + MIX_GROUP * 8 * 4;
 constexpr int SFLAG_NEG = 1, SFLAG_FAST_L = 2, SFLAG_FAST_R = 4, SFLAG_PAD = 8;
-static_assert(LDS_TOTAL % 16 == 0, "per-wave LDS slices stay 16-byte aligned");
+static_assert(WIN_BYTES % 16 == 0 && LDS_TOTAL % 16 == 0, "per-wave LDS slices and window buffers stay 16-byte aligned");
 static_assert(LDS_TOTAL <= 10240, "16 waves per CU need <= 10 KB of LDS each");
-static_assert(WIN_SLOTS >= WIN_CAP + WIN_CAP / 16 + 1, "padded window fits");
 static_assert(LDS_CKPT >= 16 * 64 * 4, "accumulator parking / cross-wave reduction use 4 KB at offset 0 and must not reach CKPT");
+static_assert(WIN_PIECES * 1024 <= 4095 + 1024, "the DMA's 12-bit instruction offset reaches every piece");
 
 __device__ __forceinline__ void wave_sync() {
     // Waves never share window/checkpoint data: the LDS pipeline executes one wave's DS operations
@@ -366,78 +373,86 @@ __device__ __forceinline__ float rl_f(float v, int lane) {
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
 }
 __device__ __forceinline__ int rl_i(int v, int lane) { return __builtin_amdgcn_readlane(v, lane); }
-__device__ __forceinline__ const float* rl_ptr(const float* p, int lane) {
-    const uint64_t u = (uint64_t)p;
-    return (const float*)(((uint64_t)(uint32_t)rl_i((int)(u >> 32), lane) << 32) | (uint64_t)(uint32_t)rl_i((int)(u & 0xffffffffu), lane));
-}
-__device__ __forceinline__ double rl_d(double v, int lane) {
-    const long long b = __double_as_longlong(v);
-    return __longlong_as_double(((long long)rl_i((int)(b >> 32), lane) << 32) | (long long)(uint32_t)rl_i((int)(b & 0xffffffff), lane));
-}
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
-// Coalesced 16 B/lane read of samples [ws, ws + 4*nvec) of a clip into registers through a buffer
-// descriptor clipped to [window, clip end): lanes outside read 0 with no memory traffic.
+// HBM -> LDS: samples [ws, ws + 4*nvec) of a clip into the window buffer at LDS byte address
+// `lds_dst`, 16 B per lane per piece, through a buffer descriptor clipped to [window, clip end):
+// lanes outside it get zeros with no memory traffic (frames.rs:105-123).  The loads are issued from
+// inline asm on purpose: hipcc would make every later ds_read wait for ALL outstanding LDS-DMA
+// (it cannot tell the two window buffers apart), which would serialise the prefetch of the next
+// source with the reads of the current one.  Completion is awaited with window_wait().
 // All descriptor inputs are wave-uniform scalars.
-__device__ __forceinline__ void window_load(u32x4 (&pre)[WIN_VECS], const float* clip, int clip_len4, int ws, int nvec, int lane) {
+__device__ __forceinline__ void window_dma(uint32_t lds_dst, const float* clip, int clip_len4, int ws, int nvec, int lane) {
     const int ws_pos = ws > 0 ? ws : 0;             // first in-clip sample of the window
     const int neg4 = (ws < 0 ? ws : 0) * 4;         // byte offset of the window start relative to it (<= 0)
     long long rec = (long long)(clip_len4 - ws_pos) * 4;          // bytes to the (padded) clip end
     const long long wend = (long long)neg4 + (long long)nvec * 16;   // bytes to the window end
     if (rec > wend) rec = wend;
     if (rec < 0) rec = 0;
-    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(clip + ws_pos), 0, (int)rec, 0x00020000);
-#pragma unroll
-    for (int k = 0; k < WIN_VECS; ++k) {
-        // negative offsets wrap to huge unsigned values: out of range -> 0
-        pre[k] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, neg4 + 16 * lane + 1024 * k, 0, 0);
-    }
+    const uint64_t base = (uint64_t)(clip + ws_pos);
+    u32x4 rsrc;
+    rsrc.x = (uint32_t)__builtin_amdgcn_readfirstlane((int)(base & 0xffffffffu));
+    rsrc.y = (uint32_t)__builtin_amdgcn_readfirstlane((int)((base >> 32) & 0xffffu));   // stride 0
+    rsrc.z = (uint32_t)__builtin_amdgcn_readfirstlane((int)rec);
+    rsrc.w = 0x00020000u;
+    const uint32_t dst = (uint32_t)__builtin_amdgcn_readfirstlane((int)lds_dst);
+    const int voff = neg4 + 16 * lane;              // negative offsets wrap to huge unsigned values: out of range -> 0
+    uint32_t keep;
+#define ODDIO_DMA_PIECE(K)                                                                                                   \
+    if (K < WIN_PIECES && lane + 64 * K < nvec)                                                                              \
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 4\n\tbuffer_load_dwordx4 %1, %2, 0 offen offset:%4 lds\n\ts_mov_b32 m0, %0" \
+                     : "=&s"(keep) : "v"(voff), "s"(rsrc), "s"(dst), "i"(1024 * K) : "memory");
+    ODDIO_DMA_PIECE(0)
+    ODDIO_DMA_PIECE(1)
+    ODDIO_DMA_PIECE(2)
+#undef ODDIO_DMA_PIECE
+    static_assert(WIN_PIECES <= 3, "add pieces");
 }
-// registers -> LDS.  Plain layout: one aligned 16-byte store per float4.
-__device__ __forceinline__ void window_store_plain(unsigned char* smem, const u32x4 (&pre)[WIN_VECS], int nvec, int lane) {
+__device__ __forceinline__ void window_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
+// Near-unit sources: plain -> padded layout in place (slot(s) = s + s/16; the pad slot repeats the
+// following sample so that a pair (w, w+1) is always two adjacent dwords).  One wave: the DS
+// operations execute in issue order, so every read below precedes every write.
+__device__ __forceinline__ void window_repack_padded(unsigned char* win_bytes, int nvec, int lane) {
+    u32x4 v[WIN_PIECES];
 #pragma unroll
-    for (int k = 0; k < WIN_VECS; ++k) {
-        if (lane + 64 * k < nvec) *reinterpret_cast<u32x4*>(smem + LDS_WIN + 16 * lane + 1024 * k) = pre[k];
-    }
-}
-// Padded layout: slot(s) = s + s/16; the pad slot repeats the following sample, so that a pair
-// (w, w+1) is always two adjacent dwords.
-__device__ __forceinline__ void window_store_padded(unsigned char* smem, const u32x4 (&pre)[WIN_VECS], int nvec, int lane) {
-    unsigned int* win = reinterpret_cast<unsigned int*>(smem + LDS_WIN);
+    for (int k = 0; k < WIN_PIECES; ++k)
+        v[k] = (lane + 64 * k < nvec) ? *reinterpret_cast<const u32x4*>(win_bytes + 16 * lane + 1024 * k) : u32x4{0u, 0u, 0u, 0u};
+    wave_sync();
+    unsigned int* win = reinterpret_cast<unsigned int*>(win_bytes);
 #pragma unroll
-    for (int k = 0; k < WIN_VECS; ++k) {
-        const int v = lane + 64 * k;
-        if (v < nvec) {
-            const int li = 4 * v;
+    for (int k = 0; k < WIN_PIECES; ++k) {
+        const int q = lane + 64 * k;
+        if (q < nvec) {
+            const int li = 4 * q;
             const int pos = li + (li >> 4);
-            win[pos + 0] = pre[k].x; win[pos + 1] = pre[k].y; win[pos + 2] = pre[k].z; win[pos + 3] = pre[k].w;
-            if ((li & 15) == 0 && li > 0) win[pos - 1] = pre[k].x;
+            win[pos + 0] = v[k].x; win[pos + 1] = v[k].y; win[pos + 2] = v[k].z; win[pos + 3] = v[k].w;
+            if ((li & 15) == 0 && li > 0) win[pos - 1] = v[k].x;
         }
     }
+    wave_sync();
 }
 
 // One source, staged-window path.  acc[i] += lerp * gain for this lane's ear (spatial.rs:458-462).
 // NONNEG: every cursor value of the source is >= 0, so fract(x) == x - trunc(x) (one v_fract_f32).
 // PAD: padded window layout (see above); also serves frames.rs:180-187's constant-fract path.
+// `x` is the lane's checkpoint (the cursor at its first frame), `wrel` its chunk's base index
+// relative to the window start.
 template <bool FULL, bool HAS_FG, bool NONNEG, bool PAD>
-__device__ __forceinline__ void mix_source_lds(const unsigned char* smem, int la, int b, int fast, float (&acc)[16], const float (&fi)[16],
-                                               uint32_t frame0, uint32_t n_frames, float fixed_gain, float g0, float dg, float ds) {
+__device__ __forceinline__ void mix_source_lds(const float* win, int wrel, float x, int b, int fast, float frac0, float (&acc)[16],
+                                               const float (&fi)[16], uint32_t frame0, uint32_t n_frames, float fixed_gain, float g0, float dg,
+                                               float ds) {
     if (!FULL && frame0 >= n_frames) return;   // this lane's 16 frames lie past the end of `out`
-    const int* cinfo = reinterpret_cast<const int*>(smem + LDS_CINFO);
-    const float* ckpt = reinterpret_cast<const float*>(smem + LDS_CKPT);
-    const float* win = reinterpret_cast<const float*>(smem + LDS_WIN);
-    const int wrel = cinfo[la * 2 + 0];
     if (PAD && fast) {
         // frames.rs:180-187 (|ds - 1| <= EPSILON): constant fract, consecutive pairs
-        const float fracf = __int_as_float(cinfo[la * 2 + 1]);
         const int w0 = wrel + 16 * b;
         float a = win[w0 + (w0 >> 4)];
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
             const int w1 = w0 + i + 1;
             const float bb = win[w1 + (w1 >> 4)];
-            float v = a + fracf * (bb - a);
+            float v = a + frac0 * (bb - a);
             if (HAS_FG) v = v * fixed_gain;
             const float p = v * (g0 + fi[i] * dg);
             if (FULL || frame0 + (uint32_t)i < n_frames) acc[i] = acc[i] + p;
@@ -446,31 +461,32 @@ __device__ __forceinline__ void mix_source_lds(const unsigned char* smem, int la
         return;
     }
     // frames.rs:189-196: x_{16b+i} = x_{16b} (+ ds) i times, exactly as the scan produced it.
-    // Software pipelined by hand: a batch's LDS reads are all issued before the first lerp
-    // consumes one.
-    float x = ckpt[la * 16 + (b ^ (la & 15))];
-#pragma unroll
-    for (int i0 = 0; i0 < 16; i0 += MIX_BATCH) {
-        float a[MIX_BATCH], bb[MIX_BATCH], fr[MIX_BATCH];
-#pragma unroll
-        for (int k = 0; k < MIX_BATCH; ++k) {
-            const int tr = (int)x;                                        // v_cvt_i32_f32 (toward zero)
-            fr[k] = NONNEG ? __builtin_amdgcn_fractf(x) : x - (float)tr;  // frames.rs:192
-            int w = wrel + tr;
-            if (PAD) w = w + (w >> 4);
-            a[k] = win[w];                                                // one ds_read2_b32
-            bb[k] = win[w + 1];
-            x = x + ds;                                                   // frames.rs:194
-        }
-#pragma unroll
-        for (int k = 0; k < MIX_BATCH; ++k) {
-            const int i = i0 + k;
-            float v = a[k] + fr[k] * (bb[k] - a[k]);              // frame.rs:39-41 lerp, unfused
-            if (HAS_FG) v = v * fixed_gain;                       // gain.rs:32-37
-            const float p = v * (g0 + fi[i] * dg);                // spatial.rs:459-460
-            if (FULL || frame0 + (uint32_t)i < n_frames) acc[i] = acc[i] + p;
-        }
+    // Software pipelined by hand: the pair reads of samples i+1 .. i+MIX_DEPTH are issued before
+    // sample i is consumed; sched_barrier keeps hipcc from sinking them back next to their use.
+    const float* wbase = win + wrel;
+    float a[16], bb[16], fr[16];
+#define ODDIO_ISSUE(I)                                                                  \
+    {                                                                                   \
+        const int tr = (int)x;                                  /* v_cvt_i32_f32 (toward zero) */ \
+        fr[I] = NONNEG ? __builtin_amdgcn_fractf(x) : x - (float)tr;   /* frames.rs:192 */          \
+        int w = tr;                                                                     \
+        if (PAD) { w = wrel + tr; w = w + (w >> 4); a[I] = win[w]; bb[I] = win[w + 1]; } \
+        else { a[I] = wbase[w]; bb[I] = wbase[w + 1]; }         /* one ds_read2_b32 */   \
+        x = x + ds;                                             /* frames.rs:194 */      \
     }
+#pragma unroll
+    for (int i = 0; i < MIX_DEPTH; ++i) ODDIO_ISSUE(i)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        if (i + MIX_DEPTH < 16) ODDIO_ISSUE(i + MIX_DEPTH)
+        __builtin_amdgcn_sched_barrier(0);
+        float v = a[i] + fr[i] * (bb[i] - a[i]);              // frame.rs:39-41 lerp, unfused
+        if (HAS_FG) v = v * fixed_gain;                       // gain.rs:32-37
+        const float p = v * (g0 + fi[i] * dg);                // spatial.rs:459-460
+        if (FULL || frame0 + (uint32_t)i < n_frames) acc[i] = acc[i] + p;
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#undef ODDIO_ISSUE
 }
 
 // frames.rs:105-123 straight from global memory
@@ -482,15 +498,52 @@ __device__ __forceinline__ float clip_at(const float* clip, uint32_t len, long l
 // Sources that do not take the staged-window path (windows larger than the LDS stage, backwards
 // or absurd cursors, Sine / Constant sources).  Kept out of line and working on accumulators
 // parked in LDS (slot i of lane l at acc_lds[i * 64 + l]) so that their register needs (sinf range
-// reduction, 64-bit indices) do not inflate the hot kernel's allocation.
-__device__ __noinline__ void mix_source_generic(float* acc_lds, int lane, float fbase, uint32_t frame0, uint32_t n_frames,
-                                                uint32_t c_abs, const float* clip, uint32_t clip_len, uint32_t clip_rate,
-                                                float fixed_gain, double t_ear, float dt, float g0, float dg, int downmix) {
-    const int b = lane & 15;
-    double t_c = t_ear;
+// reduction, 64-bit indices) do not inflate the hot kernel's allocation.  They fetch the source's
+// parameters from global memory themselves.
+__device__ __noinline__ void mix_source_rare(float* acc_lds, int lane, uint32_t frame0, uint32_t n_frames, uint32_t c_abs, int path,
+                                             const SrcStatic* __restrict__ st, const EarParams* __restrict__ ear, uint32_t src,
+                                             const float* cycle_rows, uint32_t cycle_plane) {
+    const int b = lane & 15, eB = lane >> 5;
+    const SrcStatic s = st[src];
+    const EarParams ep = ear[2 * src + eB];
+    const float fbase = (float)frame0;
+    const float g0 = ep.g0, dg = ep.dg, dt = ep.dt, fixed_gain = s.fixed_gain;
+    if (path == PATH_ROW) {
+        // Seek-set Cycle: the contribution was rendered by cycle_sources; add it at this source's position
+        const float* plane = cycle_rows + ((size_t)__float_as_uint(s.freq_or_value) * 2u + (uint32_t)eB) * cycle_plane;
+#pragma unroll 1
+        for (int i = 0; i < 16; ++i)
+            if (frame0 + (uint32_t)i < n_frames) acc_lds[i * 64 + lane] = acc_lds[i * 64 + lane] + plane[frame0 + (uint32_t)i];
+        return;
+    }
+    if (path == PATH_SINE || path == PATH_CONST) {
+        // sine.rs:34-40 inside the spatial chunk loop; Constant (constant.rs:16-18)
+        const bool is_sine = path == PATH_SINE;
+        float ph = ep.phase_ear;
+        if (is_sine) for (uint32_t cc = 0; cc < c_abs; ++cc) ph = fmodf(ph + (dt * 256.0f) * s.freq_or_value, ODDIO_TAU);
+#pragma unroll 1
+        for (int i = 0; i < 16; ++i) {
+            float v;
+            if (is_sine) {
+                const float t = dt * (float)(16 * b + i);
+                v = sinf(t * s.freq_or_value + ph);
+            } else {
+                v = s.freq_or_value;
+            }
+            v = v * fixed_gain;
+            const float p = v * (g0 + (fbase + (float)i) * dg);
+            if (frame0 + (uint32_t)i < n_frames) acc_lds[i * 64 + lane] = acc_lds[i * 64 + lane] + p;
+        }
+        return;
+    }
+    // PATH_GENERIC: frames.rs:176-201 per lane from global memory (also Downmix, downmix.rs:27-29)
+    const bool downmix = s.kind == KIND_DOWNMIX;
+    const float* clip = s.clip;
+    const uint32_t clip_len = s.clip_len;
+    double t_c = ep.t_ear;
     for (uint32_t cc = 0; cc < c_abs; ++cc) t_c = t_c + (double)dt * 256.0;
-    const double s0 = t_c * (double)clip_rate;
-    const float ds = dt * (float)clip_rate;
+    const double s0 = t_c * (double)s.clip_rate;
+    const float ds = dt * (float)s.clip_rate;
     const long long base = f64_as_isize(s0);
     const float frac0 = (float)(s0 - (double)base);
     const bool fast = fabsf(ds - 1.0f) <= FLT_EPSILON;
@@ -502,7 +555,7 @@ __device__ __noinline__ void mix_source_generic(float* acc_lds, int lane, float 
         if (fast) { idx = base + (long long)(16 * b + i); fr = frac0; }
         else { const long long tr = (long long)x; idx = base + tr; fr = x - (float)tr; }
         float v;
-        if (downmix) {   // downmix.rs:27-29: per-channel lerp of the stereo frame, then channels().sum()
+        if (downmix) {   // per-channel lerp of the stereo frame, then channels().sum()
             const bool in_a = idx >= 0 && idx < (long long)clip_len, in_b = idx + 1 >= 0 && idx + 1 < (long long)clip_len;
             const float2 fa = in_a ? reinterpret_cast<const float2*>(clip)[idx] : make_float2(0.0f, 0.0f);
             const float2 fb = in_b ? reinterpret_cast<const float2*>(clip)[idx + 1] : make_float2(0.0f, 0.0f);
@@ -521,34 +574,6 @@ __device__ __noinline__ void mix_source_generic(float* acc_lds, int lane, float 
     }
 }
 
-// sine.rs:34-40 inside the spatial chunk loop; Constant (constant.rs:16-18)
-__device__ __noinline__ void mix_source_analytic(float* acc_lds, int lane, float fbase, uint32_t frame0, uint32_t n_frames,
-                                                 uint32_t c_abs, int is_sine, float freq_or_value, float fixed_gain, float ph,
-                                                 float dt, float g0, float dg) {
-    const int b = lane & 15;
-    if (is_sine) for (uint32_t cc = 0; cc < c_abs; ++cc) ph = fmodf(ph + (dt * 256.0f) * freq_or_value, ODDIO_TAU);
-#pragma unroll 1
-    for (int i = 0; i < 16; ++i) {
-        float v;
-        if (is_sine) {
-            const float t = dt * (float)(16 * b + i);
-            v = sinf(t * freq_or_value + ph);
-        } else {
-            v = freq_or_value;
-        }
-        v = v * fixed_gain;
-        const float p = v * (g0 + (fbase + (float)i) * dg);
-        if (frame0 + (uint32_t)i < n_frames) acc_lds[i * 64 + lane] = acc_lds[i * 64 + lane] + p;
-    }
-}
-
-// Seek-set Cycle: the contribution was rendered by cycle_sources; add it at this source's position
-__device__ __noinline__ void mix_source_row(float* acc_lds, int lane, uint32_t frame0, uint32_t n_frames, const float* plane) {
-#pragma unroll 1
-    for (int i = 0; i < 16; ++i)
-        if (frame0 + (uint32_t)i < n_frames) acc_lds[i * 64 + lane] = acc_lds[i * 64 + lane] + plane[frame0 + (uint32_t)i];
-}
-
 // grid = (n_workgroups, n_tiles); block = 64 * MIX_WG_WAVES.  Wave w walks groups [g_lo, g_hi) of
 // 16 slots in DESCENDING order (the reference's reverse set walk, spatial.rs:204).  A workgroup
 // leaves ONE partial tile: partials[(tile * n_wgs + wg) * 1024 + e * 512 + f] (planar L | R).
@@ -564,6 +589,8 @@ __global__ __launch_bounds__(64 * MIX_WG_WAVES, MIX_WAVES_PER_SIMD) void spatial
     int* cinfo = reinterpret_cast<int*>(smem + LDS_CINFO);
     float4* epar = reinterpret_cast<float4*>(smem + LDS_EPAR);
     int* sinfo = reinterpret_cast<int*>(smem + LDS_SINFO);
+    // LDS byte address of this wave's slice (what the DMA's M0 wants): low half of the flat address
+    const uint32_t lds_slice = (uint32_t)(uintptr_t)smem;
     const int lane = threadIdx.x & 63;
     const uint32_t wave = blockIdx.x * MIX_WG_WAVES + wv, tile = blockIdx.y;
     const uint32_t n_frames = P.n_frames;
@@ -595,163 +622,164 @@ __global__ __launch_bounds__(64 * MIX_WG_WAVES, MIX_WAVES_PER_SIMD) void spatial
 
     for (uint32_t g = g_hi; g-- > g_lo;) {
         // ------------------------------ phase A ------------------------------
-        const uint32_t srcA = g * MIX_GROUP + (uint32_t)jA;
-        const bool validA = srcA < P.n_sources;
-        EarParams ep = {};
-        SrcStatic ss = {};
-        ep.flags = EAR_SKIP;
-        if (validA) { ep = ear[2 * srcA + eA]; ss = st[srcA]; }
-        const bool live = validA && !(ep.flags & EAR_SKIP);
-        int lo = 0x7fffffff, hi = (int)0x80000000;
-        int generic = 0, wbase = 0;
-        int fl = 0;                              // SFLAG_* contributed by this stream
-        float frac0 = 0.0f, ds = 0.0f;
-        if (live && ss.kind == KIND_DOWNMIX) generic = 1;
-        if (live && ss.kind == KIND_FRAMES) {
-            double t_c = ep.t_ear;
-            for (uint32_t cc = 0; cc < cA_abs; ++cc) t_c = t_c + (double)ep.dt * 256.0;   // frames.rs:198 per chunk
-            const double s0 = t_c * (double)ss.clip_rate;                                 // frames.rs:177
-            ds = ep.dt * (float)ss.clip_rate;                                             // :178
-            const long long base = f64_as_isize(s0);                                      // :179
-            frac0 = (float)(s0 - (double)base);                                           // :181 / :189
-            const float dev = fabsf(ds - 1.0f);
-            if (dev <= FLT_EPSILON) fl |= eA ? SFLAG_FAST_R : SFLAG_FAST_L;               // :180
-            if (dev < PAD_EPS) fl |= SFLAG_PAD;
-            // the staged path needs a forward-running, sane cursor; everything else is exact but slow
-            if (!(fabs(s0) < 1.0e9) || !(ds > 0.0f) || !(ds < 4096.0f)) generic = 1;
-            if (frac0 < 0.0f) fl |= SFLAG_NEG;
-            wbase = (int)base;
-        }
-        const bool fastA = (fl & (SFLAG_FAST_L | SFLAG_FAST_R)) != 0;
-        // exact f32 cursor scan (frames.rs:189-196); checkpoints every 16 frames, xor-swizzled so
-        // that both this (lane-strided) write and phase B's read are bank-conflict free
-        float x = frac0;
         {
-            float* ck = &ckpt[lane * 16];
-            const int sw = lane & 15;
+            const uint32_t srcA = g * MIX_GROUP + (uint32_t)jA;
+            const bool validA = srcA < P.n_sources;
+            EarParams ep = {};
+            SrcStatic ss = {};
+            ep.flags = EAR_SKIP;
+            if (validA) { ep = ear[2 * srcA + eA]; ss = st[srcA]; }
+            const bool live = validA && !(ep.flags & EAR_SKIP);
+            int lo = 0x7fffffff, hi = (int)0x80000000;
+            int generic = 0, wbase = 0;
+            int fl = 0;                              // SFLAG_* contributed by this stream
+            float frac0 = 0.0f, ds = 0.0f;
+            if (live && ss.kind == KIND_DOWNMIX) generic = 1;
+            if (live && ss.kind == KIND_FRAMES) {
+                double t_c = ep.t_ear;
+                for (uint32_t cc = 0; cc < cA_abs; ++cc) t_c = t_c + (double)ep.dt * 256.0;   // frames.rs:198 per chunk
+                const double s0 = t_c * (double)ss.clip_rate;                                 // frames.rs:177
+                ds = ep.dt * (float)ss.clip_rate;                                             // :178
+                const long long base = f64_as_isize(s0);                                      // :179
+                frac0 = (float)(s0 - (double)base);                                           // :181 / :189
+                const float dev = fabsf(ds - 1.0f);
+                if (dev <= FLT_EPSILON) fl |= eA ? SFLAG_FAST_R : SFLAG_FAST_L;               // :180
+                if (dev < PAD_EPS) fl |= SFLAG_PAD;
+                // the staged path needs a forward-running, sane cursor; everything else is exact but slow
+                if (!(fabs(s0) < 1.0e9) || !(ds > 0.0f) || !(ds < 4096.0f)) generic = 1;
+                if (frac0 < 0.0f) fl |= SFLAG_NEG;
+                wbase = (int)base;
+            }
+            const bool fastA = (fl & (SFLAG_FAST_L | SFLAG_FAST_R)) != 0;
+            // exact f32 cursor scan (frames.rs:189-196); checkpoints every 16 frames, xor-swizzled so
+            // that both this (lane-strided) write and phase B's read are bank-conflict free
+            float x = frac0;
+            {
+                float* ck = &ckpt[lane * 16];
+                const int sw = lane & 15;
 #pragma unroll 1
-            for (int b = 0; b < 15; ++b) {
-                ck[b ^ sw] = x;
+                for (int b = 0; b < 15; ++b) {
+                    ck[b ^ sw] = x;
 #pragma unroll
-                for (int i = 0; i < 16; ++i) x = x + ds;
+                    for (int i = 0; i < 16; ++i) x = x + ds;
+                }
+                ck[15 ^ sw] = x;
+#pragma unroll
+                for (int i = 0; i < 15; ++i) x = x + ds;   // x == offset at frame 255 of the chunk
             }
-            ck[15 ^ sw] = x;
-#pragma unroll
-            for (int i = 0; i < 15; ++i) x = x + ds;   // x == offset at frame 255 of the chunk
-        }
-        if (live && ss.kind == KIND_FRAMES && lenA > 0 && !generic) {
-            int i0, i1;
-            if (fastA) { i0 = wbase; i1 = wbase + 255; }
-            else {
-                if (!(x < 8.0e6f)) generic = 1;
-                i0 = wbase + (int)frac0;
-                i1 = wbase + (int)x;
+            if (live && ss.kind == KIND_FRAMES && lenA > 0 && !generic) {
+                int i0, i1;
+                if (fastA) { i0 = wbase; i1 = wbase + 255; }
+                else {
+                    if (!(x < 8.0e6f)) generic = 1;
+                    i0 = wbase + (int)frac0;
+                    i1 = wbase + (int)x;
+                }
+                lo = i0 < i1 ? i0 : i1;
+                hi = i0 < i1 ? i1 : i0;
             }
-            lo = i0 < i1 ? i0 : i1;
-            hi = i0 < i1 ? i1 : i0;
-        }
-        // per-source (4 lanes) reduction of window bounds and flags
+            // per-source (4 lanes) reduction of window bounds and flags
 #pragma unroll
-        for (int m = 1; m < 4; m <<= 1) {
-            const int olo = __shfl_xor(lo, m), ohi = __shfl_xor(hi, m), og = __shfl_xor(generic, m), of = __shfl_xor(fl, m);
-            lo = olo < lo ? olo : lo;
-            hi = ohi > hi ? ohi : hi;
-            generic |= og;
-            fl |= of;
-        }
-        const int ws = lo & ~3;
-        const int count = hi + 2 - ws;
-        int path = PATH_SKIP;
-        if (live) {
-            if (ss.kind == KIND_SINE) path = PATH_SINE;
-            else if (ss.kind == KIND_CONSTANT) path = PATH_CONST;
-            else if (ss.kind == KIND_CYCLE) path = PATH_ROW;
-            else if (generic) path = PATH_GENERIC;
-            else if (lo > hi) path = PATH_SKIP;      // no frames in this tile
-            else path = (count <= WIN_CAP) ? PATH_LDS : PATH_GENERIC;
-        }
-        cinfo[lane * 2 + 0] = wbase - ws;
-        cinfo[lane * 2 + 1] = __float_as_int(frac0);
-        if (cA == 0) epar[jA * 2 + eA] = make_float4(ep.g0, ep.dg, ds, ss.fixed_gain);
-        if ((lane & 3) == 0) {
-            sinfo[jA * 4 + 0] = ws;
-            sinfo[jA * 4 + 1] = count;
-            sinfo[jA * 4 + 2] = path;
-            sinfo[jA * 4 + 3] = fl;
+            for (int m = 1; m < 4; m <<= 1) {
+                const int olo = __shfl_xor(lo, m), ohi = __shfl_xor(hi, m), og = __shfl_xor(generic, m), of = __shfl_xor(fl, m);
+                lo = olo < lo ? olo : lo;
+                hi = ohi > hi ? ohi : hi;
+                generic |= og;
+                fl |= of;
+            }
+            const int ws = lo & ~3;
+            const int count = hi + 2 - ws;
+            int path = PATH_SKIP;
+            if (live) {
+                if (ss.kind == KIND_SINE) path = PATH_SINE;
+                else if (ss.kind == KIND_CONSTANT) path = PATH_CONST;
+                else if (ss.kind == KIND_CYCLE) path = PATH_ROW;
+                else if (generic) path = PATH_GENERIC;
+                else if (lo > hi) path = PATH_SKIP;      // no frames in this tile
+                else path = (count <= WIN_CAP) ? PATH_LDS : PATH_GENERIC;
+            }
+            cinfo[lane] = wbase - ws;
+            if (cA == 0) epar[jA * 2 + eA] = make_float4(ep.g0, ep.dg, ds, 0.0f);
+            if ((lane & 3) == 0) {
+                const uint64_t cp = (uint64_t)ss.clip;
+                int4* si = reinterpret_cast<int4*>(sinfo + jA * 8);
+                si[0] = make_int4(ws, count, path, fl);
+                si[1] = make_int4((int)(cp & 0xffffffffu), (int)(cp >> 32), (int)((ss.clip_len + 3u) & ~3u), __float_as_int(ss.fixed_gain));
+            }
         }
         wave_sync();
 
         // ------------------------------ phase B ------------------------------
-        // bit 4*j of lds_mask: source j of the group takes the staged-window path
-        const unsigned long long lds_mask = __ballot(path == PATH_LDS && (lane & 3) == 0);
-        u32x4 pre[WIN_VECS];
+        // bit j of lds_mask: source j of the group takes the staged-window path
+        unsigned lds_mask = 0;
         {
-            const int jn = lds_mask ? (63 - __builtin_clzll(lds_mask)) >> 2 : -1;
-            if (jn >= 0) {
-                const int ws_n = __builtin_amdgcn_readfirstlane(sinfo[jn * 4 + 0]);
-                const int cnt_n = __builtin_amdgcn_readfirstlane(sinfo[jn * 4 + 1]);
-                window_load(pre, rl_ptr(ss.clip, jn * 4), (rl_i((int)ss.clip_len, jn * 4) + 3) & ~3, ws_n, (cnt_n + 3) >> 2, lane);
-            }
+            const int pj = lane < MIX_GROUP ? sinfo[lane * 8 + 2] : PATH_SKIP;
+            lds_mask = (unsigned)__ballot(pj == PATH_LDS);
         }
+        int buf = 0;
+        // the window of staged source `pending` is in flight to / sits in WIN[buf]
+        int pending = lds_mask ? 31 - __builtin_clz(lds_mask) : -1;
+#define ODDIO_ISSUE_WINDOW(JN, BUF)                                                                                       \
+    {                                                                                                                     \
+        const int4 s0_ = *reinterpret_cast<const int4*>(sinfo + (JN) * 8), s1_ = *reinterpret_cast<const int4*>(sinfo + (JN) * 8 + 4); \
+        const int ws_n = __builtin_amdgcn_readfirstlane(s0_.x), cnt_n = __builtin_amdgcn_readfirstlane(s0_.y);            \
+        const uint64_t cp_ = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane(s1_.y) << 32) | (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane(s1_.x); \
+        window_dma(lds_slice + (uint32_t)((BUF) ? LDS_WIN1 : LDS_WIN0), reinterpret_cast<const float*>(cp_),              \
+                   __builtin_amdgcn_readfirstlane(s1_.z), ws_n, (cnt_n + 3) >> 2, lane);                                  \
+    }
+        if (pending >= 0) ODDIO_ISSUE_WINDOW(pending, buf)
 #pragma unroll 1
         for (int j = MIX_GROUP - 1; j >= 0; --j) {
-            const int path_j = __builtin_amdgcn_readfirstlane(sinfo[j * 4 + 2]);
+            const int4 sj = *reinterpret_cast<const int4*>(sinfo + j * 8);
+            const int path_j = __builtin_amdgcn_readfirstlane(sj.z);
             if (path_j == PATH_SKIP) continue;
-            const float4 pe = epar[j * 2 + eB];           // this lane's ear: {g0, dg, ds, fixed_gain}
-            const int la = j * 4 + eB * 2 + cB;           // (source, ear, chunk) stream of this lane
             if (path_j == PATH_LDS) {
-                const int count_j = __builtin_amdgcn_readfirstlane(sinfo[j * 4 + 1]);
-                const int flags_j = __builtin_amdgcn_readfirstlane(sinfo[j * 4 + 3]);
+                const int count_j = __builtin_amdgcn_readfirstlane(sj.y);
+                const int flags_j = __builtin_amdgcn_readfirstlane(sj.w);
+                const float fg = __int_as_float(__builtin_amdgcn_readfirstlane(sinfo[j * 8 + 7]));
+                const float4 pe = epar[j * 2 + eB];           // this lane's ear: {g0, dg, ds, -}
+                const int la = j * 4 + eB * 2 + cB;           // (source, ear, chunk) stream of this lane
+                const int wrel = cinfo[la];
+                const float x0 = ckpt[la * 16 + (bB ^ (la & 15))];
+                const float frac0 = ckpt[la * 16 + (la & 15)];            // checkpoint 0: the chunk's start offset
+                unsigned char* win_bytes = smem + (buf ? LDS_WIN1 : LDS_WIN0);
+                window_wait();                                // this source's window has landed
+                {   // start the next staged source of this group; lands while we compute
+                    const unsigned below = lds_mask & ((1u << j) - 1u);
+                    pending = below ? 31 - __builtin_clz(below) : -1;
+                    if (pending >= 0) ODDIO_ISSUE_WINDOW(pending, buf ^ 1)
+                }
                 const bool pad_j = (flags_j & SFLAG_PAD) != 0;
-                wave_sync();   // previous source's readers are done with the window
-                if (pad_j) window_store_padded(smem, pre, (count_j + 3) >> 2, lane);
-                else window_store_plain(smem, pre, (count_j + 3) >> 2, lane);
-                wave_sync();
-                {   // prefetch the next staged source of this group; lands while we compute
-                    const unsigned long long below = lds_mask & ((1ull << (4 * j)) - 1ull);
-                    if (below) {
-                        const int jn = (63 - __builtin_clzll(below)) >> 2;
-                        const int ws_n = __builtin_amdgcn_readfirstlane(sinfo[jn * 4 + 0]);
-                        const int cnt_n = __builtin_amdgcn_readfirstlane(sinfo[jn * 4 + 1]);
-                        window_load(pre, rl_ptr(ss.clip, jn * 4), (rl_i((int)ss.clip_len, jn * 4) + 3) & ~3, ws_n, (cnt_n + 3) >> 2, lane);
-                    }
-                }
+                if (pad_j) window_repack_padded(win_bytes, (count_j + 3) >> 2, lane);
+                const float* win = reinterpret_cast<const float*>(win_bytes);
                 const int fast_e = eB ? (flags_j & SFLAG_FAST_R) : (flags_j & SFLAG_FAST_L);
-                const bool plain_math = pe.w == 1.0f && !(flags_j & SFLAG_NEG);   // wave-uniform: fixed_gain is per source
+                const bool plain_math = fg == 1.0f && !(flags_j & SFLAG_NEG);   // wave-uniform
                 if (pad_j) {
-                    mix_source_lds<FULL, true, false, true>(smem, la, bB, fast_e, acc, fi, frame0, n_frames, pe.w, pe.x, pe.y, pe.z);
-                } else if (__builtin_amdgcn_readfirstlane((int)plain_math)) {
-                    mix_source_lds<FULL, false, true, false>(smem, la, bB, 0, acc, fi, frame0, n_frames, pe.w, pe.x, pe.y, pe.z);
+                    mix_source_lds<FULL, true, false, true>(win, wrel, x0, bB, fast_e, frac0, acc, fi, frame0, n_frames, fg, pe.x, pe.y, pe.z);
+                } else if (plain_math) {
+                    mix_source_lds<FULL, false, true, false>(win, wrel, x0, bB, 0, frac0, acc, fi, frame0, n_frames, fg, pe.x, pe.y, pe.z);
                 } else {
-                    mix_source_lds<FULL, true, false, false>(smem, la, bB, 0, acc, fi, frame0, n_frames, pe.w, pe.x, pe.y, pe.z);
+                    mix_source_lds<FULL, true, false, false>(win, wrel, x0, bB, 0, frac0, acc, fi, frame0, n_frames, fg, pe.x, pe.y, pe.z);
                 }
+                buf ^= 1;
             } else {
-                // rare path: park the accumulators in LDS, run out of line, fetch them back
+                // rare path: park the accumulators in LDS (over the window buffers: a window in flight is
+                // awaited first and fetched again afterwards), run out of line, fetch them back
                 float* park = reinterpret_cast<float*>(smem);
-                const int laL = j * 4, laR = j * 4 + 2;   // phase-A lanes holding this source's ears
-                const float dt = eB ? rl_f(ep.dt, laR) : rl_f(ep.dt, laL);
+                window_wait();
                 wave_sync();
 #pragma unroll
                 for (int k = 0; k < 16; ++k) park[k * 64 + lane] = acc[k];
                 wave_sync();
-                if (path_j == PATH_GENERIC) {
-                    const double t_ear = eB ? rl_d(ep.t_ear, laR) : rl_d(ep.t_ear, laL);
-                    mix_source_generic(park, lane, fbase, frame0, n_frames, cB_abs, rl_ptr(ss.clip, laL), (uint32_t)rl_i((int)ss.clip_len, laL),
-                                       (uint32_t)rl_i((int)ss.clip_rate, laL), pe.w, t_ear, dt, pe.x, pe.y,
-                                       rl_i((int)ss.kind, laL) == (int)KIND_DOWNMIX);
-                } else if (path_j == PATH_ROW) {
-                    const uint32_t row = (uint32_t)rl_i(__float_as_int(ss.freq_or_value), laL);
-                    mix_source_row(park, lane, frame0, n_frames, P.cycle_rows + ((size_t)row * 2u + (uint32_t)eB) * P.cycle_plane);
-                } else {
-                    const float ph = eB ? rl_f(ep.phase_ear, laR) : rl_f(ep.phase_ear, laL);
-                    mix_source_analytic(park, lane, fbase, frame0, n_frames, cB_abs, path_j == PATH_SINE ? 1 : 0, rl_f(ss.freq_or_value, laL), pe.w,
-                                        ph, dt, pe.x, pe.y);
-                }
+                mix_source_rare(park, lane, frame0, n_frames, cB_abs, path_j, st, ear, g * MIX_GROUP + (uint32_t)j, P.cycle_rows, P.cycle_plane);
                 wave_sync();
 #pragma unroll
                 for (int k = 0; k < 16; ++k) acc[k] = park[k * 64 + lane];
+                wave_sync();
+                if (pending >= 0) ODDIO_ISSUE_WINDOW(pending, buf)
             }
         }
+#undef ODDIO_ISSUE_WINDOW
         wave_sync();   // before the next group's phase A overwrites ckpt/cinfo
     }
 

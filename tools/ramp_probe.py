@@ -52,6 +52,35 @@ def main():
         print(f"{label:44s} wall/cb {wall:.3f} ms | mix us per 10 launches: {pts}", flush=True)
         scene.set_profiling(False)
 
+    def pre(label, fn, seconds=0.25):
+        torch.cuda.synchronize()
+        time.sleep(1.0)
+        t0 = time.perf_counter()
+        k = 0
+        while time.perf_counter() - t0 < seconds:
+            fn()
+            k += 1
+            if k % 4 == 0:
+                torch.cuda.synchronize()
+        run(40, f"{label} (+{k})")
+
+    run(args.n, "A right after scene set-up (GPU synth)")
+    time.sleep(1.0)
+    run(60, "B after 1 s idle")
+    big = torch.empty((1 << 28,), dtype=torch.float32, device="cuda")   # 1 GiB
+    big2 = torch.empty_like(big)
+    a16 = torch.randn((8192, 8192), device="cuda", dtype=torch.bfloat16)
+    a32 = torch.randn((8192, 8192), device="cuda", dtype=torch.float32)
+    d64 = torch.rand((1 << 24,), device="cuda", dtype=torch.float64)
+    pre("C 0.25 s of 1 GiB copies", lambda: big2.copy_(big))
+    pre("D 0.25 s of bf16 matmuls", lambda: a16 @ a16)
+    pre("E 0.25 s of f32 matmuls", lambda: a32 @ a32)
+    pre("F 0.25 s of f64 sin", lambda: torch.sin(d64))
+    pre("G 0.25 s of f32 sin on 1 GiB", lambda: torch.sin(big))
+    pre("H 0.05 s of bf16 matmuls", lambda: a16 @ a16, 0.05)
+    pre("I 1.0 s of bf16 matmuls", lambda: a16 @ a16, 1.0)
+    return
+
     run(args.n, "A right after scene set-up (GPU synth)")
     time.sleep(1.0)
     run(args.n, "B after 1 s idle")
