@@ -345,7 +345,7 @@ enum : int { PATH_SKIP = 0, PATH_LDS = 1, PATH_GENERIC = 2, PATH_SINE = 3, PATH_
 //         start offset frac0)
 //   CINFO per phase-A lane: window-relative base index
 //   EPAR  per (source, ear) {g0, dg, ds, -}
-//   SINFO per source {ws, count, path, flags, clip lo, clip hi, clip_len4, fixed_gain}
+//   SINFO per source {path, flags, nvec, fixed_gain} {window descriptor: word 0, word 1, bytes, start offset}
 constexpr int LDS_WIN0 = 0;
 constexpr int WIN_BYTES = WIN_CAP * 4;
 constexpr int LDS_WIN1 = LDS_WIN0 + WIN_BYTES;
@@ -377,13 +377,14 @@ __device__ __forceinline__ int rl_i(int v, int lane) { return __builtin_amdgcn_r
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 // HBM -> LDS: samples [ws, ws + 4*nvec) of a clip into the window buffer at LDS byte address
-// `lds_dst`, 16 B per lane per piece, through a buffer descriptor clipped to [window, clip end):
-// lanes outside it get zeros with no memory traffic (frames.rs:105-123).  The loads are issued from
-// inline asm on purpose: hipcc would make every later ds_read wait for ALL outstanding LDS-DMA
+// `lds_dst`, 16 B per lane per 1 KiB piece, through a buffer descriptor clipped to [window, clip
+// end): lanes outside it get zeros with no memory traffic (frames.rs:105-123).  The loads are issued
+// from inline asm on purpose: hipcc would make every later ds_read wait for ALL outstanding LDS-DMA
 // (it cannot tell the two window buffers apart), which would serialise the prefetch of the next
 // source with the reads of the current one.  Completion is awaited with window_wait().
-// All descriptor inputs are wave-uniform scalars.
-__device__ __forceinline__ void window_dma(uint32_t lds_dst, const float* clip, int clip_len4, int ws, int nvec, int lane) {
+// `desc` = {descriptor word 0, word 1, byte count, byte offset of the window start relative to the
+// descriptor base (<= 0)}, made by window_desc() in phase A; wave-uniform.
+__device__ __forceinline__ int4 window_desc(const float* clip, int clip_len4, int ws, int nvec) {
     const int ws_pos = ws > 0 ? ws : 0;             // first in-clip sample of the window
     const int neg4 = (ws < 0 ? ws : 0) * 4;         // byte offset of the window start relative to it (<= 0)
     long long rec = (long long)(clip_len4 - ws_pos) * 4;          // bytes to the (padded) clip end
@@ -391,23 +392,28 @@ __device__ __forceinline__ void window_dma(uint32_t lds_dst, const float* clip, 
     if (rec > wend) rec = wend;
     if (rec < 0) rec = 0;
     const uint64_t base = (uint64_t)(clip + ws_pos);
+    return make_int4((int)(base & 0xffffffffu), (int)((base >> 32) & 0xffffu), (int)rec, neg4);   // stride 0
+}
+constexpr int WIN_LAST_LANES = (WIN_BYTES - 2048) / 16;   // lanes of the third piece that stay inside the window buffer
+__device__ __forceinline__ void window_dma(uint32_t lds_dst, int4 desc, int nvec, int lane) {
     u32x4 rsrc;
-    rsrc.x = (uint32_t)__builtin_amdgcn_readfirstlane((int)(base & 0xffffffffu));
-    rsrc.y = (uint32_t)__builtin_amdgcn_readfirstlane((int)((base >> 32) & 0xffffu));   // stride 0
-    rsrc.z = (uint32_t)__builtin_amdgcn_readfirstlane((int)rec);
+    rsrc.x = (uint32_t)__builtin_amdgcn_readfirstlane(desc.x);
+    rsrc.y = (uint32_t)__builtin_amdgcn_readfirstlane(desc.y);
+    rsrc.z = (uint32_t)__builtin_amdgcn_readfirstlane(desc.z);
     rsrc.w = 0x00020000u;
     const uint32_t dst = (uint32_t)__builtin_amdgcn_readfirstlane((int)lds_dst);
-    const int voff = neg4 + 16 * lane;              // negative offsets wrap to huge unsigned values: out of range -> 0
+    const int voff = __builtin_amdgcn_readfirstlane(desc.w) + 16 * lane;   // negative offsets wrap to huge unsigned values: out of range -> 0
     uint32_t keep;
-#define ODDIO_DMA_PIECE(K)                                                                                                   \
-    if (K < WIN_PIECES && lane + 64 * K < nvec)                                                                              \
-        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 4\n\tbuffer_load_dwordx4 %1, %2, 0 offen offset:%4 lds\n\ts_mov_b32 m0, %0" \
-                     : "=&s"(keep) : "v"(voff), "s"(rsrc), "s"(dst), "i"(1024 * K) : "memory");
-    ODDIO_DMA_PIECE(0)
-    ODDIO_DMA_PIECE(1)
-    ODDIO_DMA_PIECE(2)
-#undef ODDIO_DMA_PIECE
-    static_assert(WIN_PIECES <= 3, "add pieces");
+    // pieces 0 and 1 from every lane: lanes past the window write zeros inside the buffer (harmless, no traffic)
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 4\n\t"
+                 "buffer_load_dwordx4 %1, %2, 0 offen lds\n\tbuffer_load_dwordx4 %1, %2, 0 offen offset:1024 lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(rsrc), "s"(dst) : "memory");
+    if (nvec > 128) {
+        if (lane < WIN_LAST_LANES)
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen offset:2048 lds\n\ts_mov_b32 m0, %0"
+                         : "=&s"(keep) : "v"(voff), "s"(rsrc), "s"(dst) : "memory");
+    }
+    static_assert(WIN_PIECES == 3 && WIN_LAST_LANES > 0 && WIN_LAST_LANES <= 64, "three pieces cover a window buffer");
 }
 __device__ __forceinline__ void window_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
@@ -701,84 +707,96 @@ __global__ __launch_bounds__(64 * MIX_WG_WAVES, MIX_WAVES_PER_SIMD) void spatial
             cinfo[lane] = wbase - ws;
             if (cA == 0) epar[jA * 2 + eA] = make_float4(ep.g0, ep.dg, ds, 0.0f);
             if ((lane & 3) == 0) {
-                const uint64_t cp = (uint64_t)ss.clip;
+                const int nvec = (count + 3) >> 2;
                 int4* si = reinterpret_cast<int4*>(sinfo + jA * 8);
-                si[0] = make_int4(ws, count, path, fl);
-                si[1] = make_int4((int)(cp & 0xffffffffu), (int)(cp >> 32), (int)((ss.clip_len + 3u) & ~3u), __float_as_int(ss.fixed_gain));
+                si[0] = make_int4(path, fl, nvec, __float_as_int(ss.fixed_gain));
+                si[1] = window_desc(ss.clip, (int)((ss.clip_len + 3u) & ~3u), ws, nvec);
             }
         }
         wave_sync();
 
         // ------------------------------ phase B ------------------------------
-        // bit j of lds_mask: source j of the group takes the staged-window path
-        unsigned lds_mask = 0;
+        // bit j of lds_mask: source j of the group takes the staged-window path; rare_mask: an out-of-line path
+        unsigned lds_mask, rare_mask;
         {
-            const int pj = lane < MIX_GROUP ? sinfo[lane * 8 + 2] : PATH_SKIP;
+            const int pj = lane < MIX_GROUP ? sinfo[lane * 8 + 0] : PATH_SKIP;
             lds_mask = (unsigned)__ballot(pj == PATH_LDS);
+            rare_mask = (unsigned)__ballot(pj != PATH_LDS && pj != PATH_SKIP);
         }
         int buf = 0;
         // the window of staged source `pending` is in flight to / sits in WIN[buf]
         int pending = lds_mask ? 31 - __builtin_clz(lds_mask) : -1;
 #define ODDIO_ISSUE_WINDOW(JN, BUF)                                                                                       \
     {                                                                                                                     \
-        const int4 s0_ = *reinterpret_cast<const int4*>(sinfo + (JN) * 8), s1_ = *reinterpret_cast<const int4*>(sinfo + (JN) * 8 + 4); \
-        const int ws_n = __builtin_amdgcn_readfirstlane(s0_.x), cnt_n = __builtin_amdgcn_readfirstlane(s0_.y);            \
-        const uint64_t cp_ = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane(s1_.y) << 32) | (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane(s1_.x); \
-        window_dma(lds_slice + (uint32_t)((BUF) ? LDS_WIN1 : LDS_WIN0), reinterpret_cast<const float*>(cp_),              \
-                   __builtin_amdgcn_readfirstlane(s1_.z), ws_n, (cnt_n + 3) >> 2, lane);                                  \
+        const int nv_ = __builtin_amdgcn_readfirstlane(sinfo[(JN) * 8 + 2]);                                              \
+        window_dma(lds_slice + (uint32_t)((BUF) ? LDS_WIN1 : LDS_WIN0), *reinterpret_cast<const int4*>(sinfo + (JN) * 8 + 4), nv_, lane); \
+    }
+        // one staged source: wait for its window, start the next one's, mix
+#define ODDIO_STAGED_SOURCE(J, SJ)                                                                                        \
+    {                                                                                                                     \
+        const int flags_j = __builtin_amdgcn_readfirstlane((SJ).y);                                                       \
+        const float fg = __int_as_float(__builtin_amdgcn_readfirstlane((SJ).w));                                          \
+        const float4 pe = epar[(J) * 2 + eB];             /* this lane's ear: {g0, dg, ds, -} */                          \
+        const int la = (J) * 4 + eB * 2 + cB;             /* (source, ear, chunk) stream of this lane */                  \
+        const int wrel = cinfo[la];                                                                                       \
+        const float x0 = ckpt[la * 16 + (bB ^ (la & 15))];                                                                \
+        unsigned char* win_bytes = smem + (buf ? LDS_WIN1 : LDS_WIN0);                                                    \
+        window_wait();                                    /* this source's window has landed */                          \
+        {   /* start the next staged source of this group; lands while we compute */                                     \
+            const unsigned below = lds_mask & ((1u << (J)) - 1u);                                                         \
+            pending = below ? 31 - __builtin_clz(below) : -1;                                                             \
+            if (pending >= 0) ODDIO_ISSUE_WINDOW(pending, buf ^ 1)                                                        \
+        }                                                                                                                 \
+        const float* win = reinterpret_cast<const float*>(win_bytes);                                                     \
+        if (flags_j & SFLAG_PAD) {                                                                                        \
+            const float frac0 = ckpt[la * 16 + (la & 15)];   /* checkpoint 0: the chunk's start offset */                 \
+            const int fast_e = eB ? (flags_j & SFLAG_FAST_R) : (flags_j & SFLAG_FAST_L);                                  \
+            window_repack_padded(win_bytes, __builtin_amdgcn_readfirstlane((SJ).z), lane);                                \
+            mix_source_lds<FULL, true, false, true>(win, wrel, x0, bB, fast_e, frac0, acc, fi, frame0, n_frames, fg, pe.x, pe.y, pe.z); \
+        } else if (fg == 1.0f && !(flags_j & SFLAG_NEG)) {   /* wave-uniform */                                           \
+            mix_source_lds<FULL, false, true, false>(win, wrel, x0, bB, 0, 0.0f, acc, fi, frame0, n_frames, fg, pe.x, pe.y, pe.z); \
+        } else {                                                                                                          \
+            mix_source_lds<FULL, true, false, false>(win, wrel, x0, bB, 0, 0.0f, acc, fi, frame0, n_frames, fg, pe.x, pe.y, pe.z); \
+        }                                                                                                                 \
+        buf ^= 1;                                                                                                         \
     }
         if (pending >= 0) ODDIO_ISSUE_WINDOW(pending, buf)
+        if (rare_mask == 0) {
+            // the common group: staged sources only (kept apart so that the out-of-line paths' register
+            // shuffling stays out of this loop)
 #pragma unroll 1
-        for (int j = MIX_GROUP - 1; j >= 0; --j) {
-            const int4 sj = *reinterpret_cast<const int4*>(sinfo + j * 8);
-            const int path_j = __builtin_amdgcn_readfirstlane(sj.z);
-            if (path_j == PATH_SKIP) continue;
-            if (path_j == PATH_LDS) {
-                const int count_j = __builtin_amdgcn_readfirstlane(sj.y);
-                const int flags_j = __builtin_amdgcn_readfirstlane(sj.w);
-                const float fg = __int_as_float(__builtin_amdgcn_readfirstlane(sinfo[j * 8 + 7]));
-                const float4 pe = epar[j * 2 + eB];           // this lane's ear: {g0, dg, ds, -}
-                const int la = j * 4 + eB * 2 + cB;           // (source, ear, chunk) stream of this lane
-                const int wrel = cinfo[la];
-                const float x0 = ckpt[la * 16 + (bB ^ (la & 15))];
-                const float frac0 = ckpt[la * 16 + (la & 15)];            // checkpoint 0: the chunk's start offset
-                unsigned char* win_bytes = smem + (buf ? LDS_WIN1 : LDS_WIN0);
-                window_wait();                                // this source's window has landed
-                {   // start the next staged source of this group; lands while we compute
-                    const unsigned below = lds_mask & ((1u << j) - 1u);
-                    pending = below ? 31 - __builtin_clz(below) : -1;
-                    if (pending >= 0) ODDIO_ISSUE_WINDOW(pending, buf ^ 1)
-                }
-                const bool pad_j = (flags_j & SFLAG_PAD) != 0;
-                if (pad_j) window_repack_padded(win_bytes, (count_j + 3) >> 2, lane);
-                const float* win = reinterpret_cast<const float*>(win_bytes);
-                const int fast_e = eB ? (flags_j & SFLAG_FAST_R) : (flags_j & SFLAG_FAST_L);
-                const bool plain_math = fg == 1.0f && !(flags_j & SFLAG_NEG);   // wave-uniform
-                if (pad_j) {
-                    mix_source_lds<FULL, true, false, true>(win, wrel, x0, bB, fast_e, frac0, acc, fi, frame0, n_frames, fg, pe.x, pe.y, pe.z);
-                } else if (plain_math) {
-                    mix_source_lds<FULL, false, true, false>(win, wrel, x0, bB, 0, frac0, acc, fi, frame0, n_frames, fg, pe.x, pe.y, pe.z);
+            for (int j = MIX_GROUP - 1; j >= 0; --j) {
+                const int4 sj = *reinterpret_cast<const int4*>(sinfo + j * 8);
+                if (__builtin_amdgcn_readfirstlane(sj.x) != PATH_LDS) continue;
+                ODDIO_STAGED_SOURCE(j, sj)
+            }
+        } else {
+#pragma unroll 1
+            for (int j = MIX_GROUP - 1; j >= 0; --j) {
+                const int4 sj = *reinterpret_cast<const int4*>(sinfo + j * 8);
+                const int path_j = __builtin_amdgcn_readfirstlane(sj.x);
+                if (path_j == PATH_SKIP) continue;
+                if (path_j == PATH_LDS) {
+                    ODDIO_STAGED_SOURCE(j, sj)
                 } else {
-                    mix_source_lds<FULL, true, false, false>(win, wrel, x0, bB, 0, frac0, acc, fi, frame0, n_frames, fg, pe.x, pe.y, pe.z);
+                    // rare path: park the accumulators in LDS (over the window buffers: a window in flight is
+                    // awaited first and fetched again afterwards), run out of line, fetch them back
+                    float* park = reinterpret_cast<float*>(smem);
+                    window_wait();
+                    wave_sync();
+#pragma unroll
+                    for (int k = 0; k < 16; ++k) park[k * 64 + lane] = acc[k];
+                    wave_sync();
+                    mix_source_rare(park, lane, frame0, n_frames, cB_abs, path_j, st, ear, g * MIX_GROUP + (uint32_t)j, P.cycle_rows, P.cycle_plane);
+                    wave_sync();
+#pragma unroll
+                    for (int k = 0; k < 16; ++k) acc[k] = park[k * 64 + lane];
+                    wave_sync();
+                    if (pending >= 0) ODDIO_ISSUE_WINDOW(pending, buf)
                 }
-                buf ^= 1;
-            } else {
-                // rare path: park the accumulators in LDS (over the window buffers: a window in flight is
-                // awaited first and fetched again afterwards), run out of line, fetch them back
-                float* park = reinterpret_cast<float*>(smem);
-                window_wait();
-                wave_sync();
-#pragma unroll
-                for (int k = 0; k < 16; ++k) park[k * 64 + lane] = acc[k];
-                wave_sync();
-                mix_source_rare(park, lane, frame0, n_frames, cB_abs, path_j, st, ear, g * MIX_GROUP + (uint32_t)j, P.cycle_rows, P.cycle_plane);
-                wave_sync();
-#pragma unroll
-                for (int k = 0; k < 16; ++k) acc[k] = park[k * 64 + lane];
-                wave_sync();
-                if (pending >= 0) ODDIO_ISSUE_WINDOW(pending, buf)
             }
         }
+#undef ODDIO_STAGED_SOURCE
 #undef ODDIO_ISSUE_WINDOW
         wave_sync();   // before the next group's phase A overwrites ckpt/cinfo
     }
