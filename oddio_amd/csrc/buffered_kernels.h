@@ -208,13 +208,15 @@ struct alignas(16) FaderPending {
     BufStatic st; BufDyn dyn;
     float duration;
     uint32_t fresh;         // swap.rs FRESH_BIT
-    uint32_t pad[2];
+    uint32_t gen;           // host-side generation of this command (the source's original signal is generation 0)
+    uint32_t pad;
 };
 struct alignas(16) FaderRec {
     BufStatic next_st; BufDyn next_dyn;
     float progress;         // Fader::progress, 1.0 when no fade is running (fader.rs:21)
     float duration;         // Command::duration of `next`
-    uint32_t pad[2];
+    uint32_t cur_gen;       // generation of the signal playing as `inner`: every older command's signal is dead
+    uint32_t next_gen;      // generation of `next`
     FaderPending pend;
 };
 constexpr uint32_t FADER_BUF = 1024;   // fader.rs:51
@@ -238,6 +240,7 @@ __device__ void fader_sample(BufStatic& st, BufDyn& dyn, FaderRec& F, float* scr
     if (F.progress >= 1.0f) {
         if (F.pend.fresh) {                               // self.next.refresh()
             F.next_st = F.pend.st; F.next_dyn = F.pend.dyn; F.duration = F.pend.duration;
+            F.next_gen = F.pend.gen;
             F.pend.fresh = 0u;
             F.progress = 0.0f;
         } else {
@@ -272,6 +275,7 @@ __device__ void fader_sample(BufStatic& st, BufDyn& dyn, FaderRec& F, float* scr
         const BufDyn old_dyn = dyn;
         signal_assign(st, dyn, nst, ndyn);
         signal_assign(F.next_st, F.next_dyn, old_st, old_dyn);
+        const uint32_t g = F.cur_gen; F.cur_gen = F.next_gen; F.next_gen = g;
     } else {
         F.next_dyn = ndyn;
     }
@@ -279,13 +283,13 @@ __device__ void fader_sample(BufStatic& st, BufDyn& dyn, FaderRec& F, float* scr
 
 // One thread per buffered slot: walk_set (spatial.rs:191-265) + the buffered mix closure
 // (spatial.rs:402-431).  contrib is [slot][n_frames][2]; skip[slot] != 0 means "not mixed".
-__global__ __launch_bounds__(64) void buffered_sources(SceneParams P, uint32_t n_buffered, BufStatic* __restrict__ st,
+__global__ __launch_bounds__(64) void buffered_sources(SceneParams P, const uint32_t* __restrict__ d_len_b, BufStatic* __restrict__ st,
                                                        BufDyn* __restrict__ dyn, SrcPending* __restrict__ pend,
                                                        float* __restrict__ contrib, uint32_t* __restrict__ skip,
                                                        uint32_t* __restrict__ stopped_hdr, uint32_t stopped_cap,
                                                        FaderRec* __restrict__ faders, float* __restrict__ fader_scratch) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_buffered) return;
+    if (i >= d_len_b[0]) return;
     BufDyn d = dyn[i];
     BufStatic s = st[i];
     SrcDyn& c = d.common;
@@ -405,13 +409,13 @@ __global__ __launch_bounds__(64) void buffered_sources(SceneParams P, uint32_t n
 }
 
 // out_b[o] = ((0 + contrib[last]) + ... + contrib[0]) : the reference's reverse walk (spatial.rs:204)
-__global__ void buffered_reduce(const float* __restrict__ contrib, const uint32_t* __restrict__ skip, uint32_t n_buffered,
+__global__ void buffered_reduce(const float* __restrict__ contrib, const uint32_t* __restrict__ skip, const uint32_t* __restrict__ d_len_b,
                                 uint32_t n_frames, float* __restrict__ out_b) {
     const uint32_t o = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t n_out = 2 * n_frames;
     if (o >= n_out) return;
     float s = 0.0f;
-    for (uint32_t i = n_buffered; i-- > 0;) {
+    for (uint32_t i = d_len_b[0]; i-- > 0;) {
         if (skip[i]) continue;
         s = s + contrib[(size_t)i * n_out + o];
     }
@@ -430,6 +434,13 @@ __global__ void apply_buf_moves(const BufMove* __restrict__ mv, uint32_t n, BufS
     st[mv[i].dst] = st[mv[i].src];
     dyn[mv[i].dst] = dyn[mv[i].src];
     pend[mv[i].dst] = pend[mv[i].src];
+}
+
+// The generation each Fader is playing, for the control thread (pinned host memory): clips handed over by
+// older fade_to commands can be released (the reference drops a retired signal at the next fade_to).
+__global__ void publish_fader_gens(const FaderRec* __restrict__ faders, uint32_t n, uint32_t* __restrict__ host_gen) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) host_gen[i] = faders[i].cur_gen;
 }
 
 // out[o] = postfx(in[o])  (scenes that hold only buffered sources)

@@ -122,14 +122,19 @@ __device__ __forceinline__ long long f64_as_isize(double x) {
 // ---------------------------------------------------------------------------------------------
 // prepass: one thread per live slot
 // ---------------------------------------------------------------------------------------------
+// `d_len` is the device-resident set length (set_kernels.h); `st_copy` receives this callback's copy of
+// the static records, so that the mix kernel of the callback reads only per-callback buffers and the set
+// can be compacted / extended for the next callback while it runs.
 __global__ __launch_bounds__(256) void spatial_prepass(SceneParams P, const SrcStatic* __restrict__ st,
                                                        SrcDyn* __restrict__ dyn, SrcPending* __restrict__ pend,
-                                                       EarParams* __restrict__ ear, uint32_t* __restrict__ stopped_hdr,
-                                                       uint32_t stopped_cap, int check_pending) {
+                                                       EarParams* __restrict__ ear, SrcStatic* __restrict__ st_copy,
+                                                       uint32_t* __restrict__ stopped_hdr, uint32_t stopped_cap, int check_pending,
+                                                       const uint32_t* __restrict__ d_len) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= P.n_sources) return;
+    if (i >= d_len[0]) return;
     SrcDyn d = dyn[i];
     const SrcStatic s = st[i];
+    st_copy[i] = s;
     EarParams e0 = {}, e1 = {};
     if (d.flags & DYN_STOPPED) {  // removed earlier, compaction not applied yet: never mixed again
         e0.flags = EAR_SKIP; e1.flags = EAR_SKIP;
@@ -239,9 +244,9 @@ __device__ __forceinline__ double f64_rem_euclid(double a, double b) {   // core
 // at the source's place in the set walk, so ORDERED mode stays bit-exact.
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(64) void cycle_sources(SceneParams P, const SrcStatic* __restrict__ st, SrcDyn* __restrict__ dyn,
-                                                    const EarParams* __restrict__ ear) {
+                                                    const EarParams* __restrict__ ear, const uint32_t* __restrict__ d_len) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= P.n_sources) return;
+    if (i >= d_len[0]) return;
     const SrcStatic s = st[i];
     if (s.kind != KIND_CYCLE) return;
     const EarParams e0 = ear[2 * i], e1 = ear[2 * i + 1];
@@ -587,8 +592,10 @@ template <bool FULL>
 __global__ __launch_bounds__(64 * MIX_WG_WAVES, MIX_WAVES_PER_SIMD) void spatial_mix(SceneParams P, const SrcStatic* __restrict__ st,
                                                                                      const EarParams* __restrict__ ear,
                                                                                      float* __restrict__ partials, const float* __restrict__ init,
-                                                                                     uint32_t groups_per_wave, uint32_t n_groups) {
+                                                                                     uint32_t groups_per_wave, uint32_t n_groups,
+                                                                                     const uint32_t* __restrict__ n_sources_ptr) {
     __shared__ __attribute__((aligned(16))) unsigned char smem_all[LDS_TOTAL * MIX_WG_WAVES];
+    const uint32_t n_sources = *n_sources_ptr;   // the set length this callback's walk saw (n_groups is the host's upper bound)
     const int wv = threadIdx.x >> 6;
     unsigned char* smem = smem_all + LDS_TOTAL * wv;
     float* ckpt = reinterpret_cast<float*>(smem + LDS_CKPT);
@@ -630,7 +637,7 @@ __global__ __launch_bounds__(64 * MIX_WG_WAVES, MIX_WAVES_PER_SIMD) void spatial
         // ------------------------------ phase A ------------------------------
         {
             const uint32_t srcA = g * MIX_GROUP + (uint32_t)jA;
-            const bool validA = srcA < P.n_sources;
+            const bool validA = srcA < n_sources;
             EarParams ep = {};
             SrcStatic ss = {};
             ep.flags = EAR_SKIP;
@@ -876,24 +883,9 @@ __global__ __launch_bounds__(256) void reduce_stage1(const float* __restrict__ p
     }
 }
 
-// The callback's list of stopped sources goes straight into pinned host memory (no memcpy packet) and
-// the device counter is re-armed for the ring slot's next use (no memset packet).  One block.
-__device__ __forceinline__ void publish_stopped_block(uint32_t* __restrict__ dev_hdr, uint32_t* __restrict__ host_hdr, uint32_t cap) {
-    const uint32_t count = dev_hdr[0];
-    const uint32_t n = count < cap ? count : cap;
-    for (uint32_t k = threadIdx.x; k < n; k += blockDim.x) host_hdr[1 + k] = dev_hdr[1 + k];
-    __syncthreads();
-    if (threadIdx.x == 0) { host_hdr[0] = count; dev_hdr[0] = 0u; }
-}
-__global__ __launch_bounds__(256) void publish_stopped(uint32_t* __restrict__ dev_hdr, uint32_t* __restrict__ host_hdr, uint32_t cap) {
-    publish_stopped_block(dev_hdr, host_hdr, cap);
-}
-
 // stage 2: out[o] = stage1[0][o] + stage1[1][o] + ... (fixed order), then Reinhard / Tanh
 __global__ __launch_bounds__(256) void reduce_stage2(const float* __restrict__ stage1, float* __restrict__ out,
-                                                     uint32_t n_wgs, uint32_t n_frames, int postfx,
-                                                     uint32_t* __restrict__ stopped_dev, uint32_t* __restrict__ stopped_host, uint32_t stopped_cap) {
-    if (blockIdx.x == gridDim.x - 1) publish_stopped_block(stopped_dev, stopped_host, stopped_cap);   // after every producer of the list
+                                                     uint32_t n_wgs, uint32_t n_frames, int postfx) {
     const uint32_t o = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t n_out = 2 * n_frames;
     if (o >= n_out) return;
@@ -965,43 +957,6 @@ __global__ __launch_bounds__(256) void adapt_kernel(float* __restrict__ buf, uin
 __global__ void zero_kernel(float* __restrict__ buf, uint32_t n) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) buf[i] = 0.0f;
-}
-
-// ---------------------------------------------------------------------------------------------
-// control-plane helpers (device side of set.rs / swap.rs semantics)
-// ---------------------------------------------------------------------------------------------
-struct MotionUpdate { uint32_t slot; float pos[3]; float vel[3]; uint32_t discontinuity; };
-
-__global__ void apply_motion_updates(const MotionUpdate* __restrict__ up, uint32_t n, SrcPending* __restrict__ pend) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const MotionUpdate u = up[i];
-    SrcPending p;
-    p.pos[0] = u.pos[0]; p.pos[1] = u.pos[1]; p.pos[2] = u.pos[2];
-    p.vel[0] = u.vel[0]; p.vel[1] = u.vel[1]; p.vel[2] = u.vel[2];
-    p.flags = PEND_FRESH | (u.discontinuity ? PEND_DISCONTINUITY : 0u);
-    p.pad = 0;
-    pend[u.slot] = p;
-}
-
-// swap_remove moves (set.rs:183-188): dst <- src, all pairs independent (host resolves chains)
-struct SlotMove { uint32_t dst, src; };
-
-__global__ void apply_slot_moves(const SlotMove* __restrict__ mv, uint32_t n, SrcStatic* st, SrcDyn* dyn, SrcPending* pend) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const SlotMove m = mv[i];
-    st[m.dst] = st[m.src];
-    dyn[m.dst] = dyn[m.src];
-    pend[m.dst] = pend[m.src];
-}
-
-__global__ void seek_all_kernel(SrcDyn* __restrict__ dyn, const SrcStatic* __restrict__ st, uint32_t n, float seconds) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    if (st[i].kind == KIND_FRAMES || st[i].kind == KIND_DOWNMIX) dyn[i].t = dyn[i].t + (double)seconds;   // frames.rs:211-213
-    else if (st[i].kind == KIND_SINE) dyn[i].phase = fmodf(dyn[i].phase + seconds * st[i].freq_or_value, ODDIO_TAU);
-    else if (st[i].kind == KIND_CYCLE) dyn[i].t = f64_rem_euclid(dyn[i].t + (double)seconds * (double)st[i].clip_rate, (double)st[i].clip_len);
 }
 
 }  // namespace oddio_hip

@@ -1,0 +1,166 @@
+// set_kernels.h -- the reference's `Set` (src/set.rs) kept on the device.
+//
+// A scene's source tables are indexed by slot == position in the reference's `Set`.  All three
+// mutations happen in stream order on the GPU, so that the audio thread never waits for the device
+// and slot order is the reference's even when callbacks are enqueued back to back:
+//   insert_sources   set.update(): `push` the sources played since the last callback, in send order,
+//                    at the current end of the set (set.rs:141-168)
+//   compact_set      set.remove(i) == Vec::swap_remove for every source the walk stopped, in the walk's
+//                    descending slot order (spatial.rs:204,258-261; set.rs:183-188); publishes the
+//                    removed handle ids to a ring in pinned host memory (the reference returns the boxes
+//                    to the control thread through its `free` channel, set.rs:84-122) and the new length
+//   *_by_id          control traffic addresses sources by handle id; the slot is looked up here
+#pragma once
+#include "buffered_kernels.h"
+
+namespace oddio_hip {
+
+constexpr uint32_t SLOT_INVALID = 0xffffffffu;
+constexpr uint32_t SLOT_BUFFERED_BIT = 0x80000000u;   // slot_of_id: the source lives in the buffered set
+
+__device__ __forceinline__ SrcDyn& dyn_common(SrcDyn& d) { return d; }
+__device__ __forceinline__ SrcDyn& dyn_common(BufDyn& d) { return d.common; }
+
+// What the device tells the host about a scene, in pinned host memory (written with system-scope stores).
+struct SetPublish {
+    volatile uint64_t len_and_inserted[2];   // per set (0 seek, 1 buffered): live length | cumulative inserts << 32
+    volatile uint32_t removed_total;         // entries ever written to the removed-id ring
+    uint32_t pad;
+};
+
+template <class S, class D>
+__global__ void insert_sources(const S* __restrict__ src_st, const D* __restrict__ src_dyn, uint32_t k, S* __restrict__ st, D* __restrict__ dyn,
+                               SrcPending* __restrict__ pend, const uint32_t* __restrict__ d_len, uint32_t* __restrict__ slot_of_id,
+                               uint32_t set_bit) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= k) return;
+    const uint32_t slot = *d_len + i;
+    const S s = src_st[i];
+    D d = src_dyn[i];
+    st[slot] = s;
+    dyn[slot] = d;
+    SrcPending p = {};
+    pend[slot] = p;
+    slot_of_id[dyn_common(d).id] = slot | set_bit;
+}
+// after insert_sources: d_len[0] += k, d_len[1] (cumulative inserts) += k
+__global__ void bump_len(uint32_t* d_len, uint32_t k) { d_len[0] += k; d_len[1] += k; }
+
+// One wave.  stopped_hdr[0] = number of sources the walk stopped this callback, [1..] their handle ids
+// (first `cap`; when more stopped, every slot's flags are scanned instead).
+template <class S, class D>
+__global__ __launch_bounds__(64) void compact_set(uint32_t* __restrict__ stopped_hdr, uint32_t cap, S* st, D* dyn, SrcPending* pend,
+                                                  uint32_t* d_len, uint32_t* slot_of_id, uint32_t set_index, uint32_t* removed_ring,
+                                                  uint32_t ring_mask, unsigned char* finished, SetPublish* pub) {
+    __shared__ uint32_t slots[4096];
+    __shared__ uint32_t sorted[4096];
+    const uint32_t lane = threadIdx.x;
+    const uint32_t set_bit = set_index ? SLOT_BUFFERED_BIT : 0u;
+    const uint32_t count = stopped_hdr[0];
+    uint32_t len = d_len[0];
+    uint32_t total = pub->removed_total;
+    // remove slot s (wave-uniform): the last element moves into it
+    auto remove_slot = [&](uint32_t s) {
+        const uint32_t last = len - 1u;
+        const uint32_t id_removed = dyn_common(dyn[s]).id;
+        if (s != last) {
+            const uint32_t* a; uint32_t* b;
+            a = reinterpret_cast<const uint32_t*>(&st[last]); b = reinterpret_cast<uint32_t*>(&st[s]);
+            for (uint32_t w = lane; w < sizeof(S) / 4; w += 64) b[w] = a[w];
+            a = reinterpret_cast<const uint32_t*>(&dyn[last]); b = reinterpret_cast<uint32_t*>(&dyn[s]);
+            for (uint32_t w = lane; w < sizeof(D) / 4; w += 64) b[w] = a[w];
+            a = reinterpret_cast<const uint32_t*>(&pend[last]); b = reinterpret_cast<uint32_t*>(&pend[s]);
+            for (uint32_t w = lane; w < sizeof(SrcPending) / 4; w += 64) b[w] = a[w];
+            if (lane == 0) slot_of_id[dyn_common(dyn[last]).id] = s | set_bit;
+        }
+        if (lane == 0) {
+            slot_of_id[id_removed] = SLOT_INVALID;
+            removed_ring[total & ring_mask] = id_removed;
+            finished[id_removed] = 1;
+        }
+        __syncthreads();   // one wave: orders the copies of this step before the next step's reads
+        total++;
+        len--;
+    };
+    if (count > 0 && count <= cap && count <= 4096u) {
+        for (uint32_t i = lane; i < count; i += 64) slots[i] = slot_of_id[stopped_hdr[1 + i]] & ~SLOT_BUFFERED_BIT;
+        __syncthreads();
+        for (uint32_t i = lane; i < count; i += 64) {       // rank sort, descending (slots are distinct)
+            const uint32_t v = slots[i];
+            uint32_t rank = 0;
+            for (uint32_t j = 0; j < count; ++j) rank += slots[j] > v ? 1u : 0u;
+            sorted[rank] = v;
+        }
+        __syncthreads();
+        for (uint32_t i = 0; i < count; ++i) remove_slot(sorted[i]);
+    } else if (count > 0) {
+        // mass removal: the list overflowed, walk every slot in the walk's order
+        for (uint32_t hi = len; hi > 0;) {
+            const uint32_t base = hi >= 64u ? hi - 64u : 0u;
+            const uint32_t s = base + lane;
+            const bool stopped = s < hi && (dyn_common(dyn[s]).flags & DYN_STOPPED);
+            unsigned long long m = __ballot(stopped);
+            __syncthreads();
+            while (m) {
+                const int top = 63 - __builtin_clzll(m);
+                remove_slot(base + (uint32_t)top);
+                m &= ~(1ull << top);
+            }
+            hi = base;
+        }
+    }
+    if (lane == 0) {
+        d_len[0] = len;
+        stopped_hdr[0] = 0u;                                 // re-armed for the next callback
+        __threadfence_system();
+        pub->removed_total = total;
+        pub->len_and_inserted[set_index] = (uint64_t)len | ((uint64_t)d_len[1] << 32);
+        __threadfence_system();
+    }
+}
+
+// the walk reads the set length on the device; mix() of the same callback sees the length the walk saw
+__global__ void snapshot_len(const uint32_t* __restrict__ d_len, uint32_t* __restrict__ snap) { *snap = d_len[0]; }
+
+// Motion updates carry handle ids (spatial.rs:137-149: the handle, not the set position)
+struct MotionById { uint32_t id; float pos[3]; float vel[3]; uint32_t discontinuity; };
+
+__global__ void apply_motion_by_id(const MotionById* __restrict__ up, uint32_t n, const uint32_t* __restrict__ slot_of_id,
+                                   SrcPending* __restrict__ pend, SrcPending* __restrict__ pend_b) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const MotionById u = up[i];
+    const uint32_t sl = slot_of_id[u.id];
+    if (sl == SLOT_INVALID) return;                          // already removed
+    SrcPending p;
+    p.pos[0] = u.pos[0]; p.pos[1] = u.pos[1]; p.pos[2] = u.pos[2];
+    p.vel[0] = u.vel[0]; p.vel[1] = u.vel[1]; p.vel[2] = u.vel[2];
+    p.flags = PEND_FRESH | (u.discontinuity ? PEND_DISCONTINUITY : 0u);
+    p.pad = 0;
+    if (sl & SLOT_BUFFERED_BIT) pend_b[sl & ~SLOT_BUFFERED_BIT] = p; else pend[sl] = p;
+}
+
+// GainControl / SpeedControl values by handle id; one thread, send order (a later value wins)
+struct ControlById { uint32_t id; uint32_t index; float value; uint32_t pad; };
+__global__ void apply_control_by_id(const ControlById* __restrict__ up, uint32_t n, const uint32_t* __restrict__ slot_of_id,
+                                    BufDyn* __restrict__ bdyn) {
+    for (uint32_t i = 0; i < n; ++i) {
+        const uint32_t sl = slot_of_id[up[i].id];
+        if (sl == SLOT_INVALID || !(sl & SLOT_BUFFERED_BIT)) continue;
+        bdyn[sl & ~SLOT_BUFFERED_BIT].shared[up[i].index & (MAX_WRAP - 1)] = up[i].value;
+    }
+}
+
+// Seek::seek on every live source (signal.rs:48-51)
+__global__ void seek_all_live(SrcDyn* __restrict__ dyn, const SrcStatic* __restrict__ st, const uint32_t* __restrict__ d_len, float seconds) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= d_len[0]) return;
+    if (st[i].kind == KIND_FRAMES || st[i].kind == KIND_DOWNMIX) dyn[i].t = dyn[i].t + (double)seconds;   // frames.rs:211-213
+    else if (st[i].kind == KIND_SINE) dyn[i].phase = fmodf(dyn[i].phase + seconds * st[i].freq_or_value, ODDIO_TAU);
+    else if (st[i].kind == KIND_CYCLE) dyn[i].t = f64_rem_euclid(dyn[i].t + (double)seconds * (double)st[i].clip_rate, (double)st[i].clip_len);
+}
+
+// FaderControl::fade_to: the flushed command of one Fader (swap.rs keeps the latest)
+__global__ void apply_fade(const FaderPending* __restrict__ cmd, FaderRec* __restrict__ rec) { rec->pend = *cmd; }
+
+}  // namespace oddio_hip
