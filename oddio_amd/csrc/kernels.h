@@ -122,19 +122,19 @@ __device__ __forceinline__ long long f64_as_isize(double x) {
 // ---------------------------------------------------------------------------------------------
 // prepass: one thread per live slot
 // ---------------------------------------------------------------------------------------------
-// `d_len` is the device-resident set length (set_kernels.h); `st_copy` receives this callback's copy of
-// the static records, so that the mix kernel of the callback reads only per-callback buffers and the set
-// can be compacted / extended for the next callback while it runs.
+// `d_len` is the device-resident set length (set_kernels.h); `len_snap` receives the length this walk saw
+// (the mix kernel of the callback reads it; the set is compacted at the end of the callback).
 __global__ __launch_bounds__(256) void spatial_prepass(SceneParams P, const SrcStatic* __restrict__ st,
                                                        SrcDyn* __restrict__ dyn, SrcPending* __restrict__ pend,
-                                                       EarParams* __restrict__ ear, SrcStatic* __restrict__ st_copy,
-                                                       uint32_t* __restrict__ stopped_hdr, uint32_t stopped_cap, int check_pending,
-                                                       const uint32_t* __restrict__ d_len) {
+                                                       EarParams* __restrict__ ear, uint32_t* __restrict__ stopped_hdr,
+                                                       uint32_t stopped_cap, int check_pending, const uint32_t* __restrict__ d_len,
+                                                       uint32_t* __restrict__ len_snap) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= d_len[0]) return;
+    const uint32_t len = d_len[0];
+    if (i == 0) *len_snap = len;
+    if (i >= len) return;
     SrcDyn d = dyn[i];
     const SrcStatic s = st[i];
-    st_copy[i] = s;
     EarParams e0 = {}, e1 = {};
     if (d.flags & DYN_STOPPED) {  // removed earlier, compaction not applied yet: never mixed again
         e0.flags = EAR_SKIP; e1.flags = EAR_SKIP;
@@ -884,8 +884,8 @@ __global__ __launch_bounds__(256) void reduce_stage1(const float* __restrict__ p
 }
 
 // stage 2: out[o] = stage1[0][o] + stage1[1][o] + ... (fixed order), then Reinhard / Tanh
-__global__ __launch_bounds__(256) void reduce_stage2(const float* __restrict__ stage1, float* __restrict__ out,
-                                                     uint32_t n_wgs, uint32_t n_frames, int postfx) {
+__device__ __forceinline__ void reduce_stage2_body(const float* __restrict__ stage1, float* __restrict__ out,
+                                                   uint32_t n_wgs, uint32_t n_frames, int postfx) {
     const uint32_t o = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t n_out = 2 * n_frames;
     if (o >= n_out) return;

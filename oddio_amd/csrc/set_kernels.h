@@ -24,8 +24,7 @@ __device__ __forceinline__ SrcDyn& dyn_common(BufDyn& d) { return d.common; }
 // What the device tells the host about a scene, in pinned host memory (written with system-scope stores).
 struct SetPublish {
     volatile uint64_t len_and_inserted[2];   // per set (0 seek, 1 buffered): live length | cumulative inserts << 32
-    volatile uint32_t removed_total;         // entries ever written to the removed-id ring
-    uint32_t pad;
+    volatile uint32_t removed_total[2];      // per set: entries ever written to its removed-id ring
 };
 
 template <class S, class D>
@@ -46,46 +45,59 @@ __global__ void insert_sources(const S* __restrict__ src_st, const D* __restrict
 // after insert_sources: d_len[0] += k, d_len[1] (cumulative inserts) += k
 __global__ void bump_len(uint32_t* d_len, uint32_t k) { d_len[0] += k; d_len[1] += k; }
 
-// One wave.  stopped_hdr[0] = number of sources the walk stopped this callback, [1..] their handle ids
-// (first `cap`; when more stopped, every slot's flags are scanned instead).
+// Arguments of one set's compaction (by value into the kernels that run it).
+template <class S, class D> struct CompactArgs {
+    uint32_t* stopped_hdr;      // [0] = number of sources the walk stopped this callback, [1..] their handle ids (first `cap`;
+    uint32_t cap;               //   when more stopped, every slot's flags are scanned instead)
+    S* st; D* dyn; SrcPending* pend;
+    uint32_t* d_len;            // [0] live length, [1] cumulative inserts
+    uint32_t* slot_of_id;
+    uint32_t set_index;         // 0 seekable, 1 buffered
+    uint32_t* removed_ring; uint32_t ring_mask;
+    unsigned char* finished;
+    SetPublish* pub;
+};
+
+// One thread block (any size).  Runs after every reader of this callback's slot layout.
 template <class S, class D>
-__global__ __launch_bounds__(64) void compact_set(uint32_t* __restrict__ stopped_hdr, uint32_t cap, S* st, D* dyn, SrcPending* pend,
-                                                  uint32_t* d_len, uint32_t* slot_of_id, uint32_t set_index, uint32_t* removed_ring,
-                                                  uint32_t ring_mask, unsigned char* finished, SetPublish* pub) {
+__device__ void compact_set_block(const CompactArgs<S, D>& A) {
     __shared__ uint32_t slots[4096];
     __shared__ uint32_t sorted[4096];
-    const uint32_t lane = threadIdx.x;
-    const uint32_t set_bit = set_index ? SLOT_BUFFERED_BIT : 0u;
-    const uint32_t count = stopped_hdr[0];
-    uint32_t len = d_len[0];
-    uint32_t total = pub->removed_total;
-    // remove slot s (wave-uniform): the last element moves into it
+    const uint32_t tid = threadIdx.x, nt = blockDim.x;
+    const uint32_t set_bit = A.set_index ? SLOT_BUFFERED_BIT : 0u;
+    const uint32_t count = A.stopped_hdr[0];
+    uint32_t len = A.d_len[0];
+    uint32_t total = A.pub->removed_total[A.set_index];
+    __syncthreads();
+    // remove slot s (block-uniform): the last element moves into it (Vec::swap_remove)
     auto remove_slot = [&](uint32_t s) {
         const uint32_t last = len - 1u;
-        const uint32_t id_removed = dyn_common(dyn[s]).id;
+        const uint32_t id_removed = dyn_common(A.dyn[s]).id;
+        __syncthreads();
         if (s != last) {
             const uint32_t* a; uint32_t* b;
-            a = reinterpret_cast<const uint32_t*>(&st[last]); b = reinterpret_cast<uint32_t*>(&st[s]);
-            for (uint32_t w = lane; w < sizeof(S) / 4; w += 64) b[w] = a[w];
-            a = reinterpret_cast<const uint32_t*>(&dyn[last]); b = reinterpret_cast<uint32_t*>(&dyn[s]);
-            for (uint32_t w = lane; w < sizeof(D) / 4; w += 64) b[w] = a[w];
-            a = reinterpret_cast<const uint32_t*>(&pend[last]); b = reinterpret_cast<uint32_t*>(&pend[s]);
-            for (uint32_t w = lane; w < sizeof(SrcPending) / 4; w += 64) b[w] = a[w];
-            if (lane == 0) slot_of_id[dyn_common(dyn[last]).id] = s | set_bit;
+            a = reinterpret_cast<const uint32_t*>(&A.st[last]); b = reinterpret_cast<uint32_t*>(&A.st[s]);
+            for (uint32_t w = tid; w < sizeof(S) / 4; w += nt) b[w] = a[w];
+            a = reinterpret_cast<const uint32_t*>(&A.dyn[last]); b = reinterpret_cast<uint32_t*>(&A.dyn[s]);
+            for (uint32_t w = tid; w < sizeof(D) / 4; w += nt) b[w] = a[w];
+            a = reinterpret_cast<const uint32_t*>(&A.pend[last]); b = reinterpret_cast<uint32_t*>(&A.pend[s]);
+            for (uint32_t w = tid; w < sizeof(SrcPending) / 4; w += nt) b[w] = a[w];
+            if (tid == 0) A.slot_of_id[dyn_common(A.dyn[last]).id] = s | set_bit;
         }
-        if (lane == 0) {
-            slot_of_id[id_removed] = SLOT_INVALID;
-            removed_ring[total & ring_mask] = id_removed;
-            finished[id_removed] = 1;
+        if (tid == 0) {
+            A.slot_of_id[id_removed] = SLOT_INVALID;
+            A.removed_ring[total & A.ring_mask] = id_removed;
+            A.finished[id_removed] = 1;
         }
-        __syncthreads();   // one wave: orders the copies of this step before the next step's reads
+        __threadfence_block();
+        __syncthreads();   // the copies of this step before the next step's reads
         total++;
         len--;
     };
-    if (count > 0 && count <= cap && count <= 4096u) {
-        for (uint32_t i = lane; i < count; i += 64) slots[i] = slot_of_id[stopped_hdr[1 + i]] & ~SLOT_BUFFERED_BIT;
+    if (count > 0 && count <= A.cap && count <= 4096u) {
+        for (uint32_t i = tid; i < count; i += nt) slots[i] = A.slot_of_id[A.stopped_hdr[1 + i]] & ~SLOT_BUFFERED_BIT;
         __syncthreads();
-        for (uint32_t i = lane; i < count; i += 64) {       // rank sort, descending (slots are distinct)
+        for (uint32_t i = tid; i < count; i += nt) {        // rank sort, descending (slots are distinct)
             const uint32_t v = slots[i];
             uint32_t rank = 0;
             for (uint32_t j = 0; j < count; ++j) rank += slots[j] > v ? 1u : 0u;
@@ -94,33 +106,41 @@ __global__ __launch_bounds__(64) void compact_set(uint32_t* __restrict__ stopped
         __syncthreads();
         for (uint32_t i = 0; i < count; ++i) remove_slot(sorted[i]);
     } else if (count > 0) {
-        // mass removal: the list overflowed, walk every slot in the walk's order
+        // mass removal: the list overflowed, walk every slot in the walk's (descending) order
         for (uint32_t hi = len; hi > 0;) {
-            const uint32_t base = hi >= 64u ? hi - 64u : 0u;
-            const uint32_t s = base + lane;
-            const bool stopped = s < hi && (dyn_common(dyn[s]).flags & DYN_STOPPED);
-            unsigned long long m = __ballot(stopped);
+            const uint32_t base = hi >= nt ? hi - nt : 0u;
+            const uint32_t s = base + tid;
+            slots[tid] = (s < hi && (dyn_common(A.dyn[s]).flags & DYN_STOPPED)) ? 1u : 0u;
             __syncthreads();
-            while (m) {
-                const int top = 63 - __builtin_clzll(m);
-                remove_slot(base + (uint32_t)top);
-                m &= ~(1ull << top);
-            }
+            for (uint32_t t = hi - base; t-- > 0;)
+                if (slots[t]) remove_slot(base + t);
+            __syncthreads();
             hi = base;
         }
     }
-    if (lane == 0) {
-        d_len[0] = len;
-        stopped_hdr[0] = 0u;                                 // re-armed for the next callback
+    if (tid == 0) {
+        A.d_len[0] = len;
+        A.stopped_hdr[0] = 0u;                               // re-armed for the next callback
         __threadfence_system();
-        pub->removed_total = total;
-        pub->len_and_inserted[set_index] = (uint64_t)len | ((uint64_t)d_len[1] << 32);
+        A.pub->removed_total[A.set_index] = total;
+        A.pub->len_and_inserted[A.set_index] = (uint64_t)len | ((uint64_t)A.d_len[1] << 32);
         __threadfence_system();
     }
 }
 
-// the walk reads the set length on the device; mix() of the same callback sees the length the walk saw
-__global__ void snapshot_len(const uint32_t* __restrict__ d_len, uint32_t* __restrict__ snap) { *snap = d_len[0]; }
+template <class S, class D>
+__global__ __launch_bounds__(256) void compact_set(CompactArgs<S, D> A) { compact_set_block(A); }
+
+// The callback's last kernel: the fixed-order sum of the stage-1 slices + Reinhard / Tanh (blocks
+// [0, n_red)), and -- in two extra blocks that need nothing from the others -- set.remove() of what the walk
+// stopped (spatial.rs:258-261), so that compaction costs no launch of its own.
+__global__ __launch_bounds__(256) void reduce_stage2_compact(const float* __restrict__ stage1, float* __restrict__ out, uint32_t n_wgs,
+                                                             uint32_t n_frames, int postfx, uint32_t n_red,
+                                                             CompactArgs<SrcStatic, SrcDyn> seek, CompactArgs<BufStatic, BufDyn> buf) {
+    if (blockIdx.x == n_red) { compact_set_block(seek); return; }
+    if (blockIdx.x == n_red + 1u) { compact_set_block(buf); return; }
+    reduce_stage2_body(stage1, out, n_wgs, n_frames, postfx);
+}
 
 // Motion updates carry handle ids (spatial.rs:137-149: the handle, not the set position)
 struct MotionById { uint32_t id; float pos[3]; float vel[3]; uint32_t discontinuity; };

@@ -78,3 +78,51 @@ def test_postfx_device_and_stream(torch_cuda):
     o = out.cpu().numpy()
     assert np.allclose(o[:, 0], o[:, 1]) and o[0, 0] > 0
     scene.close()
+
+
+def test_sample_device_removal_and_insertion_order_is_the_references(torch_cuda):
+    """Sources finish (propagation-delay rule, spatial.rs:243-261) and new ones are played while callbacks are
+    enqueued back to back with sample_device -- no host synchronisation in between.  The set lives on the device
+    (swap_remove and push in stream order), so slot order, hence the ORDERED-mode sum, is the reference's: bit
+    exact against the oracle, which removes inside its walk (set.rs:183-188)."""
+    torch = torch_cuda
+    import oddio_amd as oa
+    from oddio_amd import synth
+    from oracle import oracle_c as oc
+    rate, n_cb, n0 = 48000, 14, 40
+    sc = synth.make_scene(77, 200, cube=6.0, vmax=3.0)
+    # clips of very different lengths: sources run out at different callbacks (1024 frames each)
+    lens = [2600 + 977 * (i % 9) for i in range(200)]
+    clips = [synth.noise_clip(77, i, lens[i]) for i in range(200)]
+    control, scene = oa.SpatialScene(max_sources=256, max_frames=1024)
+    scene.set_mode(oa.MODE_ORDERED)
+    oscene = oc.SpatialScene()
+    handles = []
+    nxt = [0]
+
+    def play(k):
+        for _ in range(k):
+            i = nxt[0]
+            nxt[0] += 1
+            handles.append(control.play(oa.FramesSignal(oa.Frames.from_slice(rate, clips[i]), 0.02), oa.SpatialOptions(sc["position"][i], sc["velocity"][i], 0.1)))
+            oscene.play(oc.FramesSignal(oc.Frames(rate, clips[i]), 0.02), oc.SpatialOptions(sc["position"][i], sc["velocity"][i], 0.1))
+    play(n0)
+    outs = torch.zeros((n_cb, 1024, 2), dtype=torch.float32, device="cuda")
+    refs = []
+    for cb in range(n_cb):
+        if cb in (2, 3, 5, 6, 9):
+            play(11)                                    # lands behind whatever the walk has compacted by then
+        scene.sample_device(INTERVAL, outs[cb].data_ptr(), 1024)     # enqueued, never waited for inside the loop
+        ref = np.zeros((1024, 2), dtype=np.float32)
+        oc.run(oscene, rate, ref)
+        refs.append(ref)
+    scene.synchronize()
+    got = outs.cpu().numpy()
+    removed = n0 + 55 - len(oscene)
+    assert removed >= 20, "the scenario is supposed to remove sources while others are inserted"
+    for cb in range(n_cb):
+        np.testing.assert_array_equal(got[cb], refs[cb], err_msg=f"callback {cb}")
+    assert len(scene) == len(oscene)
+    fin = [h.is_finished() for h in handles]
+    assert sum(fin) == removed
+    scene.close()
