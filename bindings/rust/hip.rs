@@ -81,6 +81,7 @@ extern "C" {
     fn oddio_hip_mixer_set_gain(m: *mut RawMixer, id: u32, filter_index: c_int, amplitude_ratio: f32) -> c_int;
     fn oddio_hip_mixer_set_speed(m: *mut RawMixer, id: u32, filter_index: c_int, factor: f32) -> c_int;
     fn oddio_hip_mixer_stop(m: *mut RawMixer, id: u32) -> c_int;
+    fn oddio_hip_mixer_source_release(m: *mut RawMixer, id: u32) -> c_int;
     fn oddio_hip_mixer_is_stopped(m: *mut RawMixer, id: u32, stopped: *mut c_int) -> c_int;
     fn oddio_hip_mixer_set_postfx(m: *mut RawMixer, postfx: c_int) -> c_int;
     fn oddio_hip_mixer_sample(m: *mut RawMixer, interval: f32, out: *mut f32, n_frames: usize) -> c_int;
@@ -314,6 +315,11 @@ impl HipMixerControl {
         let mut id = 0u32;
         check(unsafe { oddio_hip_mixer_play_chain((self.0).0, LEAF_FRAMES, frames.0, start_seconds, 0.0, 0.0, filters.as_ptr(), filters.len() as c_int, &mut id) });
         HipMixed { mixer: self.0.clone(), id }
+    }
+}
+impl Drop for HipMixed {
+    fn drop(&mut self) {
+        unsafe { oddio_hip_mixer_source_release(self.mixer.0, self.id) };
     }
 }
 impl HipMixed {

@@ -77,6 +77,8 @@ int oddio_hip_frames_from_device(int device, uint32_t rate, const float* dev_sam
 int oddio_hip_frames_retain(oddio_hip_frames* f);
 int oddio_hip_frames_release(oddio_hip_frames* f);
 int oddio_hip_frames_info(const oddio_hip_frames* f, uint32_t* rate, size_t* len);
+/* Arc::strong_count: how many owners (caller handles, playing sources, pending fades) hold the clip. */
+int oddio_hip_frames_refcount(const oddio_hip_frames* f, int* count);
 
 /* ---- SpatialScene (src/spatial.rs:160-189 `SpatialScene::new`) ---- */
 int oddio_hip_scene_create(int device, uint32_t max_sources, uint32_t max_frames,
@@ -319,6 +321,8 @@ int oddio_hip_mixer_set_speed(oddio_hip_mixer* mixer, uint32_t source_id, int fi
 /* Mixed::stop / Mixed::is_stopped (src/mixer.rs:34-43) */
 int oddio_hip_mixer_stop(oddio_hip_mixer* mixer, uint32_t source_id);
 int oddio_hip_mixer_is_stopped(oddio_hip_mixer* mixer, uint32_t source_id, int* stopped);
+/* drop(Mixed): the handle is not used any more; its id is recycled once the source has left the mixer. */
+int oddio_hip_mixer_source_release(oddio_hip_mixer* mixer, uint32_t source_id);
 int oddio_hip_mixer_len(oddio_hip_mixer* mixer, size_t* len);
 int oddio_hip_mixer_set_postfx(oddio_hip_mixer* mixer, int postfx);
 /* Adapt::new(mixer, ..): same as oddio_hip_scene_set_adapt for a Mixer (examples/adapt.rs:6-16). */

@@ -69,6 +69,7 @@ def lib():
         "oddio_hip_frames_retain": (i32, [vp]),
         "oddio_hip_frames_release": (i32, [vp]),
         "oddio_hip_frames_info": (i32, [vp, u32p, C.POINTER(sz)]),
+        "oddio_hip_frames_refcount": (i32, [vp, C.POINTER(i32)]),
         "oddio_hip_scene_create": (i32, [i32, u32, u32, vpp]),
         "oddio_hip_scene_destroy": (i32, [vp]),
         "oddio_hip_scene_play_frames": (i32, [vp, vp, f64, f32, fp, fp, f32, u32p]),
@@ -129,6 +130,7 @@ def lib():
         "oddio_hip_mixer_set_gain_db": (i32, [vp, u32, i32, f32]),
         "oddio_hip_mixer_set_speed": (i32, [vp, u32, i32, f32]),
         "oddio_hip_mixer_stop": (i32, [vp, u32]),
+        "oddio_hip_mixer_source_release": (i32, [vp, u32]),
         "oddio_hip_mixer_is_stopped": (i32, [vp, u32, C.POINTER(i32)]),
         "oddio_hip_mixer_len": (i32, [vp, C.POINTER(sz)]),
         "oddio_hip_mixer_set_postfx": (i32, [vp, i32]),

@@ -649,6 +649,13 @@ class Mixed:
         _lib.check(_lib.lib().oddio_hip_mixer_is_stopped(self._m._h, self.id, C.byref(out)))
         return bool(out.value)
 
+    def __del__(self):      # drop(Mixed): the library may recycle the handle id once the source is gone
+        try:
+            if self._m._h:
+                _lib.lib().oddio_hip_mixer_source_release(self._m._h, self.id)
+        except Exception:
+            pass
+
 
 class _MixerSignal(Signal):
     channels = 2

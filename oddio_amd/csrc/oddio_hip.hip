@@ -150,6 +150,11 @@ extern "C" int oddio_hip_frames_release(oddio_hip_frames* f) {
     }
     return 0;
 }
+extern "C" int oddio_hip_frames_refcount(const oddio_hip_frames* f, int* count) {
+    if (!f || !count) return fail(ODDIO_HIP_EINVAL, "NULL argument");
+    *count = f->refs.load(std::memory_order_acquire);
+    return 0;
+}
 extern "C" int oddio_hip_frames_info(const oddio_hip_frames* f, uint32_t* rate, size_t* len) {
     if (!f) return fail(ODDIO_HIP_EINVAL, "NULL frames");
     if (rate) *rate = f->rate;
