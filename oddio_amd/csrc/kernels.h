@@ -316,7 +316,7 @@ __global__ __launch_bounds__(64) void cycle_sources(SceneParams P, const SrcStat
 //   * workgroups are MIX_WG_WAVES independent waves (own LDS slice, wave-local ordering only);
 //     their accumulators are summed through LDS in fixed order before one partial tile is written.
 #ifndef ODDIO_MIX_WG_WAVES
-#define ODDIO_MIX_WG_WAVES 4
+#define ODDIO_MIX_WG_WAVES 2
 #endif
 #ifndef ODDIO_MIX_WAVES
 #define ODDIO_MIX_WAVES 4
@@ -324,6 +324,7 @@ __global__ __launch_bounds__(64) void cycle_sources(SceneParams P, const SrcStat
 #ifndef ODDIO_MIX_DEPTH
 #define ODDIO_MIX_DEPTH 1
 #endif
+
 constexpr int MIX_WG_WAVES = ODDIO_MIX_WG_WAVES;       // waves per workgroup
 constexpr int MIX_WAVES_PER_SIMD = ODDIO_MIX_WAVES;    // register budget: 512 / this
 constexpr int MIX_DEPTH = ODDIO_MIX_DEPTH;             // samples whose LDS pair reads are in flight together
@@ -493,7 +494,9 @@ __device__ __forceinline__ void mix_source_lds(const float* win, int wrel, float
         __builtin_amdgcn_sched_barrier(0);
         float v = a[i] + fr[i] * (bb[i] - a[i]);              // frame.rs:39-41 lerp, unfused
         if (HAS_FG) v = v * fixed_gain;                       // gain.rs:32-37
-        const float p = v * (g0 + fi[i] * dg);                // spatial.rs:459-460
+        float dg_i = dg;
+        asm volatile("" : "+v"(dg_i));                        // keeps hipcc from hoisting 16 gain values out of the loop (16 VGPRs -> scratch)
+        const float p = v * (g0 + fi[i] * dg_i);              // spatial.rs:459-460
         if (FULL || frame0 + (uint32_t)i < n_frames) acc[i] = acc[i] + p;
         __builtin_amdgcn_sched_barrier(0);
     }
