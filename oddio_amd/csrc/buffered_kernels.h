@@ -287,11 +287,12 @@ __global__ __launch_bounds__(64) void buffered_sources(SceneParams P, const uint
                                                        BufDyn* __restrict__ dyn, SrcPending* __restrict__ pend,
                                                        float* __restrict__ contrib, uint32_t* __restrict__ skip,
                                                        uint32_t* __restrict__ stopped_hdr, uint32_t stopped_cap,
-                                                       FaderRec* __restrict__ faders, float* __restrict__ fader_scratch) {
+                                                       FaderRec* __restrict__ faders, float* __restrict__ fader_scratch, int skip_wave_shapes) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= d_len_b[0]) return;
     BufDyn d = dyn[i];
     BufStatic s = st[i];
+    if (skip_wave_shapes && s.kind == KIND_FRAMES && s.channels <= 1u && s.fader == 0u) return;   // buffered_sources_wave renders these
     SrcDyn& c = d.common;
     if (c.flags & DYN_STOPPED) { skip[i] = 1; return; }
     const float elapsed = P.elapsed;
@@ -408,17 +409,284 @@ __global__ __launch_bounds__(64) void buffered_sources(SceneParams P, const uint
     dyn[i] = d;
 }
 
-// out_b[o] = ((0 + contrib[last]) + ... + contrib[0]) : the reference's reverse walk (spatial.rs:204)
-__global__ void buffered_reduce(const float* __restrict__ contrib, const uint32_t* __restrict__ skip, const uint32_t* __restrict__ d_len_b,
-                                uint32_t n_frames, float* __restrict__ out_b) {
+// ---- wave-per-source formulation for the common buffered shape --------------------------------------
+// play_buffered(filters(FramesSignal<f32>)) with any FixedGain / Gain / Speed chain (what Gain and Speed
+// sources, the reason the buffered path exists, look like).  The reference's loops are sequential only in
+// their f32 running sums -- the leaf's cursor `offset += ds` (frames.rs:189-196), each Gain's
+// `progress = min(progress + step, 1)` (gain.rs:114-120, smooth.rs:47-49) and Ring::sample's cursor with its
+// wrap rewrite (ring.rs:59-78).  One lane per running sum replays it exactly and drops a checkpoint every 16
+// steps in LDS; then all 64 lanes restart from their checkpoints and produce 16 frames each, like the mix
+// kernel's phase A / phase B.  Bit-identical to the thread-per-source kernel, ~100x shorter critical path.
+__device__ __forceinline__ bool buffered_wave_eligible(const BufStatic& s) {
+    return s.kind == KIND_FRAMES && s.channels <= 1u && s.fader == 0u;
+}
+__device__ __forceinline__ void wg_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
+// inner.sample(interval, out[0..n]) for the chain above; every lane holds the same `s` / `d`.
+__device__ void inner_sample_wave(const BufStatic& s, BufDyn& d, float interval, float* out, uint32_t n, float (*ck)[64], int lane) {
+    float level_interval[MAX_WRAP];
+    float cur = interval;
+    for (int w = (int)s.n_wrap - 1; w >= 0; --w) {
+        level_interval[w] = cur;
+        if (s.wrap_kind[w] == WRAP_SPEED) cur = cur * d.shared[w];   // speed.rs:32-35
+    }
+    // leaf: frames.rs:176-201
+    const double s0 = d.common.t * (double)s.clip_rate;
+    const float ds = cur * (float)s.clip_rate;
+    const long long base = f64_as_isize(s0);
+    const bool fast = fabsf(ds - 1.0f) <= FLT_EPSILON;
+    const float frac0 = (float)(s0 - (double)base);
+    // Gain: Smoothed::set when the shared target moved (gain.rs:106-109), then ramp or constant
+    bool ramp[MAX_WRAP];
+    float gconst[MAX_WRAP], step[MAX_WRAP];
+    for (uint32_t w = 0; w < MAX_WRAP; ++w) {
+        ramp[w] = false; gconst[w] = 1.0f; step[w] = 0.0f;
+        if (w < s.n_wrap && s.wrap_kind[w] == WRAP_GAIN) {
+            const float shared = d.shared[w];
+            if (d.sm_next[w] != shared) {
+                d.sm_prev[w] = d.sm_prev[w] + d.sm_progress[w] * (d.sm_next[w] - d.sm_prev[w]);
+                d.sm_next[w] = shared;
+                d.sm_progress[w] = 0.0f;
+            }
+            ramp[w] = d.sm_progress[w] != 1.0f;
+            gconst[w] = d.sm_prev[w] + d.sm_progress[w] * (d.sm_next[w] - d.sm_prev[w]);
+            step[w] = level_interval[w] / 0.1f;                       // SMOOTHING_PERIOD, gain.rs:163
+        }
+    }
+    // running sums: lane 0 the leaf cursor, lane 1 + w the progress of Gain w
+    const bool is_gain = lane >= 1 && lane <= MAX_WRAP;
+    float scan = 0.0f, inc = 0.0f;
+    if (lane == 0) { scan = frac0; inc = ds; }
+    for (int w = 0; w < MAX_WRAP; ++w) if (lane == 1 + w) { scan = d.sm_progress[w]; inc = step[w]; }
+    for (uint32_t p0 = 0; p0 < n; p0 += 1024u) {
+        const uint32_t m = (n - p0) < 1024u ? (n - p0) : 1024u;
+        const uint32_t nb = (m + 15u) / 16u;
+        if (lane <= MAX_WRAP) {
+            for (uint32_t b = 0; b < nb; ++b) {
+                ck[lane][b] = scan;
+                const uint32_t cnt = (m - 16u * b) < 16u ? (m - 16u * b) : 16u;
+                for (uint32_t i = 0; i < cnt; ++i) {
+                    const float v = scan + inc;
+                    scan = is_gain ? fminf(v, 1.0f) : v;
+                }
+            }
+        }
+        wg_sync();
+        if (16u * (uint32_t)lane < m) {
+            const uint32_t f0 = p0 + 16u * (uint32_t)lane;
+            const uint32_t cnt = (m - 16u * (uint32_t)lane) < 16u ? (m - 16u * (uint32_t)lane) : 16u;
+            float off = ck[0][lane];
+            float pr[MAX_WRAP];
+            for (int w = 0; w < MAX_WRAP; ++w) pr[w] = ck[1 + w][lane];
+            for (uint32_t k = 0; k < cnt; ++k) {
+                long long idx; float fr;
+                if (fast) { idx = base + (long long)(f0 + k); fr = frac0; }                       // frames.rs:180-187
+                else { const long long tr = (long long)off; idx = base + tr; fr = off - (float)tr; off = off + ds; }   // :189-196
+                const float a = clip_ch(s.clip, s.clip_len, 1u, 0u, idx), b = clip_ch(s.clip, s.clip_len, 1u, 0u, idx + 1);
+                float v = a + fr * (b - a);
+                for (uint32_t w = 0; w < s.n_wrap; ++w) {
+                    if (s.wrap_kind[w] == WRAP_FIXED_GAIN) v = v * s.wrap_param[w];              // gain.rs:32-37
+                    else if (s.wrap_kind[w] == WRAP_GAIN) {                                       // gain.rs:110-121
+                        if (ramp[w]) {
+                            const float g = d.sm_prev[w] + pr[w] * (d.sm_next[w] - d.sm_prev[w]);
+                            v = v * g;
+                            pr[w] = fminf(pr[w] + step[w], 1.0f);
+                        } else if (gconst[w] != 1.0f) v = v * gconst[w];
+                    }
+                }
+                out[f0 + k] = v;
+            }
+        }
+        wg_sync();   // before the next pass overwrites the checkpoints
+    }
+    for (int w = 0; w < MAX_WRAP; ++w) {
+        const float fin = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(scan), 1 + w));
+        if (ramp[w]) d.sm_progress[w] = fin;
+    }
+    d.common.t = d.common.t + (double)cur * (double)n;                                            // frames.rs:198
+}
+
+// One wave per buffered slot; slots of other shapes are left to buffered_sources (skip_wave_shapes = 1 there).
+__global__ __launch_bounds__(64) void buffered_sources_wave(SceneParams P, const uint32_t* __restrict__ d_len_b, BufStatic* __restrict__ st,
+                                                            BufDyn* __restrict__ dyn, SrcPending* __restrict__ pend,
+                                                            float* __restrict__ contrib, uint32_t* __restrict__ skip,
+                                                            uint32_t* __restrict__ stopped_hdr, uint32_t stopped_cap) {
+    __shared__ float ck[8][64];
+    const uint32_t i = blockIdx.x;
+    const int lane = threadIdx.x;
+    if (i >= d_len_b[0]) return;
+    const BufStatic s = st[i];
+    if (!buffered_wave_eligible(s)) return;
+    BufDyn d = dyn[i];
+    SrcDyn& c = d.common;
+    if (c.flags & DYN_STOPPED) { if (lane == 0) skip[i] = 1; return; }
+    const float elapsed = P.elapsed;
+    const uint32_t n = P.n_frames;
+    const float nf = (float)n;
+    V3 tpos = {c.tgt_pos[0], c.tgt_pos[1], c.tgt_pos[2]};
+    V3 tvel = {c.tgt_vel[0], c.tgt_vel[1], c.tgt_vel[2]};
+    V3 ppos = {c.prev_pos[0], c.prev_pos[1], c.prev_pos[2]};
+    const SrcPending pm = pend[i];
+    if (pm.flags & PEND_FRESH) {   // spatial.rs:216-226
+        V3 npos = {pm.pos[0], pm.pos[1], pm.pos[2]};
+        V3 nvel = {pm.vel[0], pm.vel[1], pm.vel[2]};
+        ppos = (pm.flags & PEND_DISCONTINUITY) ? npos : smoothed_position(ppos, c.state_dt, 0.0f, tpos, tvel);
+        tpos = npos; tvel = nvel;
+        c.state_dt = 0.0f;
+    }
+    const Quat prev_rot = {P.prev_rot[0], P.prev_rot[1], P.prev_rot[2], P.prev_rot[3]};
+    const Quat rot = {P.rot[0], P.rot[1], P.rot[2], P.rot[3]};
+    const V3 p0 = quat_rotate(prev_rot, smoothed_position(ppos, c.state_dt, 0.0f, tpos, tvel));
+    const V3 p1 = quat_rotate(rot, smoothed_position(ppos, c.state_dt, elapsed, tpos, tvel));
+    c.state_dt = c.state_dt + elapsed;
+    c.tgt_pos[0] = tpos.x; c.tgt_pos[1] = tpos.y; c.tgt_pos[2] = tpos.z;
+    c.tgt_vel[0] = tvel.x; c.tgt_vel[1] = tvel.y; c.tgt_vel[2] = tvel.z;
+    c.prev_pos[0] = ppos.x; c.prev_pos[1] = ppos.y; c.prev_pos[2] = ppos.z;
+    // spatial.rs:243-261
+    const float distance = v3_norm(p0);
+    if (c.flags & DYN_HAS_FINISHED_FOR) {
+        if (c.finished_for > distance / ODDIO_SPEED_OF_SOUND) c.flags |= DYN_STOPPED;
+        else c.finished_for = c.finished_for + elapsed;
+    } else if (c.t >= (double)(s.clip_len - 1u) / (double)s.clip_rate) {   // is_finished passes through the filters
+        c.flags |= DYN_HAS_FINISHED_FOR; c.finished_for = elapsed;
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (lane == 0 && (pm.flags & PEND_FRESH)) pend[i].flags = 0;
+    if (c.flags & DYN_STOPPED) {
+        if (lane == 0) {
+            const uint32_t k = atomicAdd(&stopped_hdr[0], 1u);
+            if (k < stopped_cap) stopped_hdr[1 + k] = c.id;
+            skip[i] = 1;
+            dyn[i] = d;
+        }
+        return;
+    }
+    if (lane == 0) skip[i] = 0;
+    float* ring = s.ring;
+    const uint32_t len = s.ring_len;
+    {   // Ring::write (ring.rs:18-41): extend the delay queue with new data
+        const float end = fmodf(d.ring_write + elapsed * (float)s.rate, (float)len);
+        const size_t start_idx = f32_as_usize(ceilf(d.ring_write));
+        const size_t end_idx = f32_as_usize(ceilf(end));
+        const float interval = 1.0f / (float)s.rate;
+        if (end_idx > start_idx) {
+            inner_sample_wave(s, d, interval, ring + start_idx, (uint32_t)(end_idx - start_idx), ck, lane);
+        } else {
+            inner_sample_wave(s, d, interval, ring + start_idx, (uint32_t)(len - start_idx), ck, lane);
+            inner_sample_wave(s, d, interval, ring, (uint32_t)end_idx, ck, lane);
+        }
+        d.ring_write = end;
+    }
+    wg_sync();   // the ring samples written above are read back by other lanes below
+    float* my = contrib + (size_t)i * 2 * n;
+    float prev_offset[2], dts[2], g0s[2], dgs[2];
+    for (int e = 0; e < 2; ++e) {   // spatial.rs:409-423
+        float off0, g0, off1, g1;
+        ear_state(p0, e, s.radius, off0, g0);
+        ear_state(p1, e, s.radius, off1, g1);
+        prev_offset[e] = fmaxf(off0 - elapsed, -s.max_delay);
+        const float next_offset = fmaxf(off1, -s.max_delay);
+        dts[e] = (next_offset - prev_offset[e]) / nf;
+        dgs[e] = (g1 - g0) / nf;
+        g0s[e] = g0;
+    }
+    // Ring::sample (ring.rs:51-79) per ear and 256-frame chunk (spatial.rs:424): 4 chunks x 2 ears per pass
+    auto ring_step = [&](float& offset, float ds_, float& a, float& b, float& fract) {
+        size_t x = (size_t)offset;
+        fract = offset - (float)x;
+        if (x < (size_t)len - 1) { a = ring[x]; b = ring[x + 1]; }
+        else if (x < (size_t)len) { a = ring[x]; b = ring[0]; }
+        else {
+            x = x % len;
+            offset = (float)x + fract;
+            if (x < (size_t)len - 1) { a = ring[x]; b = ring[x + 1]; }
+            else { a = ring[x]; b = ring[0]; }
+        }
+        offset = offset + ds_;
+    };
+    for (uint32_t pass0 = 0; pass0 < n; pass0 += 1024u) {
+        if (lane < 8) {
+            const int e = lane >> 2;
+            const uint32_t done = pass0 + 256u * (uint32_t)(lane & 3);
+            if (done < n) {
+                const uint32_t clen = (n - done) < 256u ? (n - done) : 256u;
+                const float t = prev_offset[e] + (float)done * dts[e];                 // idx == done at the chunk's start (spatial.rs:424)
+                float offset = f32_rem_euclid(d.ring_write + t * (float)s.rate, (float)len);
+                const float ds_ = dts[e] * (float)s.rate;
+                for (uint32_t b = 0; b * 16u < clen; ++b) {
+                    ck[lane][b] = offset;
+                    const uint32_t cnt = (clen - 16u * b) < 16u ? (clen - 16u * b) : 16u;
+                    for (uint32_t k = 0; k < cnt; ++k) { float a, bb, fr; ring_step(offset, ds_, a, bb, fr); }
+                }
+            }
+        }
+        wg_sync();
+        for (int e = 0; e < 2; ++e) {
+            const int cq = lane >> 4, b = lane & 15;
+            const uint32_t done = pass0 + 256u * (uint32_t)cq;
+            const uint32_t f0 = done + 16u * (uint32_t)b;
+            if (f0 < n) {
+                const uint32_t clen = (n - done) < 256u ? (n - done) : 256u;
+                const uint32_t cnt = (clen - 16u * (uint32_t)b) < 16u ? (clen - 16u * (uint32_t)b) : 16u;
+                float offset = ck[e * 4 + cq][b];
+                const float ds_ = dts[e] * (float)s.rate;
+                for (uint32_t k = 0; k < cnt; ++k) {
+                    float a, bb, fr;
+                    ring_step(offset, ds_, a, bb, fr);
+                    const float v = a + fr * (bb - a);
+                    const float gain = g0s[e] + (float)(f0 + k) * dgs[e];              // spatial.rs:426
+                    my[2 * (f0 + k) + e] = v * gain;
+                }
+            }
+        }
+        wg_sync();
+    }
+    if (lane == 0) dyn[i] = d;
+}
+
+// out_b[o] = ((0 + contrib[last]) + ... + contrib[0]) : the reference's reverse walk (spatial.rs:204).
+// grid = (ceil(n_out / 64), n_slices), block = 256.  Slice k sums slots [k*per, (k+1)*per) in descending
+// order into part[k][o]; buffered_reduce_finish adds the slices, last slice first.  ORDERED mode uses ONE
+// slice (the reference's exact sequence); FAST mode 32 (a deterministic tree, like the seekable set's).
+// Rows are staged through LDS 64 at a time so that the sequential adds do not wait for HBM one by one.
+constexpr int BUFRED_ROWS = 64;
+__global__ __launch_bounds__(256) void buffered_reduce(const float* __restrict__ contrib, const uint32_t* __restrict__ skip,
+                                                       const uint32_t* __restrict__ d_len_b, uint32_t n_frames, float* __restrict__ part,
+                                                       uint32_t n_slices) {
+    __shared__ float tile[BUFRED_ROWS][65];
+    __shared__ uint32_t sk[BUFRED_ROWS];
+    const uint32_t n_out = 2 * n_frames;
+    const uint32_t ox = threadIdx.x & 63, sy = threadIdx.x >> 6;
+    const uint32_t o = blockIdx.x * 64 + ox;
+    const uint32_t len = d_len_b[0];
+    const uint32_t per = (len + n_slices - 1) / n_slices;
+    const uint32_t lo = blockIdx.y * per;
+    uint32_t hi = lo + per < len ? lo + per : len;
+    float s = 0.0f;
+    while (hi > lo) {
+        const uint32_t base = hi - lo >= (uint32_t)BUFRED_ROWS ? hi - BUFRED_ROWS : lo;
+        const uint32_t cnt = hi - base;
+        for (uint32_t r = sy; r < cnt; r += 4) tile[r][ox] = o < n_out ? contrib[(size_t)(base + r) * n_out + o] : 0.0f;
+        if (threadIdx.x < cnt) sk[threadIdx.x] = skip[base + threadIdx.x];
+        __syncthreads();
+        if (sy == 0)
+            for (uint32_t r = cnt; r-- > 0;)
+                if (!sk[r]) s = s + tile[r][ox];
+        __syncthreads();
+        hi = base;
+    }
+    if (sy == 0 && o < n_out) part[(size_t)blockIdx.y * n_out + o] = s;
+}
+__global__ void buffered_reduce_finish(const float* __restrict__ part, uint32_t n_slices, uint32_t n_frames, float* __restrict__ out_b) {
     const uint32_t o = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t n_out = 2 * n_frames;
     if (o >= n_out) return;
-    float s = 0.0f;
-    for (uint32_t i = d_len_b[0]; i-- > 0;) {
-        if (skip[i]) continue;
-        s = s + contrib[(size_t)i * n_out + o];
-    }
+    float s = part[(size_t)(n_slices - 1) * n_out + o];          // the walk starts at the last slot
+    for (uint32_t k = n_slices - 1; k-- > 0;) s = s + part[(size_t)k * n_out + o];
     out_b[o] = s;
 }
 
