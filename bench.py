@@ -355,7 +355,7 @@ def main():
         del scratch
     for _ in range(args.warmup):
         one_step()
-    scene.set_profiling(True)
+    scene.set_profiling(2)     # two hipEvents per callback, around spatial_mix (the roofline kernel), inside the timed region
     sync_all()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -363,6 +363,12 @@ def main():
     sync_all()
     elapsed = time.perf_counter() - t0
     hist = scene.kernel_ms_history(min(args.steps, 512))
+    # the other stages of a callback (walk, reduce): a few untimed callbacks with events around every stage
+    # (four per callback cost 3-6 us of command-processor time, tools/event_overhead.py; not inside `value`)
+    scene.set_profiling(1)
+    for _ in range(8):
+        one_step()
+    stages = scene.kernel_ms_history(8)
     scene.set_profiling(False)
     assert len(scene) == len(g["ids"]), "sources finished inside the timed region"
     assert bool(torch.isfinite(out).all()) and float(out.abs().max()) > 0.0
@@ -437,8 +443,9 @@ def main():
                 "traffic": traffic, "traffic_source": traffic_source,
                 "kernel": "spatial_mix", "avg_kernel_ms": mix_ms, "algorithmic_bytes_per_launch": b_alg,
                 "frac_callback": b_alg / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBPS,
-                "prepass_ms": float(hist[:, 0].mean()),
-                ("reduce_incl_collective_ms" if sharded else "reduce_ms"): float(hist[:, 2].mean()),
+                "prepass_ms": float(stages[:, 0].mean()),
+                ("reduce_incl_collective_ms" if sharded else "reduce_ms"): float(stages[:, 2].mean()),
+                "stage_timing": "prepass/reduce: 8 untimed callbacks after the timed region; avg_kernel_ms: every timed callback",
             },
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -418,7 +418,8 @@ class _SceneSignal(Signal):
         _lib.check(_lib.lib().oddio_hip_scene_set_mode(self._h, int(mode)))
 
     def set_profiling(self, on):
-        _lib.check(_lib.lib().oddio_hip_scene_set_profiling(self._h, int(bool(on))))
+        """False/0 off, True/1 events around every stage, 2 events around the mix kernel only."""
+        _lib.check(_lib.lib().oddio_hip_scene_set_profiling(self._h, 2 if on == 2 else int(bool(on))))
 
     def last_kernel_ms(self):
         ms = (C.c_float * 3)()

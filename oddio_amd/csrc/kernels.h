@@ -10,7 +10,7 @@
 //                                         (spatial.rs:191-265, :445-469 scalar part, :501-549)
 //   spatial_mix       4-wave workgroups, 16 sources per wave-group; the per-sample loop
 //                                         (spatial.rs:456-463 + frames.rs:176-201 + sine.rs:34-40)
-//   reduce_stage1/2   fixed-order sum of the workgroup partial tiles + Reinhard/Tanh epilogue
+//   reduce_partials   fixed-order sum of the workgroup partial tiles + Reinhard/Tanh epilogue
 //                                         (reinhard.rs:32, tanh.rs:26)
 //
 // Mix kernel work decomposition (why it is not "one lane = one output frame"):
@@ -494,9 +494,8 @@ __device__ __forceinline__ void mix_source_lds(const float* win, int wrel, float
         __builtin_amdgcn_sched_barrier(0);
         float v = a[i] + fr[i] * (bb[i] - a[i]);              // frame.rs:39-41 lerp, unfused
         if (HAS_FG) v = v * fixed_gain;                       // gain.rs:32-37
-        float dg_i = dg;
-        asm volatile("" : "+v"(dg_i));                        // keeps hipcc from hoisting 16 gain values out of the loop (16 VGPRs -> scratch)
-        const float p = v * (g0 + fi[i] * dg_i);              // spatial.rs:459-460
+        asm volatile("" : "+v"(dg));                          // keeps hipcc from hoisting 16 gain values out of the loop (16 VGPRs -> scratch)
+        const float p = v * (g0 + fi[i] * dg);                // spatial.rs:459-460
         if (FULL || frame0 + (uint32_t)i < n_frames) acc[i] = acc[i] + p;
         __builtin_amdgcn_sched_barrier(0);
     }
@@ -849,54 +848,42 @@ __device__ __forceinline__ float postfx_apply(float x, int postfx) {
     return x;
 }
 
-constexpr int RED_SPLIT = 16;   // stage-1 slices of the workgroup-partial list
-constexpr int RED_SEGS = 4;     // strided segments inside one stage-1 block
+constexpr int RED_FRAMES = 4;    // output frames per reduce block: 256 threads = (4 frames x 2 ears) x 32 segments
+constexpr int RED_SEGS = 32;     // strided segments of the workgroup-partial list
 
-// stage 1: grid = (ceil(n_frames / 32), RED_SPLIT), block = 256 = 64 outputs x RED_SEGS.
-// slice k sums workgroup partials [k*per, (k+1)*per) -> stage1[k][2*f + e]
-__global__ __launch_bounds__(256) void reduce_stage1(const float* __restrict__ partials, float* __restrict__ stage1,
-                                                     uint32_t n_wgs, uint32_t n_frames) {
-    __shared__ float red[RED_SEGS][64];
-    const uint32_t ox = threadIdx.x & 63, seg = threadIdx.x >> 6;
-    const uint32_t e = ox >> 5;
-    const uint32_t f = blockIdx.x * 32 + (ox & 31);      // output frame
+// One block sums ALL workgroup partials of its 8 outputs in a fixed order that depends only on n_wgs
+// (segment s adds workgroups s, s+32, ... in ascending order; the 32 segment sums are then added in
+// ascending order), applies Reinhard / Tanh and writes the interleaved stereo frames.  With n_wgs == 1
+// (ORDERED mode) the output is that workgroup's value unchanged.
+__device__ __forceinline__ void reduce_partials_body(const float* __restrict__ partials, float* __restrict__ out, uint32_t n_wgs,
+                                                     uint32_t n_frames, int postfx, uint32_t block) {
+    __shared__ float red[RED_SEGS][2 * RED_FRAMES];
+    const uint32_t ox = threadIdx.x & (2 * RED_FRAMES - 1), seg = threadIdx.x / (2 * RED_FRAMES);
+    const uint32_t e = ox / RED_FRAMES;
+    const uint32_t f = block * RED_FRAMES + (ox % RED_FRAMES);      // output frame
     const uint32_t tile = f / TILE_FRAMES, fin = f % TILE_FRAMES;
-    const uint32_t per = (n_wgs + RED_SPLIT - 1) / RED_SPLIT;
-    const uint32_t w0 = blockIdx.y * per;
-    uint32_t w1 = w0 + per;
-    if (w1 > n_wgs) w1 = n_wgs;
     float s = 0.0f;
     if (f < n_frames) {
         const float* p = partials + (size_t)tile * n_wgs * (2 * TILE_FRAMES) + (size_t)e * TILE_FRAMES + fin;
-        bool first = true;
-        for (uint32_t w = w0 + seg; w < w1; w += RED_SEGS) {
-            const float v = p[(size_t)w * (2 * TILE_FRAMES)];
-            s = first ? v : s + v;
-            first = false;
+        uint32_t w = seg;
+        if (w < n_wgs) { s = p[(size_t)w * (2 * TILE_FRAMES)]; w += RED_SEGS; }
+        for (; w + 7 * RED_SEGS < n_wgs; w += 8 * RED_SEGS) {
+            float v[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] = p[(size_t)(w + k * RED_SEGS) * (2 * TILE_FRAMES)];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) s = s + v[k];
         }
+        for (; w < n_wgs; w += RED_SEGS) s = s + p[(size_t)w * (2 * TILE_FRAMES)];
     }
     red[seg][ox] = s;
     __syncthreads();
     if (seg == 0 && f < n_frames) {
         float t = red[0][ox];
-        const uint32_t have = w1 > w0 ? w1 - w0 : 0;
-        const uint32_t nseg = have < RED_SEGS ? have : RED_SEGS;
+        const uint32_t nseg = n_wgs < (uint32_t)RED_SEGS ? n_wgs : (uint32_t)RED_SEGS;
         for (uint32_t k = 1; k < nseg; ++k) t = t + red[k][ox];
-        stage1[(size_t)blockIdx.y * (2 * n_frames) + 2 * f + e] = have ? t : 0.0f;
+        out[2 * f + e] = postfx_apply(n_wgs ? t : 0.0f, postfx);
     }
-}
-
-// stage 2: out[o] = stage1[0][o] + stage1[1][o] + ... (fixed order), then Reinhard / Tanh
-__device__ __forceinline__ void reduce_stage2_body(const float* __restrict__ stage1, float* __restrict__ out,
-                                                   uint32_t n_wgs, uint32_t n_frames, int postfx) {
-    const uint32_t o = blockIdx.x * blockDim.x + threadIdx.x;
-    const uint32_t n_out = 2 * n_frames;
-    if (o >= n_out) return;
-    const uint32_t per = (n_wgs + RED_SPLIT - 1) / RED_SPLIT;
-    const uint32_t used = (n_wgs + per - 1) / per;        // slices that saw at least one workgroup
-    float t = stage1[o];
-    for (uint32_t k = 1; k < used; ++k) t = t + stage1[(size_t)k * n_out + o];
-    out[o] = postfx_apply(t, postfx);
 }
 
 __global__ void postfx_kernel(float* __restrict__ buf, uint32_t n, int postfx) {

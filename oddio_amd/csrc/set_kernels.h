@@ -50,7 +50,7 @@ template <class S, class D> struct CompactArgs {
     uint32_t* stopped_hdr;      // [0] = number of sources the walk stopped this callback, [1..] their handle ids (first `cap`;
     uint32_t cap;               //   when more stopped, every slot's flags are scanned instead)
     S* st; D* dyn; SrcPending* pend;
-    uint32_t* d_len;            // [0] live length, [1] cumulative inserts
+    uint32_t* d_len;            // [0] live length, [1] cumulative inserts, [2] cumulative removals, [3] inserts last published
     uint32_t* slot_of_id;
     uint32_t set_index;         // 0 seekable, 1 buffered
     uint32_t* removed_ring; uint32_t ring_mask;
@@ -67,7 +67,7 @@ __device__ void compact_set_block(const CompactArgs<S, D>& A) {
     const uint32_t set_bit = A.set_index ? SLOT_BUFFERED_BIT : 0u;
     const uint32_t count = A.stopped_hdr[0];
     uint32_t len = A.d_len[0];
-    uint32_t total = A.pub->removed_total[A.set_index];
+    uint32_t total = A.d_len[2];
     __syncthreads();
     // remove slot s (block-uniform): the last element moves into it (Vec::swap_remove)
     auto remove_slot = [&](uint32_t s) {
@@ -119,27 +119,32 @@ __device__ void compact_set_block(const CompactArgs<S, D>& A) {
         }
     }
     if (tid == 0) {
-        A.d_len[0] = len;
-        A.stopped_hdr[0] = 0u;                               // re-armed for the next callback
-        __threadfence_system();
-        A.pub->removed_total[A.set_index] = total;
-        A.pub->len_and_inserted[A.set_index] = (uint64_t)len | ((uint64_t)A.d_len[1] << 32);
-        __threadfence_system();
+        const uint32_t inserted = A.d_len[1];
+        if (count > 0 || inserted != A.d_len[3]) {           // nothing removed, nothing inserted: the host's view is current
+            A.d_len[0] = len;
+            A.d_len[2] = total;
+            A.d_len[3] = inserted;
+            A.stopped_hdr[0] = 0u;                           // re-armed for the next callback
+            __threadfence_system();
+            A.pub->removed_total[A.set_index] = total;
+            A.pub->len_and_inserted[A.set_index] = (uint64_t)len | ((uint64_t)inserted << 32);
+            __threadfence_system();
+        }
     }
 }
 
 template <class S, class D>
 __global__ __launch_bounds__(256) void compact_set(CompactArgs<S, D> A) { compact_set_block(A); }
 
-// The callback's last kernel: the fixed-order sum of the stage-1 slices + Reinhard / Tanh (blocks
+// The callback's last kernel: the fixed-order sum of the workgroup partial tiles + Reinhard / Tanh (blocks
 // [0, n_red)), and -- in two extra blocks that need nothing from the others -- set.remove() of what the walk
-// stopped (spatial.rs:258-261), so that compaction costs no launch of its own.
-__global__ __launch_bounds__(256) void reduce_stage2_compact(const float* __restrict__ stage1, float* __restrict__ out, uint32_t n_wgs,
-                                                             uint32_t n_frames, int postfx, uint32_t n_red,
-                                                             CompactArgs<SrcStatic, SrcDyn> seek, CompactArgs<BufStatic, BufDyn> buf) {
+// stopped (spatial.rs:258-261), so that neither a second reduce stage nor compaction costs a launch of its own.
+__global__ __launch_bounds__(256) void reduce_partials_compact(const float* __restrict__ partials, float* __restrict__ out, uint32_t n_wgs,
+                                                               uint32_t n_frames, int postfx, uint32_t n_red,
+                                                               CompactArgs<SrcStatic, SrcDyn> seek, CompactArgs<BufStatic, BufDyn> buf) {
     if (blockIdx.x == n_red) { compact_set_block(seek); return; }
     if (blockIdx.x == n_red + 1u) { compact_set_block(buf); return; }
-    reduce_stage2_body(stage1, out, n_wgs, n_frames, postfx);
+    reduce_partials_body(partials, out, n_wgs, n_frames, postfx, blockIdx.x);
 }
 
 // Motion updates carry handle ids (spatial.rs:137-149: the handle, not the set position)
