@@ -284,11 +284,12 @@ __global__ __launch_bounds__(64) void mixer_general_sources(uint32_t n_sources, 
                                                             BufStatic* __restrict__ st, BufDyn* __restrict__ dyn,
                                                             float* __restrict__ slabs, uint32_t* __restrict__ skip,
                                                             uint32_t* __restrict__ stopped_hdr, uint32_t stopped_cap,
-                                                            FaderRec* __restrict__ faders, float* __restrict__ fader_scratch) {
+                                                            FaderRec* __restrict__ faders, float* __restrict__ fader_scratch, int skip_wave_shapes) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_sources) return;
     BufDyn d = dyn[i];
     BufStatic s = st[i];
+    if (skip_wave_shapes && buffered_wave_eligible(s)) return;   // mixer_general_sources_wave renders these
     if (d.common.flags & MIXDYN_STOPPED) { skip[i] = 1; return; }
     bool fin = (d.common.flags & MIXDYN_STOP_REQUESTED) != 0;                                                   // mixer.rs:102
     if (!s.fader) {   // Fader::is_finished is always false (fader.rs:76-79)
@@ -315,6 +316,43 @@ __global__ __launch_bounds__(64) void mixer_general_sources(uint32_t n_sources, 
     if (s.fader) st[i] = s;   // a completed fade swapped the signals
 }
 
+// The common general shape -- filters over a mono FramesSignal (MonoToStereo<Gain<FramesSignal>>, ...) -- one wave per
+// source: scanner lanes replay the exact f32 running sums (leaf cursor, Gain progress) and drop a checkpoint every
+// 16 frames, then 64 lanes expand 16 frames each (inner_sample_wave, buffered_kernels.h).  Same per-source sequence
+// as mixer_general_sources (mixer.rs:100-117), same slab, bit-identical samples.
+__global__ __launch_bounds__(64) void mixer_general_sources_wave(uint32_t n_sources, uint32_t n_frames, float interval,
+                                                                 const BufStatic* __restrict__ st, BufDyn* __restrict__ dyn,
+                                                                 float* __restrict__ slabs, uint32_t* __restrict__ skip,
+                                                                 uint32_t* __restrict__ stopped_hdr, uint32_t stopped_cap) {
+    __shared__ float ck[8][64];
+    const uint32_t i = blockIdx.x;
+    const int lane = threadIdx.x;
+    if (i >= n_sources) return;
+    const BufStatic s = st[i];
+    if (!buffered_wave_eligible(s)) return;
+    BufDyn d = dyn[i];
+    if (d.common.flags & MIXDYN_STOPPED) { if (lane == 0) skip[i] = 1; return; }
+    const bool fin = (d.common.flags & MIXDYN_STOP_REQUESTED) != 0                                                  // mixer.rs:102
+                     || d.common.t >= (double)(s.clip_len - 1u) / (double)s.clip_rate;                              // frames.rs:204-206
+    if (fin) {
+        if (lane == 0) {
+            d.common.flags |= MIXDYN_STOPPED;
+            const uint32_t k = atomicAdd(&stopped_hdr[0], 1u);
+            if (k < stopped_cap) stopped_hdr[1 + k] = d.common.id;
+            skip[i] = 1;
+            dyn[i] = d;
+        }
+        return;
+    }
+    if (lane == 0) skip[i] = 0;
+    float* my = slabs + (size_t)i * 2 * n_frames;
+    for (uint32_t done = 0; done < n_frames; done += 1024u) {                                                       // mixer.rs:109-117
+        const uint32_t len = (n_frames - done) < 1024u ? (n_frames - done) : 1024u;
+        inner_sample_wave(s, d, interval, my + done, len, ck, lane);
+    }
+    if (lane == 0) dyn[i] = d;
+}
+
 __global__ void mixer_general_reduce(const float* __restrict__ slabs, const uint32_t* __restrict__ skip, const BufStatic* __restrict__ st,
                                      uint32_t n_sources, uint32_t n_frames, float* __restrict__ out, int postfx) {
     const uint32_t o = blockIdx.x * blockDim.x + threadIdx.x;
@@ -327,6 +365,49 @@ __global__ void mixer_general_reduce(const float* __restrict__ slabs, const uint
         const float v = (st[i].channels == 2) ? my[2 * f + ch] : my[f];   // MonoToStereo: duplicate (signal.rs:73-80)
         s = s + v;                                                          // frame::mix, mixer.rs:114-116
     }
+    out[o] = postfx_apply(s, postfx);
+}
+
+// The same sum for many sources: grid = (ceil(n_out / 64), n_slices), block = 256.  Slice k adds slots
+// [k*per, (k+1)*per) in descending order (rows staged through LDS 64 at a time, so that the sequential adds do
+// not wait for HBM one by one); mixer_general_reduce_finish adds the slices, last slice first, and applies the
+// post filter.  ORDERED mode uses ONE slice: the reference's exact sequence (mixer.rs:100-117).
+constexpr int MIXRED_ROWS = 64;
+__global__ __launch_bounds__(256) void mixer_general_reduce_tiled(const float* __restrict__ slabs, const uint32_t* __restrict__ skip,
+                                                                  const BufStatic* __restrict__ st, uint32_t n_sources, uint32_t n_frames,
+                                                                  float* __restrict__ part, uint32_t n_slices) {
+    __shared__ float tile[MIXRED_ROWS][65];
+    __shared__ uint32_t sk[MIXRED_ROWS];
+    const uint32_t n_out = 2 * n_frames;
+    const uint32_t ox = threadIdx.x & 63, sy = threadIdx.x >> 6;
+    const uint32_t o = blockIdx.x * 64 + ox;
+    const uint32_t per = (n_sources + n_slices - 1) / n_slices;
+    const uint32_t lo = blockIdx.y * per;
+    uint32_t hi = lo + per < n_sources ? lo + per : n_sources;
+    float s = 0.0f;
+    while (hi > lo) {
+        const uint32_t base = hi - lo >= (uint32_t)MIXRED_ROWS ? hi - MIXRED_ROWS : lo;
+        const uint32_t cnt = hi - base;
+        for (uint32_t r = sy; r < cnt; r += 4) {
+            const float* my = slabs + (size_t)(base + r) * n_out;
+            tile[r][ox] = o < n_out ? ((st[base + r].channels == 2) ? my[o] : my[o >> 1]) : 0.0f;   // MonoToStereo: duplicate (signal.rs:73-80)
+        }
+        if (threadIdx.x < cnt) sk[threadIdx.x] = skip[base + threadIdx.x];
+        __syncthreads();
+        if (sy == 0)
+            for (uint32_t r = cnt; r-- > 0;)
+                if (!sk[r]) s = s + tile[r][ox];                                                     // frame::mix, mixer.rs:114-116
+        __syncthreads();
+        hi = base;
+    }
+    if (sy == 0 && o < n_out) part[(size_t)blockIdx.y * n_out + o] = s;
+}
+__global__ void mixer_general_reduce_finish(const float* __restrict__ part, uint32_t n_slices, uint32_t n_frames, float* __restrict__ out, int postfx) {
+    const uint32_t o = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t n_out = 2 * n_frames;
+    if (o >= n_out) return;
+    float s = part[(size_t)(n_slices - 1) * n_out + o];          // the walk starts at the last slot
+    for (uint32_t k = n_slices - 1; k-- > 0;) s = s + part[(size_t)k * n_out + o];
     out[o] = postfx_apply(s, postfx);
 }
 

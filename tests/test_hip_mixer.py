@@ -173,3 +173,60 @@ def test_mixer_general_vs_oracle():
         assert len(mixer) == len(cm)
         assert [h.is_stopped() for h in hs] == [h.is_stopped() for h in hc]
     mixer.close()
+
+
+@pytest.mark.parametrize("mode", ["ordered", "fast"])
+def test_mixer_general_many_sources(mode):
+    """300 filtered sources (wave-per-source kernel + tiled slab sum) beside a few shapes the thread-per-source kernel
+    renders; clips of different lengths finish inside the run.  ORDERED: bit-exact; FAST: only the sum order differs."""
+    import oddio_amd as oa
+    control, mixer = oa.Mixer(max_sources=512, max_frames=1024)
+    mixer.set_mode(oa.MODE_ORDERED if mode == "ordered" else oa.MODE_FAST)
+    cm = oc.Mixer(2)
+    rng = np.random.default_rng(5)
+    ctl = []
+    for i in range(300):
+        clip = synth.noise_clip(21, i, 2500 + 37 * i)
+        rate = (48000, 44100, 32000)[i % 3]
+        t0 = float(np.float32(rng.uniform(0.0, 0.01)))
+        if i % 4 == 0:
+            ch, sig = oa.Speed.new(oa.FramesSignal(oa.Frames.from_slice(rate, clip), t0))
+            osig = oc.Speed(oc.FramesSignal(oc.Frames(rate, clip), t0))
+            gh, sig = oa.Gain.new(oa.MonoToStereo(sig)); og = oc.Gain(oc.MonoToStereo(osig))
+            ctl.append((ch, osig, "speed")); ctl.append((gh, og, "gain"))
+            control.play(sig); cm.play(og)
+        else:
+            gh, sig = oa.Gain.new(oa.MonoToStereo(oa.FixedGain(oa.FramesSignal(oa.Frames.from_slice(rate, clip), t0), -3.0)))
+            og = oc.Gain(oc.MonoToStereo(oc.FixedGain(oc.FramesSignal(oc.Frames(rate, clip), t0), -3.0)))
+            ctl.append((gh, og, "gain"))
+            control.play(sig); cm.play(og)
+    # shapes outside the wave kernel (thread-per-source): Constant leaf, stereo clip, Cycle
+    gh, sig = oa.Gain.new(oa.MonoToStereo(oa.Constant(0.125))); og = oc.Gain(oc.MonoToStereo(oc.Constant(0.125)))
+    ctl.append((gh, og, "gain")); control.play(sig); cm.play(og)
+    stereo = np.stack([synth.noise_clip(22, 0, 9000), synth.noise_clip(22, 1, 9000)], axis=1)
+    gh, sig = oa.Gain.new(oa.FramesSignal(oa.Frames.from_slice(44100, stereo), 0.0)); og = oc.Gain(oc.FramesSignal(oc.Frames(44100, stereo), 0.0))
+    ctl.append((gh, og, "gain")); control.play(sig); cm.play(og)
+    cyc = synth.noise_clip(23, 0, 555)
+    sh, sig = oa.Speed.new(oa.MonoToStereo(oa.Cycle(oa.Frames.from_slice(32000, cyc)))); osd = oc.Speed(oc.MonoToStereo(oc.Cycle(oc.Frames(32000, cyc))))
+    ctl.append((sh, osd, "speed")); control.play(sig); cm.play(osd)
+    interval = np.float32(1.0) / np.float32(48000)
+    for cb in range(6):
+        if cb in (1, 3):
+            for j in range(0, len(ctl), 7):
+                h, o, kind = ctl[j]
+                if kind == "gain":
+                    v = float(np.float32(rng.uniform(0.2, 1.5)))
+                    h.set_amplitude_ratio(v); o.set_amplitude_ratio(v)
+                else:
+                    v = float(np.float32(rng.uniform(0.8, 1.3)))
+                    h.set_speed(v); o.set_speed(v)
+        n = (1024, 1024, 600, 1024, 1024, 1024)[cb]
+        got = mixer.sample_n(interval, n)
+        ref = cm.sample_n(interval, n)
+        if mode == "ordered":
+            np.testing.assert_array_equal(got, ref, err_msg=f"callback {cb}")
+        else:
+            np.testing.assert_allclose(got, ref, rtol=0, atol=2e-4, err_msg=f"callback {cb}")   # ~300 terms of |x| < 1.5
+        assert len(mixer) == len(cm)
+    assert len(cm) < 303      # some clips ended inside the run
+    mixer.close()
