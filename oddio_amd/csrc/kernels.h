@@ -236,65 +236,6 @@ __device__ __forceinline__ double f64_rem_euclid(double a, double b) {   // core
 }
 
 // ---------------------------------------------------------------------------------------------
-// Cycle in the Seek set (cycle.rs:26-60 inside spatial.rs:446-468), one thread per slot.
-// Cycle::sample leaves `cursor = base + offset` with the f32-accumulated offset, and the scene
-// seeks it back and forth between the ears, so every chunk's start depends on the rounding of all
-// the chunks before it (left ear first): the source is rendered serially.  The thread writes the
-// source's finished contribution s * gain (spatial.rs:459-460) to its row; spatial_mix adds the row
-// at the source's place in the set walk, so ORDERED mode stays bit-exact.
-// ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void cycle_sources(SceneParams P, const SrcStatic* __restrict__ st, SrcDyn* __restrict__ dyn,
-                                                    const EarParams* __restrict__ ear, const uint32_t* __restrict__ d_len) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= d_len[0]) return;
-    const SrcStatic s = st[i];
-    if (s.kind != KIND_CYCLE) return;
-    const EarParams e0 = ear[2 * i], e1 = ear[2 * i + 1];
-    if (e0.flags & EAR_SKIP) return;
-    double cursor = dyn[i].t;
-    const double rate = (double)s.clip_rate, lenf = (double)s.clip_len;
-    const size_t len = s.clip_len;
-    const uint32_t n = P.n_frames;
-    float* row = P.cycle_rows + (size_t)__float_as_uint(s.freq_or_value) * 2u * P.cycle_plane;
-    for (int e = 0; e < 2; ++e) {
-        const EarParams ep = e ? e1 : e0;
-        const float off0 = ep.phase_ear, eff = (float)ep.t_ear;
-        float* plane = row + (size_t)e * P.cycle_plane;
-        cursor = f64_rem_euclid(cursor + (double)off0 * rate, lenf);          // spatial.rs:449 -> cycle.rs:57-60
-        const float ds = ep.dt * (float)s.clip_rate;                          // cycle.rs:27
-        uint32_t frame = 0;
-        for (uint32_t done = 0; done < n; done += 256u) {                     // spatial.rs:456
-            const uint32_t len_c = (n - done) < 256u ? (n - done) : 256u;
-            size_t base = (size_t)f64_as_isize(cursor);                       // cycle.rs:28
-            float offset = (float)(cursor - (double)base);                    // :29
-            for (uint32_t k = 0; k < len_c; ++k, ++frame) {
-                const size_t trunc = (size_t)offset;
-                const float fract = offset - (float)trunc;
-                const size_t x = base + trunc;
-                size_t ia, ib;
-                if (x < len - 1) { ia = x; ib = x + 1; }
-                else if (x < len) { ia = x; ib = 0; }
-                else {
-                    base = 0;
-                    offset = (float)(x % len) + fract;
-                    const size_t x2 = (size_t)offset;
-                    if (x2 < len - 1) { ia = x2; ib = x2 + 1; } else { ia = x2; ib = 0; }
-                }
-                const float a = s.clip[ia], b = s.clip[ib];
-                float v = a + fract * (b - a);                                // frame::lerp
-                v = v * s.fixed_gain;                                         // FixedGain, gain.rs:32-37
-                plane[frame] = v * (ep.g0 + (float)frame * ep.dg);            // spatial.rs:459-460
-                offset = offset + ds;
-            }
-            cursor = (double)base + (double)offset;                           // cycle.rs:52
-        }
-        cursor = f64_rem_euclid(cursor + (double)(-eff - off0) * rate, lenf); // spatial.rs:465
-    }
-    cursor = f64_rem_euclid(cursor + (double)P.elapsed * rate, lenf);         // spatial.rs:468
-    dyn[i].t = cursor;
-}
-
-// ---------------------------------------------------------------------------------------------
 // mix kernel
 // ---------------------------------------------------------------------------------------------
 // Shape (measured on MI355X: tools/ubench/valu_rate.hip, hbm_ceiling.hip and the PMC passes under
@@ -379,6 +320,118 @@ __device__ __forceinline__ float rl_f(float v, int lane) {
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
 }
 __device__ __forceinline__ int rl_i(int v, int lane) { return __builtin_amdgcn_readlane(v, lane); }
+
+// ---------------------------------------------------------------------------------------------
+// Cycle in the Seek set (cycle.rs:26-60 inside spatial.rs:446-468), one wave per slot.
+// Cycle::sample leaves `cursor = base + offset` with the f32-accumulated offset, and the scene
+// seeks it back and forth between the ears, so every chunk's start depends on the rounding of all
+// the chunks before it (left ear first).  Lane 0 replays that cursor arithmetic alone (no memory
+// reads) and drops a (base, offset) checkpoint every 16 frames; the 64 lanes then restart from
+// their checkpoints with the same step function and render 16 frames each.  The wave writes the
+// source's finished contribution s * gain (spatial.rs:459-460) to its row; spatial_mix adds the row
+// at the source's place in the set walk, so ORDERED mode stays bit-exact.
+// ---------------------------------------------------------------------------------------------
+// one frame of cycle.rs:30-50: the pair to interpolate and its fraction; advances (base, offset)
+// (`offset as usize`: negative and NaN -> 0.  Clips are shorter than 2^30 samples (oddio_hip_scene_play_cycle) and
+// offset stays below len + 256 * ds, so base + trunc fits 32 bits: one v_cvt_u32_f32 and 32-bit compares instead of
+// 64-bit sequences in the 2048-step serial scan.  The clamp at 2^31 is never reached.)
+__device__ __forceinline__ uint32_t f32_as_index(float x) { return (uint32_t)fminf(fmaxf(x, 0.0f), 2147483648.0f); }
+__device__ __forceinline__ void cycle_step(uint32_t& base, float& offset, uint32_t len, float ds, uint32_t& ia, uint32_t& ib, float& fract) {
+    const uint32_t trunc = f32_as_index(offset);
+    fract = offset - (float)trunc;
+    const uint32_t x = base + trunc;
+    if (x < len - 1u) { ia = x; ib = x + 1u; }
+    else if (x < len) { ia = x; ib = 0u; }
+    else {
+        base = 0u;
+        offset = (float)(x % len) + fract;
+        const uint32_t x2 = f32_as_index(offset);
+        if (x2 < len - 1u) { ia = x2; ib = x2 + 1u; } else { ia = x2; ib = 0u; }
+    }
+    offset = offset + ds;
+}
+
+constexpr int CYCLE_WAVES = 4;   // slots per workgroup (independent waves)
+__global__ __launch_bounds__(64 * CYCLE_WAVES) void cycle_sources(SceneParams P, const SrcStatic* __restrict__ st, SrcDyn* __restrict__ dyn,
+                                                                 const EarParams* __restrict__ ear, const uint32_t* __restrict__ d_len) {
+    __shared__ uint32_t ck_base[CYCLE_WAVES][64];
+    __shared__ float ck_off[CYCLE_WAVES][64];
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const uint32_t i = blockIdx.x * CYCLE_WAVES + (uint32_t)wv;
+    if (i >= d_len[0]) return;
+    const SrcStatic s = st[i];
+    if (s.kind != KIND_CYCLE) return;
+    const EarParams e0 = ear[2 * i], e1 = ear[2 * i + 1];
+    if (e0.flags & EAR_SKIP) return;
+    double cursor = dyn[i].t;                                                 // meaningful in lane 0 from here on
+    const double rate = (double)s.clip_rate, lenf = (double)s.clip_len;
+    const uint32_t len = s.clip_len;
+    const uint32_t n = P.n_frames;
+    float* row = P.cycle_rows + (size_t)__float_as_uint(s.freq_or_value) * 2u * P.cycle_plane;
+    for (int e = 0; e < 2; ++e) {
+        const EarParams ep = e ? e1 : e0;
+        const float off0 = ep.phase_ear, eff = (float)ep.t_ear;
+        float* plane = row + (size_t)e * P.cycle_plane;
+        const float ds = ep.dt * (float)s.clip_rate;                          // cycle.rs:27
+        if (lane == 0) cursor = f64_rem_euclid(cursor + (double)off0 * rate, lenf);   // spatial.rs:449 -> cycle.rs:57-60
+        for (uint32_t pass0 = 0; pass0 < n; pass0 += 1024u) {
+            const uint32_t m = (n - pass0) < 1024u ? (n - pass0) : 1024u;
+            if (lane == 0) {
+                for (uint32_t done = 0; done < m; done += 256u) {             // spatial.rs:456
+                    const uint32_t len_c = (m - done) < 256u ? (m - done) : 256u;
+                    uint32_t base = (uint32_t)f64_as_isize(cursor);           // cycle.rs:28 (0 <= cursor < len + 256 * ds)
+                    float offset = (float)(cursor - (double)base);            // :29
+                    for (uint32_t k0 = 0; k0 < len_c; k0 += 16u) {
+                        ck_base[wv][(done + k0) >> 4] = base; ck_off[wv][(done + k0) >> 4] = offset;
+                        uint32_t ia, ib; float fract;
+                        if (len_c - k0 >= 16u) {
+#pragma unroll
+                            for (int k = 0; k < 16; ++k) cycle_step(base, offset, len, ds, ia, ib, fract);
+                        } else {
+                            for (uint32_t k = k0; k < len_c; ++k) cycle_step(base, offset, len, ds, ia, ib, fract);
+                        }
+                    }
+                    cursor = (double)base + (double)offset;                   // cycle.rs:52
+                }
+            }
+            wave_sync();
+            const uint32_t f0 = 16u * (uint32_t)lane;
+            if (f0 < m) {
+                const uint32_t done = f0 & ~255u;
+                const uint32_t len_c = (m - done) < 256u ? (m - done) : 256u;
+                const uint32_t cnt = (len_c - (f0 - done)) < 16u ? (len_c - (f0 - done)) : 16u;
+                uint32_t base = ck_base[wv][lane];
+                float offset = ck_off[wv][lane];
+                // the 16 index pairs first (registers only), then all the loads together, then the arithmetic
+                uint32_t ia[16], ib[16]; float fract[16], a[16], b[16];
+#pragma unroll
+                for (int k = 0; k < 16; ++k) cycle_step(base, offset, len, ds, ia[k], ib[k], fract[k]);   // steps past cnt touch nothing
+#pragma unroll
+                for (int k = 0; k < 16; ++k) {
+                    const bool on = (uint32_t)k < cnt;
+                    a[k] = on ? s.clip[ia[k]] : 0.0f;
+                    b[k] = on ? s.clip[ib[k]] : 0.0f;
+                }
+#pragma unroll
+                for (int k = 0; k < 16; ++k) {
+                    if ((uint32_t)k < cnt) {
+                        float v = a[k] + fract[k] * (b[k] - a[k]);            // frame::lerp
+                        v = v * s.fixed_gain;                                 // FixedGain, gain.rs:32-37
+                        const uint32_t frame = pass0 + f0 + (uint32_t)k;
+                        plane[frame] = v * (ep.g0 + (float)frame * ep.dg);    // spatial.rs:459-460
+                    }
+                }
+            }
+            wave_sync();   // before the next pass overwrites the checkpoints
+        }
+        if (lane == 0) cursor = f64_rem_euclid(cursor + (double)(-eff - off0) * rate, lenf);   // spatial.rs:465
+    }
+    if (lane == 0) {
+        cursor = f64_rem_euclid(cursor + (double)P.elapsed * rate, lenf);     // spatial.rs:468
+        dyn[i].t = cursor;
+    }
+}
+
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 

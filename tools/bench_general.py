@@ -1,6 +1,7 @@
 #!/usr/bin/env python
-"""Timing of the correctness-first (thread-per-source) paths: buffered spatial sources and the
-Mixer's general path.  Prints ms per 1024-frame callback for a few set sizes."""
+"""Timing of the paths beside the headline one: buffered spatial sources, the Mixer's general path, Seek-set Cycle
+sources (one wave per source since round 2).  Prints ms per 1024-frame callback through the host-output entry point
+(stream sync + 8 KiB D2H included) for a few set sizes."""
 import os
 import sys
 import time
