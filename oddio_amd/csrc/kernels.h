@@ -273,6 +273,11 @@ constexpr int MIX_WAVES_PER_CU = 16;                   // default grid size (wav
 constexpr int MIX_GROUP = 16;                // sources per phase-A step (16 x 2 ears x 2 chunks = 64 lanes)
 constexpr int TILE_FRAMES = 512;             // frames per (wave, tile) pass
 constexpr int TILE_CHUNKS = TILE_FRAMES / 256;
+#ifndef ODDIO_PART_PAD
+#define ODDIO_PART_PAD 64
+#endif
+constexpr int PART_STRIDE = 2 * TILE_FRAMES + ODDIO_PART_PAD;   // floats between workgroup partial tiles: not a power of two, so that the reduce's
+                                                                 // column reads (one float per tile) spread over the memory channels
 constexpr int WIN_CAP = 608;                 // samples staged per source and tile (ds <= ~1.11)
 constexpr int WIN_PIECES = (WIN_CAP * 4 + 1023) / 1024;   // 1 KiB DMA pieces covering a window buffer
 #ifndef ODDIO_PAD_EPS
@@ -865,7 +870,7 @@ __global__ __launch_bounds__(64 * MIX_WG_WAVES, MIX_WAVES_PER_SIMD) void spatial
 
     // ---- cross-wave reduction through LDS, fixed order (wave 0 + wave 1 + ...), then one store ----
     // partial tile is planar: [ear][512 frames]; this lane owns frames 16*(lane&31).. of ear lane>>5
-    float* dst = partials + ((size_t)tile * gridDim.x + blockIdx.x) * (2 * TILE_FRAMES) + (size_t)eB * TILE_FRAMES + 16 * (lane & 31);
+    float* dst = partials + ((size_t)tile * gridDim.x + blockIdx.x) * PART_STRIDE + (size_t)eB * TILE_FRAMES + 16 * (lane & 31);
     if (MIX_WG_WAVES == 1) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) reinterpret_cast<float4*>(dst)[q] = make_float4(acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]);
@@ -901,11 +906,12 @@ __device__ __forceinline__ float postfx_apply(float x, int postfx) {
     return x;
 }
 
-constexpr int RED_FRAMES = 4;    // output frames per reduce block: 256 threads = (4 frames x 2 ears) x 32 segments
-constexpr int RED_SEGS = 32;     // strided segments of the workgroup-partial list
+constexpr int RED_FRAMES = 8;    // output frames per reduce block: 256 threads = (8 frames x 2 ears) x 16 segments (measured: 4 -> 10.9 us, 8 -> 6.8, 16 -> 7.7, 32 -> 13.6)
+constexpr int RED_SEGS = 16;     // strided segments of the workgroup-partial list
+constexpr int RED_BATCH = 32;    // loads in flight per thread
 
-// One block sums ALL workgroup partials of its 8 outputs in a fixed order that depends only on n_wgs
-// (segment s adds workgroups s, s+32, ... in ascending order; the 32 segment sums are then added in
+// One block sums ALL workgroup partials of its 16 outputs in a fixed order that depends only on n_wgs
+// (segment s adds workgroups s, s+16, ... in ascending order; the 16 segment sums are then added in
 // ascending order), applies Reinhard / Tanh and writes the interleaved stereo frames.  With n_wgs == 1
 // (ORDERED mode) the output is that workgroup's value unchanged.
 __device__ __forceinline__ void reduce_partials_body(const float* __restrict__ partials, float* __restrict__ out, uint32_t n_wgs,
@@ -917,17 +923,21 @@ __device__ __forceinline__ void reduce_partials_body(const float* __restrict__ p
     const uint32_t tile = f / TILE_FRAMES, fin = f % TILE_FRAMES;
     float s = 0.0f;
     if (f < n_frames) {
-        const float* p = partials + (size_t)tile * n_wgs * (2 * TILE_FRAMES) + (size_t)e * TILE_FRAMES + fin;
-        uint32_t w = seg;
-        if (w < n_wgs) { s = p[(size_t)w * (2 * TILE_FRAMES)]; w += RED_SEGS; }
-        for (; w + 7 * RED_SEGS < n_wgs; w += 8 * RED_SEGS) {
-            float v[8];
+        const float* p = partials + (size_t)tile * n_wgs * PART_STRIDE + (size_t)e * TILE_FRAMES + fin;
+        // the first addend is taken as is (0.0f + x would turn a -0.0 into +0.0); the rest in batches whose loads
+        // are all in flight together (the partials were just written by other XCDs: every load is a ~1 us miss)
+        bool first = true;
+        for (uint32_t w = seg; w < n_wgs; w += RED_BATCH * RED_SEGS) {
+            float v[RED_BATCH];
 #pragma unroll
-            for (int k = 0; k < 8; ++k) v[k] = p[(size_t)(w + k * RED_SEGS) * (2 * TILE_FRAMES)];
+            for (int k = 0; k < RED_BATCH; ++k) {
+                const uint32_t wk = w + (uint32_t)k * RED_SEGS;
+                v[k] = wk < n_wgs ? p[(size_t)wk * PART_STRIDE] : 0.0f;
+            }
 #pragma unroll
-            for (int k = 0; k < 8; ++k) s = s + v[k];
+            for (int k = 0; k < RED_BATCH; ++k)
+                if (w + (uint32_t)k * RED_SEGS < n_wgs) { s = first ? v[k] : s + v[k]; first = false; }
         }
-        for (; w < n_wgs; w += RED_SEGS) s = s + p[(size_t)w * (2 * TILE_FRAMES)];
     }
     red[seg][ox] = s;
     __syncthreads();

@@ -142,6 +142,45 @@ def test_config3_ordered_mode_is_bit_exact(big):
         np.testing.assert_array_equal(got, big["ref32"][cb])
 
 
+def test_config4_per_gpu_scene_65536_vs_oracle(big):
+    """BASELINE configs[3] runs one 65 536-source SpatialScene per GPU: that scene size (a different grid shape from
+    configs[2]: fewer source groups per wavefront) against the oracle's sequential f32 and f64-accumulated sums."""
+    from oracle import oracle_c as oc
+    S = 65536
+    sc = big["sc"]
+    refs = {}
+    for acc64 in (False, True):
+        o = oc.SpatialScene()
+        o.play_frames_bulk(RATE, big["host"][:S], START, sc["position"][:S], sc["velocity"][:S], sc["radius"][:S])
+        outs = []
+        for cb in range(2):
+            if acc64:
+                outs.append(o.sample_f64acc(INTERVAL, N))
+            else:
+                out = np.zeros((N, 2), dtype=np.float32)
+                oc.run(o, RATE, out)
+                outs.append(out)
+        refs[acc64] = outs
+        del o
+    control, scene, handles, frames = play_shard(big, 0, S)
+    for cb in range(2):
+        got = scene.sample_n(INTERVAL, N)
+        ref, ref64 = refs[False][cb], refs[True][cb]
+        scale = float(np.abs(ref).max())
+        err_gpu = float(np.abs(got.astype(np.float64) - ref64).max())
+        err_ref = float(np.abs(ref.astype(np.float64) - ref64).max())
+        d_ref = float(np.abs(got - ref).max())
+        assert scale > 0
+        assert err_gpu <= 4 * err_ref + 1e-7 * scale, (cb, err_gpu / scale, err_ref / scale)
+        assert d_ref <= max(1e-5 * scale, err_gpu + err_ref + 1e-7 * scale), (cb, d_ref / scale)
+    assert len(scene) == S
+    scene.close()
+    control2, scene2, handles2, frames2 = play_shard(big, 0, S, mode=1)
+    for cb in range(2):
+        np.testing.assert_array_equal(scene2.sample_n(INTERVAL, N), refs[False][cb])   # ORDERED: the reference's bits
+    scene2.close()
+
+
 @pytest.mark.parametrize("world", [2, 8])
 def test_sharded_partials_equal_unsharded_hip(big, world):
     """configs[3]/[4] arithmetic on the HIP path: contiguous index shards rendered as separate scenes (what

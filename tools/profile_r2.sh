@@ -18,5 +18,7 @@ python tools/make_pmc_json.py "$OUT/pmc/summary.json" 262144 "$OUT/pmc_latest.js
 ./tools/ubench/hbm_ceiling > "$OUT/ubench_hbm_ceiling.txt" 2>&1
 ./tools/ubench/valu_rate > "$OUT/ubench_valu_rate.txt" 2>&1
 python tools/bench_general.py > "$OUT/bench_general.txt" 2>&1
+(cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_general" -o general -- python "$ROOT/tools/bench_general.py" > /dev/null 2> "$OUT/prof_general.log")
+python tools/event_overhead.py > "$OUT/event_overhead.txt" 2>&1
 for re in 8 32 320; do python bench.py --no-cpu-baseline --steps 128 --warmup 128 --reset-every $re 2>/dev/null | python tools/brief.py "128+128 callbacks, motion reset every $re:"; done > "$OUT/workload_drift.txt"
 ls "$OUT"
