@@ -124,21 +124,12 @@ __device__ __forceinline__ long long f64_as_isize(double x) {
 // ---------------------------------------------------------------------------------------------
 // `d_len` is the device-resident set length (set_kernels.h); `len_snap` receives the length this walk saw
 // (the mix kernel of the callback reads it; the set is compacted at the end of the callback).
-__global__ __launch_bounds__(256) void spatial_prepass(SceneParams P, const SrcStatic* __restrict__ st,
-                                                       SrcDyn* __restrict__ dyn, SrcPending* __restrict__ pend,
-                                                       EarParams* __restrict__ ear, uint32_t* __restrict__ stopped_hdr,
-                                                       uint32_t stopped_cap, int check_pending, const uint32_t* __restrict__ d_len,
-                                                       uint32_t* __restrict__ len_snap) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    const uint32_t len = d_len[0];
-    if (i == 0) *len_snap = len;
-    if (i >= len) return;
-    SrcDyn d = dyn[i];
-    const SrcStatic s = st[i];
-    EarParams e0 = {}, e1 = {};
+__device__ __forceinline__ void prepass_source(const SceneParams& P, const uint32_t i, SrcDyn& d, const SrcStatic& s,
+                                               SrcPending* __restrict__ pend, EarParams& e0, EarParams& e1,
+                                               uint32_t* __restrict__ stopped_hdr, uint32_t stopped_cap, int check_pending) {
+    e0 = EarParams{}; e1 = EarParams{};
     if (d.flags & DYN_STOPPED) {  // removed earlier, compaction not applied yet: never mixed again
         e0.flags = EAR_SKIP; e1.flags = EAR_SKIP;
-        ear[2 * i] = e0; ear[2 * i + 1] = e1;
         return;
     }
     const float elapsed = P.elapsed;
@@ -183,13 +174,12 @@ __global__ __launch_bounds__(256) void spatial_prepass(SceneParams P, const SrcS
         const uint32_t k = atomicAdd(&stopped_hdr[0], 1u);
         if (k < stopped_cap) stopped_hdr[1 + k] = d.id;
         e0.flags = EAR_SKIP; e1.flags = EAR_SKIP;
-        ear[2 * i] = e0; ear[2 * i + 1] = e1;
-        dyn[i] = d;
         return;
     }
 
     // spatial.rs:446-468: the scalar part of mix_signal; the sampling itself is the mix kernel's.
     const uint32_t n = P.n_frames;
+#pragma unroll
     for (int e = 0; e < 2; ++e) {
         float off0, g0, off1, g1;
         ear_state(p0, e, s.radius, off0, g0);
@@ -223,11 +213,10 @@ __global__ __launch_bounds__(256) void spatial_prepass(SceneParams P, const SrcS
             ep.phase_ear = off0;                        // cycle_sources replays the seeks around the chunks
             ep.t_ear = (double)eff;
         }
-        ear[2 * i + e] = ep;
+        if (e == 0) e0 = ep; else e1 = ep;
     }
     if (s.kind == KIND_FRAMES || s.kind == KIND_DOWNMIX) d.t = d.t + (double)elapsed;           // :468
     else if (s.kind == KIND_SINE) d.phase = fmodf(d.phase + elapsed * s.freq_or_value, ODDIO_TAU);
-    dyn[i] = d;
 }
 
 __device__ __forceinline__ double f64_rem_euclid(double a, double b) {   // core f64::rem_euclid
@@ -436,6 +425,79 @@ __global__ __launch_bounds__(64 * CYCLE_WAVES) void cycle_sources(SceneParams P,
         dyn[i].t = cursor;
     }
 }
+
+// ---------------------------------------------------------------------------------------------
+// prepass kernel.  The tables are arrays of 32/64-byte structs; a lane reading its own struct with 16-byte loads makes
+// every load instruction touch 64 separate lines.  The wave instead moves its 64 consecutive structs as one contiguous
+// block (16 B per lane, lane-consecutive) and transposes through LDS (row stride W+1 words: conflict-free).
+// ---------------------------------------------------------------------------------------------
+template <class T> __device__ __forceinline__ void wave_aos_load(T& out, const T* __restrict__ arr, uint32_t first, uint32_t n_valid, int lane, uint32_t* lds) {
+    constexpr int W = sizeof(T) / 4, Q = W / 4;       // words and 16-byte quads per element
+    const uint4* src = reinterpret_cast<const uint4*>(arr + first);
+#pragma unroll
+    for (int k = 0; k < Q; ++k) {
+        const int v = lane + 64 * k;                    // quad index inside the wave's block of 64 elements
+        const int el = v / Q, part = v % Q;
+        if ((uint32_t)el < n_valid) {
+            const uint4 q = src[v];
+            uint32_t* dst = lds + el * (W + 1) + part * 4;
+            dst[0] = q.x; dst[1] = q.y; dst[2] = q.z; dst[3] = q.w;
+        }
+    }
+    wave_sync();
+    uint32_t o[W];
+#pragma unroll
+    for (int w = 0; w < W; ++w) o[w] = lds[lane * (W + 1) + w];
+    __builtin_memcpy(&out, o, sizeof(T));
+    wave_sync();
+}
+template <class T> __device__ __forceinline__ void wave_aos_store(const T& in, T* __restrict__ arr, uint32_t first, uint32_t n_valid, int lane, uint32_t* lds) {
+    constexpr int W = sizeof(T) / 4, Q = W / 4;
+    uint32_t o[W];
+    __builtin_memcpy(o, &in, sizeof(T));
+#pragma unroll
+    for (int w = 0; w < W; ++w) lds[lane * (W + 1) + w] = o[w];
+    wave_sync();
+    uint4* dstg = reinterpret_cast<uint4*>(arr + first);
+#pragma unroll
+    for (int k = 0; k < Q; ++k) {
+        const int v = lane + 64 * k;
+        const int el = v / Q, part = v % Q;
+        if ((uint32_t)el < n_valid) {
+            const uint32_t* src = lds + el * (W + 1) + part * 4;
+            dstg[v] = make_uint4(src[0], src[1], src[2], src[3]);
+        }
+    }
+    wave_sync();
+}
+struct alignas(16) EarPair { EarParams e[2]; };
+
+// `d_len` is the device-resident set length (set_kernels.h); `len_snap` receives the length this walk saw
+// (the mix kernel of the callback reads it; the set is compacted at the end of the callback).
+__global__ __launch_bounds__(256) void spatial_prepass(SceneParams P, const SrcStatic* __restrict__ st,
+                                                       SrcDyn* __restrict__ dyn, SrcPending* __restrict__ pend,
+                                                       EarParams* __restrict__ ear, uint32_t* __restrict__ stopped_hdr,
+                                                       uint32_t stopped_cap, int check_pending, const uint32_t* __restrict__ d_len,
+                                                       uint32_t* __restrict__ len_snap) {
+    __shared__ uint32_t stage[4][64 * 17];
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    uint32_t* lds = stage[threadIdx.x >> 6];
+    const uint32_t len = d_len[0];
+    if (i == 0) *len_snap = len;
+    const uint32_t first = i - (uint32_t)lane;
+    if (first >= len) return;                                       // whole wave past the end
+    const uint32_t n_valid = (len - first) < 64u ? (len - first) : 64u;
+    SrcDyn d = {};
+    SrcStatic s = {};
+    wave_aos_load(d, dyn, first, n_valid, lane, lds);
+    wave_aos_load(s, st, first, n_valid, lane, lds);
+    EarPair ep = {};
+    if (i < len) prepass_source(P, i, d, s, pend, ep.e[0], ep.e[1], stopped_hdr, stopped_cap, check_pending);
+    wave_aos_store(ep, reinterpret_cast<EarPair*>(ear), first, n_valid, lane, lds);
+    wave_aos_store(d, dyn, first, n_valid, lane, lds);
+}
+
 
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
