@@ -612,9 +612,11 @@ __device__ __forceinline__ void mix_source_lds(const float* win, int wrel, float
     for (int i = 0; i < 16; ++i) {
         if (i + MIX_DEPTH < 16) ODDIO_ISSUE(i + MIX_DEPTH)
         __builtin_amdgcn_sched_barrier(0);
+        // keeps hipcc from hoisting 16 gain values out of the loop (16 VGPRs -> scratch); placed before the lerp so that
+        // the instruction after it does not read dg (hipcc pads an asm statement whose output is read next with s_nop)
+        asm volatile("" : "+v"(dg));
         float v = a[i] + fr[i] * (bb[i] - a[i]);              // frame.rs:39-41 lerp, unfused
         if (HAS_FG) v = v * fixed_gain;                       // gain.rs:32-37
-        asm volatile("" : "+v"(dg));                          // keeps hipcc from hoisting 16 gain values out of the loop (16 VGPRs -> scratch)
         const float p = v * (g0 + fi[i] * dg);                // spatial.rs:459-460
         if (FULL || frame0 + (uint32_t)i < n_frames) acc[i] = acc[i] + p;
         __builtin_amdgcn_sched_barrier(0);
