@@ -154,6 +154,27 @@ def test_fast_mode_4096_sources_tolerance():
     hb.close()
 
 
+@pytest.mark.parametrize("n_src,n_frames", [(1, 1024), (15, 1024), (17, 700), (33, 1024), (63, 512), (65, 1300), (257, 1024), (1000, 1024),
+                                            (3001, 1), (5000, 1536)])
+def test_fast_mode_ragged_sizes(n_src, n_frames):
+    """FAST mode over set sizes that leave partial source groups, partial wavefronts in the walk, one to many
+    workgroup partial tiles in the reduce, and callback lengths that are not whole 512-frame tiles."""
+    spec = scenario.random_spec(1000 + n_src, n_src, clip_len=8192, start=0.05, cube=8.0, noise=True)   # delay <= 0.04 s: reads stay inside the clip
+    ob = scenario.play_all(scenario.OracleBackend(), spec)
+    ob64 = scenario.play_all(scenario.OracleBackend(), spec)
+    hb = scenario.play_all(scenario.HipBackend(max_sources=n_src, max_frames=n_frames, mode=0), spec)
+    for cb in range(2):
+        ref = ob.sample(INTERVAL, n_frames)
+        ref64 = ob64.sample_f64(INTERVAL, n_frames)
+        got = hb.sample(INTERVAL, n_frames)
+        scale = max(float(np.abs(ref).max()), 1e-30)
+        err_gpu = float(np.abs(got.astype(np.float64) - ref64).max())
+        err_ref = float(np.abs(ref.astype(np.float64) - ref64).max())
+        assert err_gpu <= 4 * err_ref + 1e-6 * scale, (cb, err_gpu / scale, err_ref / scale)
+        assert float(np.abs(got - ref).max()) <= max(1e-5 * scale, err_gpu + err_ref + 1e-7 * scale)
+    hb.close()
+
+
 def test_fast_mode_deterministic():
     spec = scenario.random_spec(43, 600, clip_len=20480)
     outs = []
