@@ -112,6 +112,8 @@ int oddio_hip_scene_play_frames_downmix(oddio_hip_scene* scene, oddio_hip_frames
                                         double start_seconds, float fixed_gain_db,
                                         const float position[3], const float velocity[3], float radius,
                                         uint32_t* source_id);
+/* play(Cycle::new(frames)) (src/cycle.rs:17-23; optionally inside FixedGain).  Mono clips of fewer than 2^30 samples
+ * (ODDIO_HIP_EINVAL otherwise: the device replays the cursor with 32-bit index arithmetic). */
 int oddio_hip_scene_play_cycle(oddio_hip_scene* scene, oddio_hip_frames* frames, float fixed_gain_db,
                                const float position[3], const float velocity[3], float radius,
                                uint32_t* source_id);
