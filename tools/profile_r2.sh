@@ -15,7 +15,9 @@ rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof" -o final -- 
 cd "$ROOT"
 tools/profile_pmc.sh $TAG/pmc --steps 8 --warmup 2 --no-cpu-baseline --precondition-ms 0 > "$OUT/pmc.log" 2>&1
 python tools/make_pmc_json.py "$OUT/pmc/summary.json" 262144 "$OUT/pmc_latest.json" >> "$OUT/pmc.log" 2>&1
+make -C tools/ubench -s all > /dev/null 2>&1
 ./tools/ubench/hbm_ceiling > "$OUT/ubench_hbm_ceiling.txt" 2>&1
+./tools/ubench/dma_probe > "$OUT/ubench_dma_probe.txt" 2>&1
 ./tools/ubench/valu_rate > "$OUT/ubench_valu_rate.txt" 2>&1
 python tools/bench_general.py > "$OUT/bench_general.txt" 2>&1
 (cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_general" -o general -- python "$ROOT/tools/bench_general.py" > /dev/null 2> "$OUT/prof_general.log")
