@@ -712,12 +712,16 @@ __device__ __noinline__ void mix_source_rare(float* acc_lds, int lane, uint32_t 
 // grid = (n_workgroups, n_tiles); block = 64 * MIX_WG_WAVES.  Wave w walks groups [g_lo, g_hi) of
 // 16 slots in DESCENDING order (the reference's reverse set walk, spatial.rs:204).  A workgroup
 // leaves ONE partial tile: partials[(tile * n_wgs + wg) * 1024 + e * 512 + f] (planar L | R).
-template <bool FULL>
+// STORE (ORDERED mode at scale): instead of accumulating, every source's contribution `s * gain` (spatial.rs:459-460)
+// is written to its own row contrib[(source * 2 + ear) * contrib_fp + frame]; ordered_sum then adds the rows in the
+// reference's order.  `partials` / `init` are unused there.
+template <bool FULL, bool STORE = false>
 __global__ __launch_bounds__(64 * MIX_WG_WAVES, MIX_WAVES_PER_SIMD) void spatial_mix(SceneParams P, const SrcStatic* __restrict__ st,
                                                                                      const EarParams* __restrict__ ear,
                                                                                      float* __restrict__ partials, const float* __restrict__ init,
                                                                                      uint32_t groups_per_wave, uint32_t n_groups,
-                                                                                     const uint32_t* __restrict__ n_sources_ptr) {
+                                                                                     const uint32_t* __restrict__ n_sources_ptr,
+                                                                                     float* __restrict__ contrib, uint32_t contrib_fp) {
     __shared__ __attribute__((aligned(16))) unsigned char smem_all[LDS_TOTAL * MIX_WG_WAVES];
     const uint32_t n_sources = *n_sources_ptr;   // the set length this callback's walk saw (n_groups is the host's upper bound)
     const int wv = threadIdx.x >> 6;
@@ -738,7 +742,7 @@ __global__ __launch_bounds__(64 * MIX_WG_WAVES, MIX_WAVES_PER_SIMD) void spatial
     const float fbase = (float)frame0;
 #pragma unroll
     for (int k = 0; k < 16; ++k) { acc[k] = 0.0f; fi[k] = fbase + (float)k; }   // `i as f32` (spatial.rs:459)
-    if (init != nullptr && wave == 0) {
+    if (!STORE && init != nullptr && wave == 0) {
         // the buffered set is walked before the seekable one (spatial.rs:395-438): its sum is the
         // value the first source of this walk is added to
 #pragma unroll
@@ -891,6 +895,18 @@ __global__ __launch_bounds__(64 * MIX_WG_WAVES, MIX_WAVES_PER_SIMD) void spatial
         }                                                                                                                 \
         buf ^= 1;                                                                                                         \
     }
+        // STORE: the accumulators hold exactly one source's contribution (0 + p); write the row, start the next from zero
+        // (a skipped source -- stopped, or no frames in this tile -- leaves a row of zeros: x + 0.0 == x for every x the
+        // running sum can hold, which is never -0.0)
+#define ODDIO_EMIT(J)                                                                                                     \
+    if (STORE) {                                                                                                          \
+        const uint32_t src_ = g * MIX_GROUP + (uint32_t)(J);                                                              \
+        if (src_ < n_sources) {                                                                                           \
+            float4* row_ = reinterpret_cast<float4*>(contrib + ((size_t)src_ * 2 + (size_t)eB) * contrib_fp + frame0);    \
+            _Pragma("unroll") for (int q = 0; q < 4; ++q) row_[q] = make_float4(acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]); \
+        }                                                                                                                 \
+        _Pragma("unroll") for (int k = 0; k < 16; ++k) acc[k] = 0.0f;                                                     \
+    }
         if (pending >= 0) ODDIO_ISSUE_WINDOW(pending, buf)
         if (rare_mask == 0) {
             // the common group: staged sources only (kept apart so that the out-of-line paths' register
@@ -898,15 +914,16 @@ __global__ __launch_bounds__(64 * MIX_WG_WAVES, MIX_WAVES_PER_SIMD) void spatial
 #pragma unroll 1
             for (int j = MIX_GROUP - 1; j >= 0; --j) {
                 const int4 sj = *reinterpret_cast<const int4*>(sinfo + j * 8);
-                if (__builtin_amdgcn_readfirstlane(sj.x) != PATH_LDS) continue;
+                if (__builtin_amdgcn_readfirstlane(sj.x) != PATH_LDS) { ODDIO_EMIT(j) continue; }
                 ODDIO_STAGED_SOURCE(j, sj)
+                ODDIO_EMIT(j)
             }
         } else {
 #pragma unroll 1
             for (int j = MIX_GROUP - 1; j >= 0; --j) {
                 const int4 sj = *reinterpret_cast<const int4*>(sinfo + j * 8);
                 const int path_j = __builtin_amdgcn_readfirstlane(sj.x);
-                if (path_j == PATH_SKIP) continue;
+                if (path_j == PATH_SKIP) { ODDIO_EMIT(j) continue; }
                 if (path_j == PATH_LDS) {
                     ODDIO_STAGED_SOURCE(j, sj)
                 } else {
@@ -925,13 +942,16 @@ __global__ __launch_bounds__(64 * MIX_WG_WAVES, MIX_WAVES_PER_SIMD) void spatial
                     wave_sync();
                     if (pending >= 0) ODDIO_ISSUE_WINDOW(pending, buf)
                 }
+                ODDIO_EMIT(j)
             }
         }
+#undef ODDIO_EMIT
 #undef ODDIO_STAGED_SOURCE
 #undef ODDIO_ISSUE_WINDOW
         wave_sync();   // before the next group's phase A overwrites ckpt/cinfo
     }
 
+    if (STORE) return;
     // ---- cross-wave reduction through LDS, fixed order (wave 0 + wave 1 + ...), then one store ----
     // partial tile is planar: [ear][512 frames]; this lane owns frames 16*(lane&31).. of ear lane>>5
     float* dst = partials + ((size_t)tile * gridDim.x + blockIdx.x) * PART_STRIDE + (size_t)eB * TILE_FRAMES + 16 * (lane & 31);
@@ -1011,6 +1031,61 @@ __device__ __forceinline__ void reduce_partials_body(const float* __restrict__ p
         for (uint32_t k = 1; k < nseg; ++k) t = t + red[k][ox];
         out[2 * f + e] = postfx_apply(n_wgs ? t : 0.0f, postfx);
     }
+}
+
+// ORDERED mode at scale, second half: out[f][e] = ((init + row[len-1]) + row[len-2]) + ... + row[0] -- the
+// reference's sequential f32 sum in its reverse set walk (spatial.rs:204,460), one lane per output.  The chain of
+// `len` dependent adds per output is the whole cost, so the rows are streamed ahead of it: 4 waves fetch the next
+// ORD_ROWS x 64 tile into registers while wave 0 adds the current one from LDS.
+// grid = (ceil(n_frames / 64), 2 ears), block = 256.
+constexpr int ORD_ROWS = 128;
+__global__ __launch_bounds__(256) void ordered_sum(const float* __restrict__ contrib, uint32_t contrib_fp, const uint32_t* __restrict__ n_sources_ptr,
+                                                   uint32_t n_frames, const float* __restrict__ init, float* __restrict__ out, int postfx) {
+    __shared__ float tile[2][ORD_ROWS][64];   // lanes walk along a row in both directions: no padding needed
+    const uint32_t col = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const uint32_t f = blockIdx.x * 64 + col, e = blockIdx.y;
+    const uint32_t n = *n_sources_ptr;
+    const float* colp = contrib + (size_t)e * contrib_fp + f;            // + source * 2 * contrib_fp
+    constexpr int PER = ORD_ROWS / 4;                                     // rows each wave fetches per tile
+    float v[PER];
+    float s = (init != nullptr && f < n_frames) ? init[2 * f + e] : 0.0f; // the buffered set's sum (walked first, spatial.rs:395-438)
+    uint32_t hi = n;
+    uint32_t base = hi >= (uint32_t)ORD_ROWS ? hi - ORD_ROWS : 0u, cnt = hi - base;
+    auto fetch = [&](uint32_t b, uint32_t c) {
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+            const uint32_t r = wv * PER + (uint32_t)k;
+            v[k] = r < c ? colp[(size_t)(b + r) * 2 * contrib_fp] : 0.0f;
+        }
+    };
+    auto stash = [&](int buf) {
+#pragma unroll
+        for (int k = 0; k < PER; ++k) tile[buf][wv * PER + k][col] = v[k];
+    };
+    if (cnt) { fetch(base, cnt); stash(0); }
+    __syncthreads();
+    int cur = 0;
+    while (cnt) {
+        const uint32_t hi2 = base;
+        const uint32_t base2 = hi2 >= (uint32_t)ORD_ROWS ? hi2 - ORD_ROWS : 0u, cnt2 = hi2 - base2;
+        if (cnt2) fetch(base2, cnt2);                                     // in flight while wave 0 adds
+        if (wv == 0) {
+            uint32_t r = cnt;
+            for (; r >= 16; r -= 16) {
+                float t[16];
+#pragma unroll
+                for (int k = 0; k < 16; ++k) t[k] = tile[cur][r - 1 - k][col];
+#pragma unroll
+                for (int k = 0; k < 16; ++k) s = s + t[k];                // frame::mix of `out[i][ear] += sample * gain`, in walk order
+            }
+            for (; r > 0; --r) s = s + tile[cur][r - 1][col];
+        }
+        if (cnt2) stash(cur ^ 1);
+        __syncthreads();
+        cur ^= 1;
+        base = base2; cnt = cnt2;
+    }
+    if (wv == 0 && f < n_frames) out[2 * f + e] = postfx_apply(s, postfx);
 }
 
 __global__ void postfx_kernel(float* __restrict__ buf, uint32_t n, int postfx) {
