@@ -47,9 +47,13 @@ enum { /* oddio_hip_scene_set_postfx */
 
 enum { /* oddio_hip_scene_set_mode */
     ODDIO_HIP_MODE_FAST = 0,    /* sources spread over the whole chip; deterministic tree sum */
-    ODDIO_HIP_MODE_ORDERED = 1, /* one wavefront walks the set in the reference's reverse-index
-                                   order: bit-comparable with the sequential f32 sum of
-                                   src/spatial.rs:204,460 (slow; for parity tests <= ~4096 sources) */
+    ODDIO_HIP_MODE_ORDERED = 1, /* the contributions are added in the reference's reverse-index order:
+                                   bit-comparable with the sequential f32 sum of src/spatial.rs:204,460.
+                                   Scenes: up to 1024 sources one wavefront walks the set; above that every
+                                   source's contribution is rendered on the whole chip and a second kernel
+                                   adds the rows in order (about 10x the FAST callback; set_mode allocates
+                                   8 KiB per source slot for it, on the calling thread).  Mixers: one
+                                   wavefront. */
 };
 
 typedef struct oddio_hip_frames oddio_hip_frames; /* == Arc<Frames<f32>>, src/frames.rs:19-22 */

@@ -713,15 +713,17 @@ __device__ __noinline__ void mix_source_rare(float* acc_lds, int lane, uint32_t 
 // 16 slots in DESCENDING order (the reference's reverse set walk, spatial.rs:204).  A workgroup
 // leaves ONE partial tile: partials[(tile * n_wgs + wg) * 1024 + e * 512 + f] (planar L | R).
 // STORE (ORDERED mode at scale): instead of accumulating, every source's contribution `s * gain` (spatial.rs:459-460)
-// is written to its own row contrib[(source * 2 + ear) * contrib_fp + frame]; ordered_sum then adds the rows in the
-// reference's order.  `partials` / `init` are unused there.
+// is written out -- layout contrib[group of 16 sources][ear][column block of 16 frames][source in group][16], i.e. a
+// lane's 16 accumulators are one 64-byte row, a group fills one 1-KiB chunk per (ear, column block) and everything a
+// wave writes while it walks a group lies within 2 * ncb KiB -- and ordered_sum then adds the rows in the reference's
+// order.  `partials` / `init` are unused there.  contrib_ncb = column blocks per ear.
 template <bool FULL, bool STORE = false>
 __global__ __launch_bounds__(64 * MIX_WG_WAVES, MIX_WAVES_PER_SIMD) void spatial_mix(SceneParams P, const SrcStatic* __restrict__ st,
                                                                                      const EarParams* __restrict__ ear,
                                                                                      float* __restrict__ partials, const float* __restrict__ init,
                                                                                      uint32_t groups_per_wave, uint32_t n_groups,
                                                                                      const uint32_t* __restrict__ n_sources_ptr,
-                                                                                     float* __restrict__ contrib, uint32_t contrib_fp) {
+                                                                                     float* __restrict__ contrib, uint32_t contrib_ncb) {
     __shared__ __attribute__((aligned(16))) unsigned char smem_all[LDS_TOTAL * MIX_WG_WAVES];
     const uint32_t n_sources = *n_sources_ptr;   // the set length this callback's walk saw (n_groups is the host's upper bound)
     const int wv = threadIdx.x >> 6;
@@ -902,7 +904,7 @@ __global__ __launch_bounds__(64 * MIX_WG_WAVES, MIX_WAVES_PER_SIMD) void spatial
     if (STORE) {                                                                                                          \
         const uint32_t src_ = g * MIX_GROUP + (uint32_t)(J);                                                              \
         if (src_ < n_sources) {                                                                                           \
-            float4* row_ = reinterpret_cast<float4*>(contrib + ((size_t)src_ * 2 + (size_t)eB) * contrib_fp + frame0);    \
+            float4* row_ = reinterpret_cast<float4*>(contrib + ((((size_t)g * 2 + (size_t)eB) * contrib_ncb + (frame0 >> 4)) * MIX_GROUP + (size_t)(J)) * 16); \
             _Pragma("unroll") for (int q = 0; q < 4; ++q) row_[q] = make_float4(acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]); \
         }                                                                                                                 \
         _Pragma("unroll") for (int k = 0; k < 16; ++k) acc[k] = 0.0f;                                                     \
@@ -1035,57 +1037,96 @@ __device__ __forceinline__ void reduce_partials_body(const float* __restrict__ p
 
 // ORDERED mode at scale, second half: out[f][e] = ((init + row[len-1]) + row[len-2]) + ... + row[0] -- the
 // reference's sequential f32 sum in its reverse set walk (spatial.rs:204,460), one lane per output.  The chain of
-// `len` dependent adds per output is the whole cost, so the rows are streamed ahead of it: 4 waves fetch the next
-// ORD_ROWS x 64 tile into registers while wave 0 adds the current one from LDS.
-// grid = (ceil(n_frames / 64), 2 ears), block = 256.
-constexpr int ORD_ROWS = 128;
-__global__ __launch_bounds__(256) void ordered_sum(const float* __restrict__ contrib, uint32_t contrib_fp, const uint32_t* __restrict__ n_sources_ptr,
-                                                   uint32_t n_frames, const float* __restrict__ init, float* __restrict__ out, int postfx) {
-    __shared__ float tile[2][ORD_ROWS][64];   // lanes walk along a row in both directions: no padding needed
-    const uint32_t col = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const uint32_t f = blockIdx.x * 64 + col, e = blockIdx.y;
+// `len` dependent adds per output IS the cost (~1 ms at 262 144 sources), so everything else stays off it: one
+// wavefront per (ear, column block of 16 frames); a tile is 8 source groups = 8 chunks of 1 KiB (16 rows of 16
+// frames), streamed HBM -> LDS through a ring of ORD_RING tiles (buffer_load ... lds, several tiles ahead of the
+// adds, no registers).  Rows of sources >= len (stale chunks of an earlier, longer set) are never added.
+// grid = (column blocks, 2 ears), block = 64.
+constexpr int ORD_GROUPS = 8;                 // source groups per tile
+constexpr int ORD_ROWS = ORD_GROUPS * MIX_GROUP;   // 128 sources: 8 KiB = 8 DMA instructions
+constexpr int ORD_RING = 6;                   // tiles in the LDS ring (48 KiB), ORD_RING - 1 in flight
+__global__ __launch_bounds__(64) void ordered_sum(const float* __restrict__ contrib, uint32_t contrib_ncb,
+                                                  const uint32_t* __restrict__ n_sources_ptr, uint32_t n_frames,
+                                                  const float* __restrict__ init, float* __restrict__ out, int postfx) {
+    __shared__ __attribute__((aligned(16))) float ring[ORD_RING][ORD_ROWS][16];
+    const int lane = threadIdx.x;
+    const uint32_t cb = blockIdx.x, e = blockIdx.y;
     const uint32_t n = *n_sources_ptr;
-    const float* colp = contrib + (size_t)e * contrib_fp + f;            // + source * 2 * contrib_fp
-    constexpr int PER = ORD_ROWS / 4;                                     // rows each wave fetches per tile
-    float v[PER];
-    float s = (init != nullptr && f < n_frames) ? init[2 * f + e] : 0.0f; // the buffered set's sum (walked first, spatial.rs:395-438)
-    uint32_t hi = n;
-    uint32_t base = hi >= (uint32_t)ORD_ROWS ? hi - ORD_ROWS : 0u, cnt = hi - base;
-    auto fetch = [&](uint32_t b, uint32_t c) {
-#pragma unroll
-        for (int k = 0; k < PER; ++k) {
-            const uint32_t r = wv * PER + (uint32_t)k;
-            v[k] = r < c ? colp[(size_t)(b + r) * 2 * contrib_fp] : 0.0f;
+    const uint32_t f = cb * 16 + (uint32_t)(lane & 15);
+    float s = (init != nullptr && f < n_frames) ? init[2 * f + e] : 0.0f;   // the buffered set's sum (walked first, spatial.rs:395-438)
+    asm volatile("" :: "v"(s));                                  // the load above is awaited here, before the DMA counter is in use
+    const uint32_t group_stride = 2u * contrib_ncb * 1024u;      // bytes from a group's chunk to the next group's
+    const unsigned char* chunk0 = reinterpret_cast<const unsigned char*>(contrib) + ((size_t)e * contrib_ncb + cb) * 1024u;   // group 0
+    const uint32_t lds0 = (uint32_t)(uintptr_t)&ring[0][0][0];
+    const uint32_t n_tiles = (n + ORD_ROWS - 1) / ORD_ROWS;
+    // the instruction offset (i * 1024) advances both the LDS and the memory address: the scalar offset adds the rest of i * group_stride
+    const uint32_t so = group_stride - 1024u;
+    const int voff = 16 * lane;
+    // tile t = groups [8t, 8t + 8), all inside the allocation (it is sized in whole tiles); issued from the top tile down
+    auto issue = [&](uint32_t t) {
+        const uint64_t base = (uint64_t)(chunk0 + (size_t)t * ORD_GROUPS * group_stride);
+        u32x4 rsrc;
+        rsrc.x = (uint32_t)__builtin_amdgcn_readfirstlane((int)(base & 0xffffffffu));
+        rsrc.y = (uint32_t)__builtin_amdgcn_readfirstlane((int)((base >> 32) & 0xffffu));
+        rsrc.z = (uint32_t)__builtin_amdgcn_readfirstlane((int)(ORD_GROUPS * group_stride));
+        rsrc.w = 0x00020000u;
+        const uint32_t dst = (uint32_t)__builtin_amdgcn_readfirstlane((int)(lds0 + (t % ORD_RING) * (ORD_ROWS * 64)));
+        const uint32_t so0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)so);
+        uint32_t keep;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t"
+                     "buffer_load_dwordx4 %1, %2, 0 offen lds\n\t"
+                     "buffer_load_dwordx4 %1, %2, %4 offen offset:1024 lds\n\t"
+                     "buffer_load_dwordx4 %1, %2, %5 offen offset:2048 lds\n\t"
+                     "buffer_load_dwordx4 %1, %2, %6 offen offset:3072 lds\n\t"
+                     "s_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(voff), "s"(rsrc), "s"(dst), "s"(so0), "s"(2u * so0), "s"(3u * so0) : "memory");
+        const uint32_t dst2 = dst + 4096u;
+        const int voff2 = voff + (int)(4u * group_stride);      // chunk 4 (8 * 128 KiB fits the 32-bit offset)
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t"
+                     "buffer_load_dwordx4 %1, %2, 0 offen lds\n\t"
+                     "buffer_load_dwordx4 %1, %2, %4 offen offset:1024 lds\n\t"
+                     "buffer_load_dwordx4 %1, %2, %5 offen offset:2048 lds\n\t"
+                     "buffer_load_dwordx4 %1, %2, %6 offen offset:3072 lds\n\t"
+                     "s_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(voff2), "s"(rsrc), "s"(dst2), "s"(so0), "s"(2u * so0), "s"(3u * so0) : "memory");
+    };
+    static_assert(ORD_ROWS * 64 == 8192, "a tile is 8 DMA instructions of 1 KiB");
+    // k counts tiles from the top: tile index t = n_tiles - 1 - k
+    for (uint32_t k = 0; k < (uint32_t)(ORD_RING - 1) && k < n_tiles; ++k) issue(n_tiles - 1u - k);
+    for (uint32_t k = 0; k < n_tiles; ++k) {
+        const uint32_t t = n_tiles - 1u - k;
+        // keep ORD_RING - 1 tiles in flight: the ring slot of tile t - (ORD_RING - 1) is the one tile t + 1 was just read from
+        if (k + ORD_RING - 1 < n_tiles) {
+            issue(t - (uint32_t)(ORD_RING - 1));
+            asm volatile("s_waitcnt vmcnt(%0)" :: "n"(8 * (ORD_RING - 1)) : "memory");     // everything but the newest ORD_RING-1 tiles has landed
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
-    };
-    auto stash = [&](int buf) {
+        wave_sync();
+        const float* tp = &ring[t % ORD_RING][0][lane & 15];
+        if (k == 0 && (n % ORD_ROWS) != 0u) {
+            // top tile of a set whose length is not a whole number of tiles: rows of sources >= n are not part of the sum
+            for (int r = (int)(n - t * ORD_ROWS) - 1; r >= 0; --r) s = s + tp[r * 16];
+        } else {
+            // rows in descending order; the reads of the next 16 rows are in flight while the current 16 are added
+            float v[16], w[16];
 #pragma unroll
-        for (int k = 0; k < PER; ++k) tile[buf][wv * PER + k][col] = v[k];
-    };
-    if (cnt) { fetch(base, cnt); stash(0); }
-    __syncthreads();
-    int cur = 0;
-    while (cnt) {
-        const uint32_t hi2 = base;
-        const uint32_t base2 = hi2 >= (uint32_t)ORD_ROWS ? hi2 - ORD_ROWS : 0u, cnt2 = hi2 - base2;
-        if (cnt2) fetch(base2, cnt2);                                     // in flight while wave 0 adds
-        if (wv == 0) {
-            uint32_t r = cnt;
-            for (; r >= 16; r -= 16) {
-                float t[16];
+            for (int q = 0; q < 16; ++q) v[q] = tp[(ORD_ROWS - 1 - q) * 16];
 #pragma unroll
-                for (int k = 0; k < 16; ++k) t[k] = tile[cur][r - 1 - k][col];
+            for (int r = ORD_ROWS - 32; r >= -16; r -= 16) {
+                if (r >= 0) {
 #pragma unroll
-                for (int k = 0; k < 16; ++k) s = s + t[k];                // frame::mix of `out[i][ear] += sample * gain`, in walk order
+                    for (int q = 0; q < 16; ++q) w[q] = tp[(r + 15 - q) * 16];
+                }
+#pragma unroll
+                for (int q = 0; q < 16; ++q) s = s + v[q];          // `out[i][ear] += sample * gain` in walk order
+#pragma unroll
+                for (int q = 0; q < 16; ++q) v[q] = w[q];
             }
-            for (; r > 0; --r) s = s + tile[cur][r - 1][col];
         }
-        if (cnt2) stash(cur ^ 1);
-        __syncthreads();
-        cur ^= 1;
-        base = base2; cnt = cnt2;
+        wave_sync();                                                // the adds above are done with this slot before it is refilled
     }
-    if (wv == 0 && f < n_frames) out[2 * f + e] = postfx_apply(s, postfx);
+    if (lane < 16 && f < n_frames) out[2 * f + e] = postfx_apply(s, postfx);
 }
 
 __global__ void postfx_kernel(float* __restrict__ buf, uint32_t n, int postfx) {

@@ -150,3 +150,27 @@ def test_buffered_cycle_leaf():
         assert np.abs(a).max() > 0 or cb == 0
         np.testing.assert_array_equal(b, a)
     scene.close()
+
+
+def test_ordered_large_scene_with_buffered_sources():
+    """The buffered set is walked first (spatial.rs:395-433): in the large-scene ORDERED path its sum seeds ordered_sum."""
+    import oddio_amd as oa
+    n_seek, n_buf = 1500, 40
+    control, scene = oa.SpatialScene(max_sources=2048, max_frames=1024)
+    scene.set_mode(oa.MODE_ORDERED)
+    ref = oc.SpatialScene()
+    sc = synth.make_scene(77, n_seek + n_buf, cube=6.0, vmax=4.0)
+    for i in range(n_buf):
+        clip = synth.noise_clip(78, i, 20000)
+        gh, g_h = oa.Gain.new(oa.FramesSignal(oa.Frames.from_slice(48000, clip), 0.0))
+        g_o = oc.Gain(oc.FramesSignal(oc.Frames(48000, clip), 0.0))
+        control.play_buffered(g_h, oa.SpatialOptions(sc["position"][i], sc["velocity"][i], 0.1), 50.0, 48000, 0.1)
+        ref.play_buffered(g_o, oc.SpatialOptions(sc["position"][i], sc["velocity"][i], 0.1), 50.0, 48000, 0.1)
+    for i in range(n_buf, n_buf + n_seek):
+        clip = synth.noise_clip(79, i, 9000)
+        control.play(oa.FramesSignal(oa.Frames.from_slice(48000, clip), 0.04), oa.SpatialOptions(sc["position"][i], sc["velocity"][i], 0.1))
+        ref.play(oc.FramesSignal(oc.Frames(48000, clip), 0.04), oc.SpatialOptions(sc["position"][i], sc["velocity"][i], 0.1))
+    interval = np.float32(1.0) / np.float32(48000)
+    for cb, n in enumerate((1024, 600, 1024)):
+        np.testing.assert_array_equal(scene.sample_n(interval, n), ref.sample_n(interval, n), err_msg=f"callback {cb}")
+    scene.close()

@@ -52,6 +52,19 @@ def test_ordered_mode_bit_exact(n_src, n_frames):
     hb.close()
 
 
+@pytest.mark.parametrize("n_src,n_frames,postfx", [(1025, 1024, 0), (1100, 700, 1), (2049, 1536, 0), (3000, 1, 0), (5003, 1024, 1)])
+def test_ordered_mode_large_sets_bit_exact(n_src, n_frames, postfx):
+    """Above 1024 sources ORDERED mode renders every source's contribution on the whole chip and adds the rows in the
+    reference's order (spatial_mix<.., STORE> + ordered_sum): set sizes that leave partial groups / partial 128-source
+    tiles, callback lengths that are not whole 512-frame tiles, every kind of Seek source, a post filter."""
+    spec = scenario.random_spec(300 + n_src, n_src, kinds=("frames", "frames", "frames", "constant", "frames", "cycle", "downmix"),
+                                clip_len=6000, start=0.05, cube=8.0, gain_db=(None, -4.0, None), cycle_len=333)
+    ref, got, ob, hb = run_pair(spec, n_frames, 3, mode=1, postfx=postfx, max_sources=n_src + 7)
+    assert np.abs(ref).max() > 0
+    np.testing.assert_array_equal(got, ref)
+    hb.close()
+
+
 def test_ordered_motion_rotation_constant_fixedgain():
     spec = scenario.random_spec(11, 24, kinds=("frames", "frames", "constant"), gain_db=(None, -6.0, 3.0, None))
     rng = np.random.default_rng(0)
