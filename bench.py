@@ -392,6 +392,23 @@ def main():
         step_no += 1
     host_ms = (time.perf_counter() - th0) / n_host * 1e3
 
+    # the bit-exact mode (reference's sum order, tests/test_hip_large_scene.py) on the same scene: a few callbacks, reported only
+    ordered_ms = None
+    if world == 1:
+        import oddio_amd as oa
+        scene.set_mode(oa.MODE_ORDERED)
+        for k in range(5):
+            if step_no % span == 0:
+                scene.seek_all(rewind_seconds)
+            if k == 1:
+                scene.synchronize()
+                to0 = time.perf_counter()
+            scene.sample_device(interval, out.data_ptr(), N_FRAMES)
+            step_no += 1
+        scene.synchronize()
+        ordered_ms = (time.perf_counter() - to0) / 4 * 1e3
+        scene.set_mode(oa.MODE_FAST)
+
     ranks_seen = 1
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64)
@@ -445,6 +462,7 @@ def main():
             "max_realtime_sources": value / RATE,
             "realtime_factor_per_gpu": (N_FRAMES / RATE) / (elapsed / args.steps),
             "host_output_ms_per_step": host_ms,
+            "ordered_mode_ms_per_step": ordered_ms,      # bit-exact (reference sum order) mode, same scene
             "precondition_ms": args.precondition_ms,
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,

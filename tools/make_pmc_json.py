@@ -10,7 +10,8 @@ import sys
 
 summary, sources, out = sys.argv[1], int(sys.argv[2]), sys.argv[3]
 d = json.load(open(summary))
-k = next(k for k in d if k.startswith("spatial_mix"))
+# the accumulate instantiation (FAST mode), not spatial_mix<.., STORE> of the few ORDERED-mode callbacks: most dispatches
+k = max((k for k in d if k.startswith("spatial_mix")), key=lambda k: d[k].get("_dispatches") or 0)
 c = d[k]
 res = {
     "kernel": k, "sources": sources, "dispatches": c.get("_dispatches"),
