@@ -832,6 +832,18 @@ __global__ __launch_bounds__(64 * MIX_WG_WAVES, MIX_WAVES_PER_SIMD) void spatial
             }
             const int ws = lo & ~3;
             const int count = hi + 2 - ws;
+            {   // the padded layout (one extra slot per 16 samples, written a whole 16-byte vector at a time) must fit
+                // the window buffer too.  Near-unit windows are ~550 samples, but a listener rotation inside the
+                // callback can pull one ear's ratio to 1 while the other's window grows to the full 608: re-laid, that
+                // window would run 12 floats into the next buffer.  Such a source keeps the plain layout (bank conflicts
+                // only), or, if it needs the constant-fract branch that only the padded variant implements, the exact
+                // per-lane path.
+                const int vec_samples = ((count + 3) >> 2) << 2;
+                if ((fl & SFLAG_PAD) && vec_samples + (vec_samples >> 4) + 1 > WIN_CAP) {
+                    if (fl & (SFLAG_FAST_L | SFLAG_FAST_R)) generic = 1;
+                    else fl &= ~SFLAG_PAD;
+                }
+            }
             int path = PATH_SKIP;
             if (live) {
                 if (ss.kind == KIND_SINE) path = PATH_SINE;

@@ -155,6 +155,7 @@ __global__ void apply_motion_by_id(const MotionById* __restrict__ up, uint32_t n
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const MotionById u = up[i];
+    if (u.id == 0xffffffffu) return;                        // sent for the id's previous owner (scene_host.inc)
     const uint32_t sl = slot_of_id[u.id];
     if (sl == SLOT_INVALID) return;                          // already removed
     SrcPending p;
@@ -170,6 +171,7 @@ struct ControlById { uint32_t id; uint32_t index; float value; uint32_t pad; };
 __global__ void apply_control_by_id(const ControlById* __restrict__ up, uint32_t n, const uint32_t* __restrict__ slot_of_id,
                                     BufDyn* __restrict__ bdyn) {
     for (uint32_t i = 0; i < n; ++i) {
+        if (up[i].id == 0xffffffffu) continue;             // sent for the id's previous owner
         const uint32_t sl = slot_of_id[up[i].id];
         if (sl == SLOT_INVALID || !(sl & SLOT_BUFFERED_BIT)) continue;
         bdyn[sl & ~SLOT_BUFFERED_BIT].shared[up[i].index & (MAX_WRAP - 1)] = up[i].value;

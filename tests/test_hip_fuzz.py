@@ -22,7 +22,10 @@ def _vec(rng, scale):
     return (rng.uniform(-1, 1, 3) * scale).astype(np.float32)
 
 
-@pytest.mark.parametrize("seed", range(10))
+# 5094: a listener rotation inside the callback gave one ear a near-unit resample ratio and the other a full-size
+# window (padded re-layout overran its buffer); 5173: a control update sent for a finished source whose handle id was
+# released and handed to a new source before the next callback.  Both found by tests/soak_fuzz.py.
+@pytest.mark.parametrize("seed", list(range(10)) + [5094, 5173])
 def test_random_operations_bit_exact(seed):
     import oddio_amd as oa
     rng = np.random.default_rng(9000 + seed)

@@ -41,6 +41,10 @@ int main() {
         {900, 100, 0, "runs past the clip's end"},
         {1200, 30, 0, "starts after the clip's end"},
         {96, 32, 8, "record count cut in the middle of a 16-byte group"},
+        {-604, 39, 0, "short window far before the clip (fuzz seed 5094)"},
+        {-604, 20, 0, "shorter"},
+        {-16, 39, 0, "window starting 16 samples before the clip"},
+        {-4, 39, 0, "window starting 4 samples before the clip"},
     };
     int bad_total = 0;
     for (const Case& c : cases) {
