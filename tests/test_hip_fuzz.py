@@ -7,6 +7,8 @@ must be bit-identical, and set sizes and is_finished flags must agree throughout
 This is the test of the host side: slot bookkeeping under swap_remove (src/set.rs:170-188) for both
 sets, handle-id reuse, latest-value-wins motion (src/swap.rs), propagation-delay removal
 (src/spatial.rs:243-261)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -30,7 +32,8 @@ def test_random_operations_bit_exact(seed):
     import oddio_amd as oa
     rng = np.random.default_rng(9000 + seed)
     control, scene = oa.SpatialScene(max_sources=96, max_frames=1536)
-    scene.set_mode(oa.MODE_ORDERED)
+    fast = os.environ.get("ODDIO_FUZZ_MODE") == "fast"      # soak option: the multi-wavefront tree sum, compared with a tolerance
+    scene.set_mode(oa.MODE_FAST if fast else oa.MODE_ORDERED)
     scene.set_postfx((0, 1, 0)[seed % 3])
     ref_scene = oc.SpatialScene()
     ref = oc.Reinhard(ref_scene) if seed % 3 == 1 else ref_scene
@@ -115,7 +118,10 @@ def test_random_operations_bit_exact(seed):
         n = int(rng.choice([1024, 1024, 512, 256, 1, 300, 1300, 1536]))
         a = ref.sample_n(INTERVAL, n)
         b = scene.sample_n(INTERVAL, n)
-        np.testing.assert_array_equal(b, a, err_msg=f"seed {seed} callback {cb} n {n}")
+        if fast:
+            np.testing.assert_allclose(b, a, rtol=0, atol=1e-5 * max(float(np.abs(a).max()), 1e-3), err_msg=f"seed {seed} callback {cb} n {n}")
+        else:
+            np.testing.assert_array_equal(b, a, err_msg=f"seed {seed} callback {cb} n {n}")
         assert (len(scene), scene.len_buffered()) == (len(ref_scene), ref_scene.len_buffered())
         peak_len = max(peak_len, len(scene) + scene.len_buffered())
         removed_seen = removed_seen or any(e[0].is_finished() for e in live)
