@@ -130,6 +130,121 @@ def test_random_operations_bit_exact(seed):
     scene.close()
 
 
+@pytest.mark.parametrize("seed", range(6))
+def test_random_operations_unsynchronised(seed):
+    """The same operation stream with the callbacks ENQUEUED (oddio_hip_scene_sample_device): inserts, removals, handle-id
+    reuse and control updates all take effect in stream order on the device while the host runs ahead (decisions that
+    need `is_finished` use the oracle's answer).  The host waits only every third callback: the library stages a
+    callback's updates in one of three pinned slots, and a callback that finds all of them still unread by the device
+    leaves its updates queued for the next one (it never waits) -- beyond that distance the device path is no longer
+    callback-for-callback the reference.  Outputs compared afterwards."""
+    import torch
+    import oddio_amd as oa
+    rng = np.random.default_rng(19000 + seed)
+    control, scene = oa.SpatialScene(max_sources=96, max_frames=1536)
+    fast = False
+    sizes, wants = [], []
+    dev_out = torch.zeros((60, 1536, 2), dtype=torch.float32, device="cuda")
+    scene.set_mode(oa.MODE_FAST if fast else oa.MODE_ORDERED)
+    scene.set_postfx((0, 1, 0)[seed % 3])
+    ref_scene = oc.SpatialScene()
+    ref = oc.Reinhard(ref_scene) if seed % 3 == 1 else ref_scene
+    live = []          # [hip handle, oracle handle, hip controls, oracle controls]
+    clip_no = 0
+    peak_len, removed_seen = 0, False
+    for cb in range(60):
+        n_ops = int(rng.integers(0, 5))
+        for _ in range(n_ops):
+            op = rng.choice(["play", "play", "buffered", "motion", "motion", "rotation", "control", "drop"])
+            if op in ("play", "buffered") and len(live) < 60:
+                clip_no += 1
+                kind = rng.choice(["frames", "frames", "cycle", "constant"] + (["downmix"] if op == "play" else []))
+                rate = int(rng.choice([48000, 44100, 22050]))
+                pos, vel = _vec(rng, 12.0), _vec(rng, 25.0)
+                radius = float(rng.choice([0.1, 0.5]))
+                hc, rc = [], []
+                if kind == "frames":
+                    clip = synth.noise_clip(seed, clip_no, int(rng.integers(1, 9000)))
+                    start = float(rng.uniform(-0.01, 0.02))
+                    sh, so = oa.FramesSignal(oa.Frames.from_slice(rate, clip), start), oc.FramesSignal(oc.Frames(rate, clip), start)
+                elif kind == "downmix":
+                    n = int(rng.integers(1, 9000))
+                    clip = np.stack([synth.noise_clip(seed, clip_no, n), synth.noise_clip(seed + 77, clip_no, n)], axis=1)
+                    start = float(rng.uniform(-0.01, 0.02))
+                    sh = oa.Downmix(oa.FramesSignal(oa.Frames.from_slice(rate, clip), start))
+                    so = oc.Downmix(oc.FramesSignal(oc.Frames(rate, clip), start))
+                elif kind == "cycle":
+                    clip = synth.noise_clip(seed, clip_no, int(rng.integers(1, 700)))
+                    sh, so = oa.Cycle(oa.Frames.from_slice(rate, clip)), oc.Cycle(oc.Frames(rate, clip))
+                else:
+                    val = float(rng.uniform(-1, 1))
+                    sh, so = oa.Constant(val), oc.Constant(val)
+                if rng.random() < 0.4 and kind != "constant":
+                    db = float(rng.uniform(-12, 6))
+                    sh, so = oa.FixedGain(sh, db), oc.FixedGain(so, db)
+                if op == "buffered":
+                    for _ in range(int(rng.integers(0, 3))):
+                        if rng.random() < 0.5:
+                            c, sh = oa.Gain.new(sh)
+                            so = oc.Gain(so)
+                        else:
+                            c, sh = oa.Speed.new(sh)
+                            so = oc.Speed(so)
+                        hc.append(c)
+                        rc.append(so)
+                    h = control.play_buffered(sh, oa.SpatialOptions(pos, vel, radius), 60.0, 48000, 0.05)
+                    r = ref_scene.play_buffered(so, oc.SpatialOptions(pos, vel, radius), 60.0, 48000, 0.05)
+                else:
+                    h = control.play(sh, oa.SpatialOptions(pos, vel, radius))
+                    r = ref_scene.play(so, oc.SpatialOptions(pos, vel, radius))
+                live.append([h, r, hc, rc])
+            elif op == "motion" and live:
+                for _ in range(int(rng.integers(1, 4))):      # several per callback: the latest must win
+                    k = int(rng.integers(0, len(live)))
+                    pos, vel, disc = _vec(rng, 12.0), _vec(rng, 25.0), bool(rng.random() < 0.3)
+                    live[k][0].set_motion(pos, vel, disc)
+                    live[k][1].set_motion(pos, vel, disc)
+            elif op == "rotation":
+                q = rng.normal(size=4).astype(np.float32)
+                q = (q / np.linalg.norm(q)).astype(np.float32)
+                control.set_listener_rotation(q)
+                ref_scene.set_listener_rotation(q)
+            elif op == "control":
+                cands = [e for e in live if e[2]]
+                if cands:
+                    e = cands[int(rng.integers(0, len(cands)))]
+                    i = int(rng.integers(0, len(e[2])))
+                    if isinstance(e[2][i], oa.GainControl):
+                        v = float(rng.uniform(0.0, 2.0))
+                        e[2][i].set_amplitude_ratio(v)
+                        e[3][i].set_amplitude_ratio(v)
+                    else:
+                        v = float(rng.uniform(0.5, 1.6))
+                        e[2][i].set_speed(v)
+                        e[3][i].set_speed(v)
+            elif op == "drop" and live:
+                k = int(rng.integers(0, len(live)))
+                if live[k][1].is_finished():                 # (the oracle's answer: the device may be callbacks behind)
+                    live[k][0].release()
+                    live.pop(k)
+        n = int(rng.choice([1024, 1024, 512, 256, 1, 300, 1300, 1536]))
+        wants.append(ref.sample_n(INTERVAL, n))
+        sizes.append(n)
+        scene.sample_device(INTERVAL, dev_out[cb].data_ptr(), n)
+        if cb % 3 == 2:
+            scene.synchronize()
+        peak_len = max(peak_len, len(ref_scene) + ref_scene.len_buffered())
+        removed_seen = removed_seen or any(e[1].is_finished() for e in live)
+    scene.synchronize()
+    got = dev_out.cpu().numpy()
+    for cb in range(60):
+        np.testing.assert_array_equal(got[cb, :sizes[cb]], wants[cb], err_msg=f"seed {seed} callback {cb} n {sizes[cb]}")
+    assert (len(scene), scene.len_buffered()) == (len(ref_scene), ref_scene.len_buffered())
+    assert [e[0].is_finished() for e in live] == [e[1].is_finished() for e in live]
+    assert clip_no >= 15 and peak_len >= 5 and removed_seen, (clip_no, peak_len, removed_seen)
+    scene.close()
+
+
 @pytest.mark.parametrize("seed", range(8))
 def test_mixer_random_operations_bit_exact(seed):
     # Mixer<[f32;2]> (src/mixer.rs:92-119): plays of mono / stereo clips, Cycle, Constant under
