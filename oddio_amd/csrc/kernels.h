@@ -6,12 +6,16 @@
 // (Sine differs only by the device sinf vs glibc sinf, a few ulp).
 //
 // Kernels
-//   spatial_prepass   1 thread / source   walk_set + EarState + cursor bookkeeping
+//   spatial_prepass   1 thread / source (table rows moved through LDS a wavefront at a time)
+//                                         walk_set + EarState + cursor bookkeeping
 //                                         (spatial.rs:191-265, :445-469 scalar part, :501-549)
-//   spatial_mix       4-wave workgroups, 16 sources per wave-group; the per-sample loop
-//                                         (spatial.rs:456-463 + frames.rs:176-201 + sine.rs:34-40)
+//   cycle_sources     1 wave / Seek-set Cycle source: serial cursor scan + 64-lane render (cycle.rs:26-60)
+//   spatial_mix       2-wave workgroups, 16 sources per phase-A group; the per-sample loop
+//                                         (spatial.rs:456-463 + frames.rs:176-201 + sine.rs:34-40);
+//                                         <.., STORE>: per-source contribution rows for ORDERED mode at scale
 //   reduce_partials   fixed-order sum of the workgroup partial tiles + Reinhard/Tanh epilogue
-//                                         (reinhard.rs:32, tanh.rs:26)
+//                                         (reinhard.rs:32, tanh.rs:26); set_kernels.h adds the set compaction
+//   ordered_sum       the reference's sequential sum over the contribution rows (spatial.rs:204,460)
 //
 // Mix kernel work decomposition (why it is not "one lane = one output frame"):
 //   FramesSignal's slow path advances its f32 cursor by a *sequentially rounded* `offset += ds`
@@ -23,12 +27,12 @@
 //   Phase B: for one source at a time, lanes 0-31 are the left ear and 32-63 the right ear; lane l
 //   owns 16 consecutive output frames of its ear (16 register accumulators), restarts from its
 //   checkpoint and replays 15 exact adds.  The source's sample window (~N*ds + 32 floats) is
-//   fetched one source ahead with bounds-checked 16 B buffer loads (out-of-clip reads return 0, so
-//   frames.rs:105-123 `get_pair` needs no branches), staged into LDS, and read back as
+//   fetched one source ahead with bounds-checked 16 B buffer loads straight into LDS (out-of-clip
+//   reads return 0, so frames.rs:105-123 `get_pair` needs no branches) and read back as
 //   ds_read2_b32 pairs.  Windows with |ds-1| < PAD_EPS use a layout with one pad float per 16
 //   samples so that the near-unit lane stride does not alias LDS banks.
-//   The 4 waves of a workgroup sum their register tiles through LDS in fixed order and write one
-//   planar partial tile per workgroup; DESIGN.md section 3 has the byte and cycle accounting.
+//   The waves of a workgroup sum their register tiles through LDS in fixed order and write one
+//   planar partial tile per workgroup; DESIGN.md section 4 has the byte and cycle accounting.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <float.h>
