@@ -18,6 +18,9 @@ from oracle import oracle_c as oc
 pytestmark = pytest.mark.gpu
 
 INTERVAL = np.float32(1.0) / np.float32(48000)
+# soak options (tests/soak_fuzz.py): more live sources / operations per callback than the default 60 / 0-4
+LIVE_MAX = int(os.environ.get("ODDIO_FUZZ_LIVE", "60"))
+OPS_MAX = int(os.environ.get("ODDIO_FUZZ_OPS", "5"))
 
 
 def _vec(rng, scale):
@@ -31,7 +34,7 @@ def _vec(rng, scale):
 def test_random_operations_bit_exact(seed):
     import oddio_amd as oa
     rng = np.random.default_rng(9000 + seed)
-    control, scene = oa.SpatialScene(max_sources=96, max_frames=1536)
+    control, scene = oa.SpatialScene(max_sources=LIVE_MAX + 36, max_frames=1536)
     fast = os.environ.get("ODDIO_FUZZ_MODE") == "fast"      # soak option: the multi-wavefront tree sum, compared with a tolerance
     scene.set_mode(oa.MODE_FAST if fast else oa.MODE_ORDERED)
     scene.set_postfx((0, 1, 0)[seed % 3])
@@ -41,10 +44,10 @@ def test_random_operations_bit_exact(seed):
     clip_no = 0
     peak_len, removed_seen = 0, False
     for cb in range(60):
-        n_ops = int(rng.integers(0, 5))
+        n_ops = int(rng.integers(0, OPS_MAX))
         for _ in range(n_ops):
             op = rng.choice(["play", "play", "buffered", "motion", "motion", "rotation", "control", "drop"])
-            if op in ("play", "buffered") and len(live) < 60:
+            if op in ("play", "buffered") and len(live) < LIVE_MAX:
                 clip_no += 1
                 kind = rng.choice(["frames", "frames", "cycle", "constant"] + (["downmix"] if op == "play" else []))
                 rate = int(rng.choice([48000, 44100, 22050]))
@@ -141,7 +144,7 @@ def test_random_operations_unsynchronised(seed):
     import torch
     import oddio_amd as oa
     rng = np.random.default_rng(19000 + seed)
-    control, scene = oa.SpatialScene(max_sources=96, max_frames=1536)
+    control, scene = oa.SpatialScene(max_sources=LIVE_MAX + 36, max_frames=1536)
     fast = False
     sizes, wants = [], []
     dev_out = torch.zeros((60, 1536, 2), dtype=torch.float32, device="cuda")
@@ -153,10 +156,10 @@ def test_random_operations_unsynchronised(seed):
     clip_no = 0
     peak_len, removed_seen = 0, False
     for cb in range(60):
-        n_ops = int(rng.integers(0, 5))
+        n_ops = int(rng.integers(0, OPS_MAX))
         for _ in range(n_ops):
             op = rng.choice(["play", "play", "buffered", "motion", "motion", "rotation", "control", "drop"])
-            if op in ("play", "buffered") and len(live) < 60:
+            if op in ("play", "buffered") and len(live) < LIVE_MAX:
                 clip_no += 1
                 kind = rng.choice(["frames", "frames", "cycle", "constant"] + (["downmix"] if op == "play" else []))
                 rate = int(rng.choice([48000, 44100, 22050]))
