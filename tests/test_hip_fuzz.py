@@ -35,6 +35,8 @@ def test_random_operations_bit_exact(seed):
     import oddio_amd as oa
     rng = np.random.default_rng(9000 + seed)
     control, scene = oa.SpatialScene(max_sources=LIVE_MAX + 36, max_frames=1536)
+    if LIVE_MAX > 200:
+        scene.reserve_buffered(LIVE_MAX + 36)
     fast = os.environ.get("ODDIO_FUZZ_MODE") == "fast"      # soak option: the multi-wavefront tree sum, compared with a tolerance
     scene.set_mode(oa.MODE_FAST if fast else oa.MODE_ORDERED)
     scene.set_postfx((0, 1, 0)[seed % 3])
@@ -145,6 +147,8 @@ def test_random_operations_unsynchronised(seed):
     import oddio_amd as oa
     rng = np.random.default_rng(19000 + seed)
     control, scene = oa.SpatialScene(max_sources=LIVE_MAX + 36, max_frames=1536)
+    if LIVE_MAX > 200:
+        scene.reserve_buffered(LIVE_MAX + 36)
     fast = False
     sizes, wants = [], []
     dev_out = torch.zeros((60, 1536, 2), dtype=torch.float32, device="cuda")
