@@ -281,6 +281,12 @@ __device__ void fader_sample(BufStatic& st, BufDyn& dyn, FaderRec& F, float* scr
     }
 }
 
+// the shapes the wave-per-source kernels render: FixedGain / Gain / Speed over a mono FramesSignal or a mono Cycle
+// (whose 32-bit cursor arithmetic, cycle_step in kernels.h, wants clips of fewer than 2^30 samples)
+__host__ __device__ __forceinline__ bool buffered_wave_shape(uint32_t kind, uint32_t channels, uint32_t fader, uint32_t clip_len) {
+    return (kind == KIND_FRAMES || (kind == KIND_CYCLE && clip_len < (1u << 30))) && channels <= 1u && fader == 0u;
+}
+
 // One thread per buffered slot: walk_set (spatial.rs:191-265) + the buffered mix closure
 // (spatial.rs:402-431).  contrib is [slot][n_frames][2]; skip[slot] != 0 means "not mixed".
 __global__ __launch_bounds__(64) void buffered_sources(SceneParams P, const uint32_t* __restrict__ d_len_b, BufStatic* __restrict__ st,
@@ -292,7 +298,7 @@ __global__ __launch_bounds__(64) void buffered_sources(SceneParams P, const uint
     if (i >= d_len_b[0]) return;
     BufDyn d = dyn[i];
     BufStatic s = st[i];
-    if (skip_wave_shapes && s.kind == KIND_FRAMES && s.channels <= 1u && s.fader == 0u) return;   // buffered_sources_wave renders these
+    if (skip_wave_shapes && buffered_wave_shape(s.kind, s.channels, s.fader, s.clip_len)) return;   // buffered_sources_wave renders these
     SrcDyn& c = d.common;
     if (c.flags & DYN_STOPPED) { skip[i] = 1; return; }
     const float elapsed = P.elapsed;
@@ -417,9 +423,7 @@ __global__ __launch_bounds__(64) void buffered_sources(SceneParams P, const uint
 // wrap rewrite (ring.rs:59-78).  One lane per running sum replays it exactly and drops a checkpoint every 16
 // steps in LDS; then all 64 lanes restart from their checkpoints and produce 16 frames each, like the mix
 // kernel's phase A / phase B.  Bit-identical to the thread-per-source kernel, ~100x shorter critical path.
-__device__ __forceinline__ bool buffered_wave_eligible(const BufStatic& s) {
-    return s.kind == KIND_FRAMES && s.channels <= 1u && s.fader == 0u;
-}
+__device__ __forceinline__ bool buffered_wave_eligible(const BufStatic& s) { return buffered_wave_shape(s.kind, s.channels, s.fader, s.clip_len); }
 __device__ __forceinline__ void wg_sync() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __builtin_amdgcn_wave_barrier();
@@ -434,12 +438,15 @@ __device__ void inner_sample_wave(const BufStatic& s, BufDyn& d, float interval,
         level_interval[w] = cur;
         if (s.wrap_kind[w] == WRAP_SPEED) cur = cur * d.shared[w];   // speed.rs:32-35
     }
-    // leaf: frames.rs:176-201
+    // leaf: frames.rs:176-201, or cycle.rs:26-53 (d.common.t is then the cursor in samples; ck row 5 holds `base`)
+    const bool cyc = s.kind == KIND_CYCLE;
     const double s0 = d.common.t * (double)s.clip_rate;
     const float ds = cur * (float)s.clip_rate;
     const long long base = f64_as_isize(s0);
-    const bool fast = fabsf(ds - 1.0f) <= FLT_EPSILON;
+    const bool fast = !cyc && fabsf(ds - 1.0f) <= FLT_EPSILON;
     const float frac0 = (float)(s0 - (double)base);
+    uint32_t cbase = cyc ? (uint32_t)f64_as_isize(d.common.t) : 0u;        // cycle.rs:28
+    float coff = cyc ? (float)(d.common.t - (double)cbase) : 0.0f;          // :29
     // Gain: Smoothed::set when the shared target moved (gain.rs:106-109), then ramp or constant
     bool ramp[MAX_WRAP];
     float gconst[MAX_WRAP], step[MAX_WRAP];
@@ -465,7 +472,14 @@ __device__ void inner_sample_wave(const BufStatic& s, BufDyn& d, float interval,
     for (uint32_t p0 = 0; p0 < n; p0 += 1024u) {
         const uint32_t m = (n - p0) < 1024u ? (n - p0) : 1024u;
         const uint32_t nb = (m + 15u) / 16u;
-        if (lane <= MAX_WRAP) {
+        if (lane == 0 && cyc) {
+            for (uint32_t b = 0; b < nb; ++b) {
+                ck[0][b] = coff;
+                ck[5][b] = __uint_as_float(cbase);
+                const uint32_t cnt = (m - 16u * b) < 16u ? (m - 16u * b) : 16u;
+                for (uint32_t i = 0; i < cnt; ++i) { uint32_t ia, ib; float fr; cycle_step(cbase, coff, s.clip_len, ds, ia, ib, fr); }
+            }
+        } else if (lane <= MAX_WRAP) {
             for (uint32_t b = 0; b < nb; ++b) {
                 ck[lane][b] = scan;
                 const uint32_t cnt = (m - 16u * b) < 16u ? (m - 16u * b) : 16u;
@@ -480,13 +494,21 @@ __device__ void inner_sample_wave(const BufStatic& s, BufDyn& d, float interval,
             const uint32_t f0 = p0 + 16u * (uint32_t)lane;
             const uint32_t cnt = (m - 16u * (uint32_t)lane) < 16u ? (m - 16u * (uint32_t)lane) : 16u;
             float off = ck[0][lane];
+            uint32_t cb_ = cyc ? __float_as_uint(ck[5][lane]) : 0u;
             float pr[MAX_WRAP];
             for (int w = 0; w < MAX_WRAP; ++w) pr[w] = ck[1 + w][lane];
             for (uint32_t k = 0; k < cnt; ++k) {
-                long long idx; float fr;
-                if (fast) { idx = base + (long long)(f0 + k); fr = frac0; }                       // frames.rs:180-187
-                else { const long long tr = (long long)off; idx = base + tr; fr = off - (float)tr; off = off + ds; }   // :189-196
-                const float a = clip_ch(s.clip, s.clip_len, 1u, 0u, idx), b = clip_ch(s.clip, s.clip_len, 1u, 0u, idx + 1);
+                float a, b, fr;
+                if (cyc) {                                                                         // cycle.rs:30-50
+                    uint32_t ia, ib;
+                    cycle_step(cb_, off, s.clip_len, ds, ia, ib, fr);
+                    a = s.clip[ia]; b = s.clip[ib];
+                } else {
+                    long long idx;
+                    if (fast) { idx = base + (long long)(f0 + k); fr = frac0; }                   // frames.rs:180-187
+                    else { const long long tr = (long long)off; idx = base + tr; fr = off - (float)tr; off = off + ds; }   // :189-196
+                    a = clip_ch(s.clip, s.clip_len, 1u, 0u, idx); b = clip_ch(s.clip, s.clip_len, 1u, 0u, idx + 1);
+                }
                 float v = a + fr * (b - a);
                 for (uint32_t w = 0; w < s.n_wrap; ++w) {
                     if (s.wrap_kind[w] == WRAP_FIXED_GAIN) v = v * s.wrap_param[w];              // gain.rs:32-37
@@ -507,7 +529,13 @@ __device__ void inner_sample_wave(const BufStatic& s, BufDyn& d, float interval,
         const float fin = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(scan), 1 + w));
         if (ramp[w]) d.sm_progress[w] = fin;
     }
-    d.common.t = d.common.t + (double)cur * (double)n;                                            // frames.rs:198
+    if (cyc) {   // cycle.rs:52: the cursor the scanner lane ended on, for every lane
+        const uint32_t fb = (uint32_t)__builtin_amdgcn_readlane((int)cbase, 0);
+        const float fo = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(coff), 0));
+        d.common.t = (double)fb + (double)fo;
+    } else {
+        d.common.t = d.common.t + (double)cur * (double)n;                                        // frames.rs:198
+    }
 }
 
 // One wave per buffered slot; slots of other shapes are left to buffered_sources (skip_wave_shapes = 1 there).
@@ -551,7 +579,7 @@ __global__ __launch_bounds__(64) void buffered_sources_wave(SceneParams P, const
     if (c.flags & DYN_HAS_FINISHED_FOR) {
         if (c.finished_for > distance / ODDIO_SPEED_OF_SOUND) c.flags |= DYN_STOPPED;
         else c.finished_for = c.finished_for + elapsed;
-    } else if (c.t >= (double)(s.clip_len - 1u) / (double)s.clip_rate) {   // is_finished passes through the filters
+    } else if (s.kind == KIND_FRAMES && c.t >= (double)(s.clip_len - 1u) / (double)s.clip_rate) {   // is_finished passes through the filters (a Cycle never finishes)
         c.flags |= DYN_HAS_FINISHED_FOR; c.finished_for = elapsed;
     }
     __builtin_amdgcn_wave_barrier();

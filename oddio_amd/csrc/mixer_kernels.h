@@ -333,7 +333,7 @@ __global__ __launch_bounds__(64) void mixer_general_sources_wave(uint32_t n_sour
     BufDyn d = dyn[i];
     if (d.common.flags & MIXDYN_STOPPED) { if (lane == 0) skip[i] = 1; return; }
     const bool fin = (d.common.flags & MIXDYN_STOP_REQUESTED) != 0                                                  // mixer.rs:102
-                     || d.common.t >= (double)(s.clip_len - 1u) / (double)s.clip_rate;                              // frames.rs:204-206
+                     || (s.kind == KIND_FRAMES && d.common.t >= (double)(s.clip_len - 1u) / (double)s.clip_rate);   // frames.rs:204-206 (a Cycle never finishes)
     if (fin) {
         if (lane == 0) {
             d.common.flags |= MIXDYN_STOPPED;

@@ -51,6 +51,17 @@ def main():
         print(f"Seek-set Cycle sources: {min(n_src, 1024):5d} -> {time_calls(scene):8.3f} ms / 1024-frame callback")
         scene.close()
 
+    for n_src in (64, 1024):
+        control, scene = oa.SpatialScene(max_sources=8192, max_frames=1024)
+        sc = synth.make_scene(6, n_src)
+        scene.reserve_buffered(n_src)
+        cyc = oa.Frames.from_slice(48000, synth.noise_clip(3, 0, 5000))
+        for i in range(n_src):
+            gc, g = oa.Gain.new(oa.Cycle(cyc))
+            control.play_buffered(g, oa.SpatialOptions(sc["position"][i], sc["velocity"][i], 0.1), 100.0, 48000, 0.1)
+        print(f"buffered spatial sources (Gain<Cycle>): {n_src:5d} -> {time_calls(scene):8.3f} ms / 1024-frame callback")
+        scene.close()
+
 
 if __name__ == "__main__":
     main()
