@@ -71,6 +71,7 @@ extern "C" {
     fn oddio_hip_source_release(s: *mut RawScene, id: u32) -> c_int;
     fn oddio_hip_scene_set_listener_rotation(s: *mut RawScene, rotation_sxyz: *const f32) -> c_int;
     fn oddio_hip_scene_set_postfx(s: *mut RawScene, postfx: c_int) -> c_int;
+    fn oddio_hip_scene_set_mode(s: *mut RawScene, mode: c_int) -> c_int;
     fn oddio_hip_scene_sample(s: *mut RawScene, interval: f32, out: *mut f32, n_frames: usize) -> c_int;
     fn oddio_hip_scene_reduce_init(s: *mut RawScene, rank: c_int, world: c_int, unique_id: *const c_void, unique_id_bytes: usize) -> c_int;
     fn oddio_hip_mixer_create(device: c_int, max_sources: u32, max_frames: u32, out: *mut *mut RawMixer) -> c_int;
@@ -151,6 +152,12 @@ impl HipSpatialScene {
     /// `Reinhard::new(scene)` / `Tanh::new(scene)` fused on the device (src/reinhard.rs, src/tanh.rs)
     pub fn with_postfx(self, postfx: c_int) -> Self {
         check(unsafe { oddio_hip_scene_set_postfx((self.0).0, postfx) });
+        self
+    }
+    /// The reference's sequential f32 sum, bit for bit (ODDIO_HIP_MODE_ORDERED): about 10x the cost of the default
+    /// deterministic tree sum; allocates the per-source contribution rows on the calling thread.
+    pub fn bit_exact(self) -> Self {
+        check(unsafe { oddio_hip_scene_set_mode((self.0).0, 1) });
         self
     }
     /// One logical scene split by source index over `world` GPUs (BASELINE configs[4]): every rank

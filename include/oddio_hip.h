@@ -184,6 +184,15 @@ int oddio_hip_scene_set_listener_rotation(oddio_hip_scene* scene, const float ro
 
 int oddio_hip_scene_set_postfx(oddio_hip_scene* scene, int postfx);
 int oddio_hip_scene_set_mode(oddio_hip_scene* scene, int mode);
+/* What a *_sample* call does when all of its staging slots for control updates are still unread by the device,
+ * i.e. the caller has enqueued several callbacks with control traffic (oddio_hip_scene_sample_device) without
+ * waiting for the device:
+ *   0 (default) never wait: the updates stay queued and take effect one callback later (src/signal.rs:11-13, "the
+ *     audio thread waits for nobody") -- beyond that run-ahead the output is no longer callback-for-callback the
+ *     reference's;
+ *   1 wait for the oldest slot (offline rendering into device buffers: every update takes effect in the callback
+ *     it was sent before, like the reference's, at the price of a host wait). */
+int oddio_hip_scene_set_exact_updates(oddio_hip_scene* scene, int wait_for_staging);
 /* Number of live sources in the set after the last sample call (== `scene.recv.len()` in the
  * reference's own test, src/spatial.rs:643). */
 int oddio_hip_scene_len(oddio_hip_scene* scene, size_t* len);

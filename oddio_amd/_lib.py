@@ -103,6 +103,7 @@ def lib():
         "oddio_hip_scene_set_listener_rotation": (i32, [vp, fp]),
         "oddio_hip_scene_set_postfx": (i32, [vp, i32]),
         "oddio_hip_scene_set_mode": (i32, [vp, i32]),
+        "oddio_hip_scene_set_exact_updates": (i32, [vp, i32]),
         "oddio_hip_scene_len": (i32, [vp, C.POINTER(sz)]),
         "oddio_hip_scene_sample": (i32, [vp, f32, fp, sz]),
         "oddio_hip_scene_run": (i32, [vp, u32, fp, sz]),

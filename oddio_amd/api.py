@@ -417,6 +417,10 @@ class _SceneSignal(Signal):
     def set_mode(self, mode):
         _lib.check(_lib.lib().oddio_hip_scene_set_mode(self._h, int(mode)))
 
+    def set_exact_updates(self, wait_for_staging: bool):
+        """Un-synchronised `sample_device` callers: wait for a staging slot rather than let updates slip a callback."""
+        _lib.check(_lib.lib().oddio_hip_scene_set_exact_updates(self._h, int(bool(wait_for_staging))))
+
     def set_profiling(self, on):
         """False/0 off, True/1 events around every stage, 2 events around the mix kernel only."""
         _lib.check(_lib.lib().oddio_hip_scene_set_profiling(self._h, 2 if on == 2 else int(bool(on))))

@@ -135,14 +135,16 @@ def test_random_operations_bit_exact(seed):
     scene.close()
 
 
+@pytest.mark.parametrize("exact", [False, True])
 @pytest.mark.parametrize("seed", range(6))
-def test_random_operations_unsynchronised(seed):
+def test_random_operations_unsynchronised(seed, exact):
     """The same operation stream with the callbacks ENQUEUED (oddio_hip_scene_sample_device): inserts, removals, handle-id
     reuse and control updates all take effect in stream order on the device while the host runs ahead (decisions that
-    need `is_finished` use the oracle's answer).  The host waits only every third callback: the library stages a
-    callback's updates in one of three pinned slots, and a callback that finds all of them still unread by the device
-    leaves its updates queued for the next one (it never waits) -- beyond that distance the device path is no longer
-    callback-for-callback the reference.  Outputs compared afterwards."""
+    need `is_finished` use the oracle's answer).  The library stages a callback's updates in one of three pinned slots;
+    by default a callback that finds all of them still unread by the device leaves its updates queued for the next
+    one (it never waits), so `exact=False` lets the host run at most three callbacks ahead.  `exact=True`
+    (oddio_hip_scene_set_exact_updates) enqueues all 60 callbacks without a single host wait of the test's own: the
+    library then waits for a slot instead of letting updates slip.  Outputs compared afterwards."""
     import torch
     import oddio_amd as oa
     rng = np.random.default_rng(19000 + seed)
@@ -150,6 +152,7 @@ def test_random_operations_unsynchronised(seed):
     if LIVE_MAX > 200:
         scene.reserve_buffered(LIVE_MAX + 36)
     fast = False
+    scene.set_exact_updates(exact)
     sizes, wants = [], []
     dev_out = torch.zeros((60, 1536, 2), dtype=torch.float32, device="cuda")
     scene.set_mode(oa.MODE_FAST if fast else oa.MODE_ORDERED)
@@ -238,7 +241,7 @@ def test_random_operations_unsynchronised(seed):
         wants.append(ref.sample_n(INTERVAL, n))
         sizes.append(n)
         scene.sample_device(INTERVAL, dev_out[cb].data_ptr(), n)
-        if cb % 3 == 2:
+        if not exact and cb % 3 == 2:
             scene.synchronize()
         peak_len = max(peak_len, len(ref_scene) + ref_scene.len_buffered())
         removed_seen = removed_seen or any(e[1].is_finished() for e in live)
