@@ -96,6 +96,7 @@ def test_sample_device_removal_and_insertion_order_is_the_references(torch_cuda)
     clips = [synth.noise_clip(77, i, lens[i]) for i in range(200)]
     control, scene = oa.SpatialScene(max_sources=256, max_frames=1024)
     scene.set_mode(oa.MODE_ORDERED)
+    scene.set_exact_updates(True)      # 14 callbacks with plays in between and no wait of the test's own: never let an update slip a callback
     oscene = oc.SpatialScene()
     handles = []
     nxt = [0]

@@ -30,6 +30,7 @@ def test_thousands_of_sources_stop_in_one_callback(device_mode):
     total = sum(g[0] for g in groups)
     control, scene = oa.SpatialScene(max_sources=total + 64, max_frames=N)
     scene.set_mode(oa.MODE_ORDERED)
+    scene.set_exact_updates(True)      # the device-mode variant enqueues 12 callbacks without a wait
     ref = oc.SpatialScene()
     handles = []
     seed = 31
