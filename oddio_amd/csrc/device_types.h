@@ -72,6 +72,24 @@ struct alignas(16) EarParams {
 };
 static_assert(sizeof(EarParams) == 32, "EarParams layout");
 
+// What the walk kernel leaves for the mix kernel per (source, 512-frame tile): everything of frames.rs:176-201's
+// set-up that does not depend on the output frame -- the f64 cursor split per 256-frame chunk (`frac0`), the
+// resample step, the gain ramp, and the clip window the tile touches as a ready-made buffer descriptor -- so that
+// spatial_mix starts each source from 64 bytes instead of redoing the f64 arithmetic per tile.
+//   desc     buffer descriptor words 0-2 of the window, clipped to the clip (kernels.h window_desc)
+//   info     path (bits 0-2) | SFLAG_* (bits 3-7) | nvec (bits 8-15: 16-byte vectors of the window) | negvec (bits
+//            16-23: vectors of the window that lie before the clip start; the descriptor base is the clip start then)
+//   ear[e]   {ds, g0, dg, wrel chunk 0 | chunk 1 << 16}: wrel = the chunk's base index relative to the window start
+//   frac0    [ear][chunk] the chunk's start offset (frames.rs:181/189)
+struct alignas(16) TileRec {
+    uint32_t desc[3];
+    uint32_t info;
+    struct { float ds, g0, dg; uint32_t wrel; } ear[2];
+    float frac0[2][2];
+};
+static_assert(sizeof(TileRec) == 64, "TileRec layout");
+constexpr int REC_TILES = 2;   // tiles whose records the walk kernel writes itself; longer callbacks run in passes of this many tiles
+
 struct SceneParams {
     float prev_rot[4];      // (s,x,y,z) listener rotation used for the callback's start
     float rot[4];           //           ... and for its end (spatial.rs:382-386)

@@ -286,23 +286,19 @@ enum : int { PATH_SKIP = 0, PATH_LDS = 1, PATH_GENERIC = 2, PATH_SINE = 3, PATH_
 //         |ds-1| <= EPSILON fast path) are re-laid in place with one pad float per 16 samples
 //         (slot s + s/16; the pad repeats the next sample), otherwise the lanes' 16-frame runs,
 //         16 samples apart, would all hit two banks.
-//   CKPT  64 phase-A lanes x 16 cursor checkpoints, xor-swizzled (checkpoint 0 == the chunk's
-//         start offset frac0)
-//   CINFO per phase-A lane: window-relative base index
-//   EPAR  per (source, ear) {g0, dg, ds, -}
-//   SINFO per source {path, flags, nvec, fixed_gain} {window descriptor: word 0, word 1, bytes, start offset}
+//   STREAM 64 blocks of 20 words, one per phase-A stream (source j, ear e, chunk c) = lane 4j + 2e + c:
+//         words 0-15 the cursor checkpoints (checkpoint 0 == the chunk's start offset frac0),
+//         words 16-19 {4 * wrel, g0, dg, ds}: what a phase-B lane of that stream needs besides its checkpoint.
 constexpr int LDS_WIN0 = 0;
 constexpr int WIN_BYTES = WIN_CAP * 4;
 constexpr int LDS_WIN1 = LDS_WIN0 + WIN_BYTES;
-constexpr int LDS_CKPT = LDS_WIN1 + WIN_BYTES;
-constexpr int LDS_CINFO = LDS_CKPT + 64 * 16 * 4;
-constexpr int LDS_EPAR = LDS_CINFO + 64 * 4;
-constexpr int LDS_SINFO = LDS_EPAR + MIX_GROUP * 2 * 16;
-constexpr int LDS_TOTAL = LDS_SINFO + MIX_GROUP * 8 * 4;
-constexpr int SFLAG_NEG = 1, SFLAG_FAST_L = 2, SFLAG_FAST_R = 4, SFLAG_PAD = 8;
+constexpr int LDS_STREAM = LDS_WIN1 + WIN_BYTES;
+constexpr int STREAM_WORDS = 20;
+constexpr int LDS_TOTAL = LDS_STREAM + 64 * STREAM_WORDS * 4;
+constexpr int SFLAG_NEG = 1, SFLAG_FAST_L = 2, SFLAG_FAST_R = 4, SFLAG_PAD = 8, SFLAG_FG = 16;
 static_assert(WIN_BYTES % 16 == 0 && LDS_TOTAL % 16 == 0, "per-wave LDS slices and window buffers stay 16-byte aligned");
 static_assert(LDS_TOTAL <= 10240, "16 waves per CU need <= 10 KB of LDS each");
-static_assert(LDS_CKPT >= 16 * 64 * 4, "accumulator parking / cross-wave reduction use 4 KB at offset 0 and must not reach CKPT");
+static_assert(LDS_STREAM >= 16 * 64 * 4, "accumulator parking / cross-wave reduction use 4 KB at offset 0 and must not reach the stream blocks");
 static_assert(WIN_PIECES * 1024 <= 4095 + 1024, "the DMA's 12-bit instruction offset reaches every piece");
 
 __device__ __forceinline__ void wave_sync() {
@@ -476,13 +472,124 @@ template <class T> __device__ __forceinline__ void wave_aos_store(const T& in, T
 }
 struct alignas(16) EarPair { EarParams e[2]; };
 
+// HBM -> LDS window descriptor: samples [ws, ws + 4*nvec) of a clip through a buffer descriptor clipped to
+// [window, clip end): lanes outside it get zeros with no memory traffic (frames.rs:105-123).
+// Returns {descriptor word 0, word 1, byte count, byte offset of the window start relative to the descriptor
+// base (<= 0)}.
+__device__ __forceinline__ int4 window_desc(const float* clip, int clip_len4, int ws, int nvec) {
+    const int ws_pos = ws > 0 ? ws : 0;             // first in-clip sample of the window
+    const int neg4 = (ws < 0 ? ws : 0) * 4;         // byte offset of the window start relative to it (<= 0)
+    long long rec = (long long)(clip_len4 - ws_pos) * 4;          // bytes to the (padded) clip end
+    const long long wend = (long long)neg4 + (long long)nvec * 16;   // bytes to the window end
+    if (rec > wend) rec = wend;
+    if (rec < 0) rec = 0;
+    const uint64_t base = (uint64_t)(clip + ws_pos);
+    return make_int4((int)(base & 0xffffffffu), (int)((base >> 32) & 0xffffu), (int)rec, neg4);   // stride 0
+}
+
+// frames.rs:176-201's per-chunk set-up for one (source, 512-frame tile): what spatial_mix's phase A used to redo per
+// tile.  A pure function of the walk's per-ear results (EarParams), the source and the tile index.
+//   per (ear, chunk) stream: t_c = the inner clock at the chunk's start (frames.rs:198 applied per earlier chunk),
+//   s0 = t_c * rate (f64, :177), base = s0 as isize (:179), frac0 = (s0 - base) as f32 (:181/:189), ds (:178);
+//   the window = every sample index the tile's four streams can touch.  Its upper end only has to be an upper bound:
+//   the cursor after 255 sequentially rounded `offset += ds` steps is below frac0 + 255 * ds by at most
+//   255 half-ulps of its own magnitude, so the closed form plus that margin covers it.
+__device__ __forceinline__ TileRec make_tile_rec(const SceneParams& P, const SrcStatic& s, const EarParams& e0, const EarParams& e1, uint32_t tile) {
+    TileRec r = {};                                  // info == 0: PATH_SKIP
+    if (e0.flags & EAR_SKIP) return r;
+    if (s.kind == KIND_SINE) { r.info = PATH_SINE; return r; }
+    if (s.kind == KIND_CONSTANT) { r.info = PATH_CONST; return r; }
+    if (s.kind == KIND_CYCLE) { r.info = PATH_ROW; return r; }
+    if (s.kind != KIND_FRAMES) { r.info = PATH_GENERIC; return r; }   // Downmix: exact per-lane path
+    int lo = 0x7fffffff, hi = (int)0x80000000, generic = 0, fl = 0;
+    int wbase[2][2];
+    const double rate = (double)s.clip_rate;
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+        const EarParams& ep = e ? e1 : e0;
+        const float ds = ep.dt * (float)s.clip_rate;                                      // frames.rs:178
+        const float dev = fabsf(ds - 1.0f);
+        const bool fast = dev <= FLT_EPSILON;                                            // :180
+        if (fast) fl |= e ? SFLAG_FAST_R : SFLAG_FAST_L;
+        if (dev < PAD_EPS) fl |= SFLAG_PAD;
+        // the staged path needs a forward-running, sane cursor; everything else is exact but slow
+        if (!(ds > 0.0f) || !(ds < 4096.0f)) generic = 1;
+        double t_c = ep.t_ear;
+        for (uint32_t cc = 0; cc < tile * TILE_CHUNKS; ++cc) t_c = t_c + (double)ep.dt * 256.0;   // frames.rs:198 per chunk
+#pragma unroll
+        for (int c = 0; c < TILE_CHUNKS; ++c) {
+            const uint32_t c_abs = tile * TILE_CHUNKS + (uint32_t)c;
+            const int rem = (int)P.n_frames - (int)(c_abs * 256u);
+            const int len = rem < 0 ? 0 : (rem > 256 ? 256 : rem);
+            const double s0 = t_c * rate;                                                 // :177
+            const long long base = f64_as_isize(s0);                                      // :179
+            const float frac0 = (float)(s0 - (double)base);                               // :181 / :189
+            if (!(fabs(s0) < 1.0e9)) generic = 1;
+            if (frac0 < 0.0f) fl |= SFLAG_NEG;
+            wbase[e][c] = (int)base;
+            r.frac0[e][c] = frac0;
+            if (len > 0 && !generic) {
+                int i0, i1;
+                if (fast) { i0 = (int)base; i1 = (int)base + 255; }
+                else {
+                    const double xb = (double)frac0 + 255.0 * (double)ds;
+                    const double xu = xb + fabs(xb) * 4.0e-5 + 1.0e-4;                    // >= the exactly rounded running sum
+                    if (!(xu < 8.0e6)) generic = 1;
+                    i0 = (int)base + (int)frac0;
+                    i1 = (int)base + (int)xu;
+                }
+                lo = min(lo, min(i0, i1));
+                hi = max(hi, max(i0, i1));
+            }
+            t_c = t_c + (double)ep.dt * 256.0;
+        }
+        r.ear[e].ds = ds; r.ear[e].g0 = ep.g0; r.ear[e].dg = ep.dg;
+    }
+    const int ws = lo & ~3;
+    const int count = hi + 2 - ws;
+    {   // the padded layout (one extra slot per 16 samples, written a whole 16-byte vector at a time) must fit the
+        // window buffer too.  Near-unit windows are ~550 samples, but a listener rotation inside the callback can pull
+        // one ear's ratio to 1 while the other's window grows to the full 608: re-laid, that window would run 12 floats
+        // into the next buffer.  Such a source keeps the plain layout (bank conflicts only), or, if it needs the
+        // constant-fract branch that only the padded variant implements, the exact per-lane path.
+        const int vec_samples = ((count + 3) >> 2) << 2;
+        if ((fl & SFLAG_PAD) && vec_samples + (vec_samples >> 4) + 1 > WIN_CAP) {
+            if (fl & (SFLAG_FAST_L | SFLAG_FAST_R)) generic = 1;
+            else fl &= ~SFLAG_PAD;
+        }
+    }
+    int path;
+    if (generic) path = PATH_GENERIC;
+    else if (lo > hi) path = PATH_SKIP;              // no frames in this tile
+    else path = (count <= WIN_CAP) ? PATH_LDS : PATH_GENERIC;
+    if (path != PATH_LDS) { r.info = (uint32_t)path; return r; }
+    if (s.fixed_gain != 1.0f) fl |= SFLAG_FG;
+    const int nvec = (count + 3) >> 2;
+    const int4 d = window_desc(s.clip, (int)((s.clip_len + 3u) & ~3u), ws, nvec);
+    r.desc[0] = (uint32_t)d.x; r.desc[1] = (uint32_t)d.y; r.desc[2] = (uint32_t)d.z;
+    // a window that starts before the clip: the descriptor base is the clip start and the first -ws/4 vectors are out
+    // of range (zeros); one that lies entirely before it has a zero-byte descriptor, any offset reads zeros
+    const int negvec = (d.z > 0) ? ((-d.w) >> 4) : 0;
+    r.info = (uint32_t)path | ((uint32_t)fl << 3) | ((uint32_t)nvec << 8) | ((uint32_t)negvec << 16);
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+        const int w0 = min(max(wbase[e][0] - ws, 0), 65535), w1 = min(max(wbase[e][1] - ws, 0), 65535);
+        r.ear[e].wrel = (uint32_t)w0 | ((uint32_t)w1 << 16);
+    }
+    return r;
+}
+
 // `d_len` is the device-resident set length (set_kernels.h); `len_snap` receives the length this walk saw
 // (the mix kernel of the callback reads it; the set is compacted at the end of the callback).
+// `recs`: the tile records of the callback's first `n_rec_tiles` (<= REC_TILES) tiles, [tile][rec_stride].
+// EarParams are written only where something reads them: the out-of-line paths of spatial_mix / cycle_sources and
+// tile_records (callbacks longer than REC_TILES tiles).
 __global__ __launch_bounds__(256) void spatial_prepass(SceneParams P, const SrcStatic* __restrict__ st,
                                                        SrcDyn* __restrict__ dyn, SrcPending* __restrict__ pend,
                                                        EarParams* __restrict__ ear, uint32_t* __restrict__ stopped_hdr,
                                                        uint32_t stopped_cap, int check_pending, const uint32_t* __restrict__ d_len,
-                                                       uint32_t* __restrict__ len_snap) {
+                                                       uint32_t* __restrict__ len_snap, TileRec* __restrict__ recs, uint32_t rec_stride,
+                                                       uint32_t n_rec_tiles, int ear_always) {
     __shared__ uint32_t stage[4][64 * 17];
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     const int lane = threadIdx.x & 63;
@@ -497,51 +604,71 @@ __global__ __launch_bounds__(256) void spatial_prepass(SceneParams P, const SrcS
     wave_aos_load(d, dyn, first, n_valid, lane, lds);
     wave_aos_load(s, st, first, n_valid, lane, lds);
     EarPair ep = {};
+    ep.e[0].flags = EAR_SKIP; ep.e[1].flags = EAR_SKIP;
     if (i < len) prepass_source(P, i, d, s, pend, ep.e[0], ep.e[1], stopped_hdr, stopped_cap, check_pending);
-    wave_aos_store(ep, reinterpret_cast<EarPair*>(ear), first, n_valid, lane, lds);
+    bool needs_ear = false;
+    for (uint32_t t = 0; t < n_rec_tiles; ++t) {
+        const TileRec r = make_tile_rec(P, s, ep.e[0], ep.e[1], t);
+        const uint32_t path = r.info & 7u;
+        needs_ear = needs_ear || (path != PATH_LDS && path != PATH_SKIP);
+        wave_aos_store(r, recs + (size_t)t * rec_stride, first, n_valid, lane, lds);
+    }
+    needs_ear = needs_ear || (i < len && s.kind == KIND_CYCLE);    // cycle_sources reads the flags of a stopped Cycle too
+    if (ear_always || __any(needs_ear)) wave_aos_store(ep, reinterpret_cast<EarPair*>(ear), first, n_valid, lane, lds);
     wave_aos_store(d, dyn, first, n_valid, lane, lds);
+}
+
+// Callbacks longer than REC_TILES tiles run the mix in passes; this writes the records of the pass's tiles
+// [tile0, tile0 + n) from the EarParams the walk left.
+__global__ __launch_bounds__(256) void tile_records(SceneParams P, const SrcStatic* __restrict__ st, const EarParams* __restrict__ ear,
+                                                    const uint32_t* __restrict__ len_snap, TileRec* __restrict__ recs, uint32_t rec_stride,
+                                                    uint32_t tile0, uint32_t n) {
+    __shared__ uint32_t stage[4][64 * 17];
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    uint32_t* lds = stage[threadIdx.x >> 6];
+    const uint32_t len = *len_snap;
+    const uint32_t first = i - (uint32_t)lane;
+    if (first >= len) return;
+    const uint32_t n_valid = (len - first) < 64u ? (len - first) : 64u;
+    SrcStatic s = {};
+    EarPair ep = {};
+    wave_aos_load(s, st, first, n_valid, lane, lds);
+    wave_aos_load(ep, reinterpret_cast<const EarPair*>(ear), first, n_valid, lane, lds);
+    if (i >= len) { ep.e[0].flags = EAR_SKIP; ep.e[1].flags = EAR_SKIP; }
+    for (uint32_t t = 0; t < n; ++t) {
+        const TileRec r = make_tile_rec(P, s, ep.e[0], ep.e[1], tile0 + t);
+        wave_aos_store(r, recs + (size_t)t * rec_stride, first, n_valid, lane, lds);
+    }
 }
 
 
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
-// HBM -> LDS: samples [ws, ws + 4*nvec) of a clip into the window buffer at LDS byte address
-// `lds_dst`, 16 B per lane per 1 KiB piece, through a buffer descriptor clipped to [window, clip
-// end): lanes outside it get zeros with no memory traffic (frames.rs:105-123).  The loads are issued
-// from inline asm on purpose: hipcc would make every later ds_read wait for ALL outstanding LDS-DMA
-// (it cannot tell the two window buffers apart), which would serialise the prefetch of the next
-// source with the reads of the current one.  Completion is awaited with window_wait().
-// `desc` = {descriptor word 0, word 1, byte count, byte offset of the window start relative to the
-// descriptor base (<= 0)}, made by window_desc() in phase A; wave-uniform.
-__device__ __forceinline__ int4 window_desc(const float* clip, int clip_len4, int ws, int nvec) {
-    const int ws_pos = ws > 0 ? ws : 0;             // first in-clip sample of the window
-    const int neg4 = (ws < 0 ? ws : 0) * 4;         // byte offset of the window start relative to it (<= 0)
-    long long rec = (long long)(clip_len4 - ws_pos) * 4;          // bytes to the (padded) clip end
-    const long long wend = (long long)neg4 + (long long)nvec * 16;   // bytes to the window end
-    if (rec > wend) rec = wend;
-    if (rec < 0) rec = 0;
-    const uint64_t base = (uint64_t)(clip + ws_pos);
-    return make_int4((int)(base & 0xffffffffu), (int)((base >> 32) & 0xffffu), (int)rec, neg4);   // stride 0
-}
+// HBM -> LDS: the window of one (source, tile) into the window buffer at LDS byte address `lds_dst`, 16 B per
+// lane per 1 KiB piece, through the bounds-checked descriptor the walk kernel made (window_desc): lanes outside
+// it get zeros with no memory traffic (frames.rs:105-123).  The loads are issued from inline asm on purpose: hipcc
+// would make every later ds_read wait for ALL outstanding LDS-DMA (it cannot tell the two window buffers apart),
+// which would serialise the prefetch of the next source with the reads of the current one.  Completion is awaited
+// with window_wait().  d0..d2, info: wave-uniform words of the source's TileRec; lane16 = 16 * lane.
 constexpr int WIN_LAST_LANES = (WIN_BYTES - 2048) / 16;   // lanes of the third piece that stay inside the window buffer
-__device__ __forceinline__ void window_dma(uint32_t lds_dst, int4 desc, int nvec, int lane) {
+__device__ __forceinline__ void window_dma(uint32_t lds_dst, uint32_t d0, uint32_t d1, uint32_t d2, uint32_t info, int lane16) {
     u32x4 rsrc;
-    rsrc.x = (uint32_t)__builtin_amdgcn_readfirstlane(desc.x);
-    rsrc.y = (uint32_t)__builtin_amdgcn_readfirstlane(desc.y);
-    rsrc.z = (uint32_t)__builtin_amdgcn_readfirstlane(desc.z);
+    rsrc.x = d0; rsrc.y = d1; rsrc.z = d2;
     rsrc.w = 0x00020000u;
-    const uint32_t dst = (uint32_t)__builtin_amdgcn_readfirstlane((int)lds_dst);
-    const int voff = __builtin_amdgcn_readfirstlane(desc.w) + 16 * lane;   // negative offsets wrap to huge unsigned values: out of range -> 0
+    const int nvec = (int)((info >> 8) & 255u);
+    const int neg = -16 * (int)((info >> 16) & 255u);
+    const int voff = neg + lane16;   // negative offsets wrap to huge unsigned values: out of range -> 0
     uint32_t keep;
     // pieces 0 and 1 from every lane: lanes past the window write zeros inside the buffer (harmless, no traffic)
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 4\n\t"
                  "buffer_load_dwordx4 %1, %2, 0 offen lds\n\tbuffer_load_dwordx4 %1, %2, 0 offen offset:1024 lds\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(voff), "s"(rsrc), "s"(dst) : "memory");
+                 : "=&s"(keep) : "v"(voff), "s"(rsrc), "s"(lds_dst) : "memory");
     if (nvec > 128) {
-        if (lane < WIN_LAST_LANES)
+        if (lane16 < 16 * WIN_LAST_LANES)
             asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen offset:2048 lds\n\ts_mov_b32 m0, %0"
-                         : "=&s"(keep) : "v"(voff), "s"(rsrc), "s"(dst) : "memory");
+                         : "=&s"(keep) : "v"(voff), "s"(rsrc), "s"(lds_dst) : "memory");
     }
     static_assert(WIN_PIECES == 3 && WIN_LAST_LANES > 0 && WIN_LAST_LANES <= 64, "three pieces cover a window buffer");
 }
@@ -573,16 +700,24 @@ __device__ __forceinline__ void window_repack_padded(unsigned char* win_bytes, i
 // One source, staged-window path.  acc[i] += lerp * gain for this lane's ear (spatial.rs:458-462).
 // NONNEG: every cursor value of the source is >= 0, so fract(x) == x - trunc(x) (one v_fract_f32).
 // PAD: padded window layout (see above); also serves frames.rs:180-187's constant-fract path.
-// `x` is the lane's checkpoint (the cursor at its first frame), `wrel` its chunk's base index
+// `x` is the lane's checkpoint (the cursor at its first frame), `wrel4` 4 x its chunk's base index
 // relative to the window start.
+// The accumulate is an in-place v_add_f32 (inline asm with a tied operand) in the FULL kernels: hipcc otherwise
+// gives the sums of each inlined variant fresh registers and copies all 16 back at every join.
+template <bool FULL>
+__device__ __forceinline__ void acc_add(float& acc, float p, bool on) {
+    if (FULL) asm("v_add_f32 %0, %0, %1" : "+v"(acc) : "v"(p));
+    else if (on) acc = acc + p;
+}
 template <bool FULL, bool HAS_FG, bool NONNEG, bool PAD>
-__device__ __forceinline__ void mix_source_lds(const float* win, int wrel, float x, int b, int fast, float frac0, float (&acc)[16],
+__device__ __forceinline__ void mix_source_lds(const unsigned char* win_bytes, int wrel4, float x, int b, int fast, float frac0, float (&acc)[16],
                                                const float (&fi)[16], uint32_t frame0, uint32_t n_frames, float fixed_gain, float g0, float dg,
                                                float ds) {
     if (!FULL && frame0 >= n_frames) return;   // this lane's 16 frames lie past the end of `out`
+    const float* win = reinterpret_cast<const float*>(win_bytes);
     if (PAD && fast) {
         // frames.rs:180-187 (|ds - 1| <= EPSILON): constant fract, consecutive pairs
-        const int w0 = wrel + 16 * b;
+        const int w0 = (wrel4 >> 2) + 16 * b;
         float a = win[w0 + (w0 >> 4)];
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
@@ -591,7 +726,7 @@ __device__ __forceinline__ void mix_source_lds(const float* win, int wrel, float
             float v = a + frac0 * (bb - a);
             if (HAS_FG) v = v * fixed_gain;
             const float p = v * (g0 + fi[i] * dg);
-            if (FULL || frame0 + (uint32_t)i < n_frames) acc[i] = acc[i] + p;
+            acc_add<FULL>(acc[i], p, frame0 + (uint32_t)i < n_frames);
             a = bb;
         }
         return;
@@ -599,7 +734,8 @@ __device__ __forceinline__ void mix_source_lds(const float* win, int wrel, float
     // frames.rs:189-196: x_{16b+i} = x_{16b} (+ ds) i times, exactly as the scan produced it.
     // Software pipelined by hand: the pair reads of samples i+1 .. i+MIX_DEPTH are issued before
     // sample i is consumed; sched_barrier keeps hipcc from sinking them back next to their use.
-    const float* wbase = win + wrel;
+    const float* wbase = reinterpret_cast<const float*>(win_bytes + wrel4);
+    const int wrel = wrel4 >> 2;
     float a[16], bb[16], fr[16];
 #define ODDIO_ISSUE(I)                                                                  \
     {                                                                                   \
@@ -622,7 +758,7 @@ __device__ __forceinline__ void mix_source_lds(const float* win, int wrel, float
         float v = a[i] + fr[i] * (bb[i] - a[i]);              // frame.rs:39-41 lerp, unfused
         if (HAS_FG) v = v * fixed_gain;                       // gain.rs:32-37
         const float p = v * (g0 + fi[i] * dg);                // spatial.rs:459-460
-        if (FULL || frame0 + (uint32_t)i < n_frames) acc[i] = acc[i] + p;
+        acc_add<FULL>(acc[i], p, frame0 + (uint32_t)i < n_frames);
         __builtin_amdgcn_sched_barrier(0);
     }
 #undef ODDIO_ISSUE
@@ -713,9 +849,36 @@ __device__ __noinline__ void mix_source_rare(float* acc_lds, int lane, uint32_t 
     }
 }
 
-// grid = (n_workgroups, n_tiles); block = 64 * MIX_WG_WAVES.  Wave w walks groups [g_lo, g_hi) of
+// v_mov_b32_dpp quad_perm:[K,K,K,K]: every lane reads lane K of its group of four
+template <int K> __device__ __forceinline__ float quad_bcast(float v) {
+    return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), K * 0x55, 0xf, 0xf, true));
+}
+
+// STORE (ORDERED mode at scale): one source's 16 accumulators of every lane -> its rows in `contrib`.
+// A lane's 16 values are one 64-byte row; written as they are, every store instruction would touch 64 separate
+// lines with 16 bytes each.  The four lanes of a quad (four adjacent column blocks) instead exchange 16-byte pieces
+// (DPP, registers only), so that store k writes the whole row of the quad's lane k: 64 contiguous bytes per quad.
+__device__ __forceinline__ void store_rows(const float (&acc)[16], unsigned char* group_base, uint32_t voff, int lane) {
+    const int i = lane & 3;
+    float4 o[4];
+#define ODDIO_PICK(K, M) \
+    { const float c0 = quad_bcast<K>(acc[M]), c1 = quad_bcast<K>(acc[4 + M]), c2 = quad_bcast<K>(acc[8 + M]), c3 = quad_bcast<K>(acc[12 + M]); \
+      const float v = i == 0 ? c0 : (i == 1 ? c1 : (i == 2 ? c2 : c3)); \
+      if (M == 0) o[K].x = v; else if (M == 1) o[K].y = v; else if (M == 2) o[K].z = v; else o[K].w = v; }
+#define ODDIO_PICK4(K) ODDIO_PICK(K, 0) ODDIO_PICK(K, 1) ODDIO_PICK(K, 2) ODDIO_PICK(K, 3)
+    ODDIO_PICK4(0) ODDIO_PICK4(1) ODDIO_PICK4(2) ODDIO_PICK4(3)
+#undef ODDIO_PICK4
+#undef ODDIO_PICK
+    unsigned char* p = group_base + voff;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) *reinterpret_cast<float4*>(p + k * 1024) = o[k];
+}
+
+// grid = (n_workgroups, tiles of this pass); block = 64 * MIX_WG_WAVES.  Wave w walks groups [g_lo, g_hi) of
 // 16 slots in DESCENDING order (the reference's reverse set walk, spatial.rs:204).  A workgroup
-// leaves ONE partial tile: partials[(tile * n_wgs + wg) * 1024 + e * 512 + f] (planar L | R).
+// leaves ONE partial tile: partials[(tile * n_wgs + wg) * PART_STRIDE + e * 512 + f] (planar L | R).
+// `recs`: the tile records of this pass, [blockIdx.y][rec_stride], made by the walk kernel (make_tile_rec);
+// `tile0`: the callback tile that blockIdx.y == 0 renders.
 // STORE (ORDERED mode at scale): instead of accumulating, every source's contribution `s * gain` (spatial.rs:459-460)
 // is written out -- layout contrib[group of 16 sources][ear][column block of 16 frames][source in group][16], i.e. a
 // lane's 16 accumulators are one 64-byte row, a group fills one 1-KiB chunk per (ear, column block) and everything a
@@ -724,6 +887,7 @@ __device__ __noinline__ void mix_source_rare(float* acc_lds, int lane, uint32_t 
 template <bool FULL, bool STORE = false>
 __global__ __launch_bounds__(64 * MIX_WG_WAVES, MIX_WAVES_PER_SIMD) void spatial_mix(SceneParams P, const SrcStatic* __restrict__ st,
                                                                                      const EarParams* __restrict__ ear,
+                                                                                     const TileRec* __restrict__ recs, uint32_t rec_stride, uint32_t tile0,
                                                                                      float* __restrict__ partials, const float* __restrict__ init,
                                                                                      uint32_t groups_per_wave, uint32_t n_groups,
                                                                                      const uint32_t* __restrict__ n_sources_ptr,
@@ -732,14 +896,12 @@ __global__ __launch_bounds__(64 * MIX_WG_WAVES, MIX_WAVES_PER_SIMD) void spatial
     const uint32_t n_sources = *n_sources_ptr;   // the set length this callback's walk saw (n_groups is the host's upper bound)
     const int wv = threadIdx.x >> 6;
     unsigned char* smem = smem_all + LDS_TOTAL * wv;
-    float* ckpt = reinterpret_cast<float*>(smem + LDS_CKPT);
-    int* cinfo = reinterpret_cast<int*>(smem + LDS_CINFO);
-    float4* epar = reinterpret_cast<float4*>(smem + LDS_EPAR);
-    int* sinfo = reinterpret_cast<int*>(smem + LDS_SINFO);
     // LDS byte address of this wave's slice (what the DMA's M0 wants): low half of the flat address
-    const uint32_t lds_slice = (uint32_t)(uintptr_t)smem;
+    const uint32_t lds_slice = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uintptr_t)smem);
     const int lane = threadIdx.x & 63;
-    const uint32_t wave = blockIdx.x * MIX_WG_WAVES + wv, tile = blockIdx.y;
+    const int lane16 = 16 * lane;
+    const uint32_t wave = blockIdx.x * MIX_WG_WAVES + wv, tile = tile0 + blockIdx.y;
+    const TileRec* __restrict__ trecs = recs + (size_t)blockIdx.y * rec_stride;
     const uint32_t n_frames = P.n_frames;
     float acc[16], fi[16];
     // phase-B role: ear e, chunk c (of the tile), block b -> 16 consecutive frames
@@ -763,190 +925,141 @@ __global__ __launch_bounds__(64 * MIX_WG_WAVES, MIX_WAVES_PER_SIMD) void spatial
 
     // phase-A role: source j of the group, ear e, chunk c
     const int jA = lane >> 2, eA = (lane >> 1) & 1, cA = lane & 1;
-    const uint32_t cA_abs = tile * TILE_CHUNKS + (uint32_t)cA;
-    const int remA = (int)n_frames - (int)(cA_abs * 256u);
-    const int lenA = remA < 0 ? 0 : (remA > 256 ? 256 : remA);
+    // this lane's stream block in phase B belongs to stream 4j + 2e + c: byte offset of source 0's, then 4 blocks per source
+    unsigned char* const blkB0 = smem + LDS_STREAM + (eB * 2 + cB) * (STREAM_WORDS * 4);
+    constexpr int BLK_SRC = 4 * STREAM_WORDS * 4;            // bytes of stream blocks per source
+    // STORE: this lane's byte offset inside a group's rows for source 0 (store_rows)
+    const uint32_t row_off0 = (((uint32_t)eB * contrib_ncb + ((frame0 >> 4) & ~3u)) * MIX_GROUP) * 64u + 16u * (uint32_t)(lane & 3);
 
     for (uint32_t g = g_hi; g-- > g_lo;) {
+        const TileRec* __restrict__ grec = trecs + (size_t)g * MIX_GROUP;
         // ------------------------------ phase A ------------------------------
+        // lanes 0-15 keep {descriptor words, info} of source `lane` for the whole group (read per source with
+        // v_readlane: wave-uniform values without a trip through memory)
+        uint4 vdesc = make_uint4(0u, 0u, 0u, 0u);
+        float4 q = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        float frac0 = 0.0f;
         {
             const uint32_t srcA = g * MIX_GROUP + (uint32_t)jA;
-            const bool validA = srcA < n_sources;
-            EarParams ep = {};
-            SrcStatic ss = {};
-            ep.flags = EAR_SKIP;
-            if (validA) { ep = ear[2 * srcA + eA]; ss = st[srcA]; }
-            const bool live = validA && !(ep.flags & EAR_SKIP);
-            int lo = 0x7fffffff, hi = (int)0x80000000;
-            int generic = 0, wbase = 0;
-            int fl = 0;                              // SFLAG_* contributed by this stream
-            float frac0 = 0.0f, ds = 0.0f;
-            if (live && ss.kind == KIND_DOWNMIX) generic = 1;
-            if (live && ss.kind == KIND_FRAMES) {
-                double t_c = ep.t_ear;
-                for (uint32_t cc = 0; cc < cA_abs; ++cc) t_c = t_c + (double)ep.dt * 256.0;   // frames.rs:198 per chunk
-                const double s0 = t_c * (double)ss.clip_rate;                                 // frames.rs:177
-                ds = ep.dt * (float)ss.clip_rate;                                             // :178
-                const long long base = f64_as_isize(s0);                                      // :179
-                frac0 = (float)(s0 - (double)base);                                           // :181 / :189
-                const float dev = fabsf(ds - 1.0f);
-                if (dev <= FLT_EPSILON) fl |= eA ? SFLAG_FAST_R : SFLAG_FAST_L;               // :180
-                if (dev < PAD_EPS) fl |= SFLAG_PAD;
-                // the staged path needs a forward-running, sane cursor; everything else is exact but slow
-                if (!(fabs(s0) < 1.0e9) || !(ds > 0.0f) || !(ds < 4096.0f)) generic = 1;
-                if (frac0 < 0.0f) fl |= SFLAG_NEG;
-                wbase = (int)base;
+            if (lane < MIX_GROUP && g * MIX_GROUP + (uint32_t)lane < n_sources) vdesc = *reinterpret_cast<const uint4*>(grec + lane);
+            if (srcA < n_sources) {
+                const TileRec* r = grec + jA;
+                q = *reinterpret_cast<const float4*>(&r->ear[eA]);     // {ds, g0, dg, wrel}
+                frac0 = r->frac0[eA][cA];
             }
-            const bool fastA = (fl & (SFLAG_FAST_L | SFLAG_FAST_R)) != 0;
-            // exact f32 cursor scan (frames.rs:189-196); checkpoints every 16 frames, xor-swizzled so
-            // that both this (lane-strided) write and phase B's read are bank-conflict free
+        }
+        // bit j of lds_mask: source j of the group takes the staged-window path; rare_mask: an out-of-line path
+        const int pj = (int)(vdesc.w & 7u);
+        const unsigned lds_mask = (unsigned)__ballot(pj == PATH_LDS);
+        const unsigned rare_mask = (unsigned)__ballot(pj != PATH_LDS && pj != PATH_SKIP);
+        int buf = 0;
+        // `cur`: the next staged source of the walk; its window is in flight to / sits in WIN[buf]
+        int cur = lds_mask ? 31 - __builtin_clz(lds_mask) : -1;
+        uint32_t cur_info = 0;
+#define ODDIO_ISSUE_WINDOW(JN, BUF)                                                                                       \
+    window_dma(lds_slice + (uint32_t)((BUF) ? LDS_WIN1 : LDS_WIN0), (uint32_t)__builtin_amdgcn_readlane((int)vdesc.x, (JN)),  \
+               (uint32_t)__builtin_amdgcn_readlane((int)vdesc.y, (JN)), (uint32_t)__builtin_amdgcn_readlane((int)vdesc.z, (JN)), \
+               (uint32_t)__builtin_amdgcn_readlane((int)vdesc.w, (JN)), lane16);
+        if (cur >= 0) {   // the first window is on its way while the cursors are scanned
+            cur_info = (uint32_t)__builtin_amdgcn_readlane((int)vdesc.w, cur);
+            ODDIO_ISSUE_WINDOW(cur, buf)
+        }
+        {
+            // exact f32 cursor scan (frames.rs:189-196) of stream (j, e, c): checkpoints every 16 frames
+            float* blk = reinterpret_cast<float*>(smem + LDS_STREAM + lane * (STREAM_WORDS * 4));
+            const float ds = q.x;
             float x = frac0;
-            {
-                float* ck = &ckpt[lane * 16];
-                const int sw = lane & 15;
 #pragma unroll 1
-                for (int b = 0; b < 15; ++b) {
-                    ck[b ^ sw] = x;
+            for (int b = 0; b < 15; ++b) {
+                blk[b] = x;
 #pragma unroll
-                    for (int i = 0; i < 16; ++i) x = x + ds;
-                }
-                ck[15 ^ sw] = x;
-#pragma unroll
-                for (int i = 0; i < 15; ++i) x = x + ds;   // x == offset at frame 255 of the chunk
+                for (int i = 0; i < 16; ++i) x = x + ds;
             }
-            if (live && ss.kind == KIND_FRAMES && lenA > 0 && !generic) {
-                int i0, i1;
-                if (fastA) { i0 = wbase; i1 = wbase + 255; }
-                else {
-                    if (!(x < 8.0e6f)) generic = 1;
-                    i0 = wbase + (int)frac0;
-                    i1 = wbase + (int)x;
-                }
-                lo = i0 < i1 ? i0 : i1;
-                hi = i0 < i1 ? i1 : i0;
-            }
-            // per-source (4 lanes) reduction of window bounds and flags
-#pragma unroll
-            for (int m = 1; m < 4; m <<= 1) {
-                const int olo = __shfl_xor(lo, m), ohi = __shfl_xor(hi, m), og = __shfl_xor(generic, m), of = __shfl_xor(fl, m);
-                lo = olo < lo ? olo : lo;
-                hi = ohi > hi ? ohi : hi;
-                generic |= og;
-                fl |= of;
-            }
-            const int ws = lo & ~3;
-            const int count = hi + 2 - ws;
-            {   // the padded layout (one extra slot per 16 samples, written a whole 16-byte vector at a time) must fit
-                // the window buffer too.  Near-unit windows are ~550 samples, but a listener rotation inside the
-                // callback can pull one ear's ratio to 1 while the other's window grows to the full 608: re-laid, that
-                // window would run 12 floats into the next buffer.  Such a source keeps the plain layout (bank conflicts
-                // only), or, if it needs the constant-fract branch that only the padded variant implements, the exact
-                // per-lane path.
-                const int vec_samples = ((count + 3) >> 2) << 2;
-                if ((fl & SFLAG_PAD) && vec_samples + (vec_samples >> 4) + 1 > WIN_CAP) {
-                    if (fl & (SFLAG_FAST_L | SFLAG_FAST_R)) generic = 1;
-                    else fl &= ~SFLAG_PAD;
-                }
-            }
-            int path = PATH_SKIP;
-            if (live) {
-                if (ss.kind == KIND_SINE) path = PATH_SINE;
-                else if (ss.kind == KIND_CONSTANT) path = PATH_CONST;
-                else if (ss.kind == KIND_CYCLE) path = PATH_ROW;
-                else if (generic) path = PATH_GENERIC;
-                else if (lo > hi) path = PATH_SKIP;      // no frames in this tile
-                else path = (count <= WIN_CAP) ? PATH_LDS : PATH_GENERIC;
-            }
-            cinfo[lane] = wbase - ws;
-            if (cA == 0) epar[jA * 2 + eA] = make_float4(ep.g0, ep.dg, ds, 0.0f);
-            if ((lane & 3) == 0) {
-                const int nvec = (count + 3) >> 2;
-                int4* si = reinterpret_cast<int4*>(sinfo + jA * 8);
-                si[0] = make_int4(path, fl, nvec, __float_as_int(ss.fixed_gain));
-                si[1] = window_desc(ss.clip, (int)((ss.clip_len + 3u) & ~3u), ws, nvec);
-            }
+            blk[15] = x;
+            const uint32_t wr = (__float_as_uint(q.w) >> (16 * cA)) & 0xffffu;
+            *reinterpret_cast<float4*>(blk + 16) = make_float4(__uint_as_float(4u * wr), q.y, q.z, q.x);
         }
         wave_sync();
 
         // ------------------------------ phase B ------------------------------
-        // bit j of lds_mask: source j of the group takes the staged-window path; rare_mask: an out-of-line path
-        unsigned lds_mask, rare_mask;
-        {
-            const int pj = lane < MIX_GROUP ? sinfo[lane * 8 + 0] : PATH_SKIP;
-            lds_mask = (unsigned)__ballot(pj == PATH_LDS);
-            rare_mask = (unsigned)__ballot(pj != PATH_LDS && pj != PATH_SKIP);
-        }
-        int buf = 0;
-        // the window of staged source `pending` is in flight to / sits in WIN[buf]
-        int pending = lds_mask ? 31 - __builtin_clz(lds_mask) : -1;
-#define ODDIO_ISSUE_WINDOW(JN, BUF)                                                                                       \
+        // lane data of the staged source about to be mixed: its checkpoint and {4 * wrel, g0, dg, ds}
+        float cx0 = 0.0f;
+        float4 ct = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+#define ODDIO_LANE_DATA(J, X0, T)                                                                                         \
     {                                                                                                                     \
-        const int nv_ = __builtin_amdgcn_readfirstlane(sinfo[(JN) * 8 + 2]);                                              \
-        window_dma(lds_slice + (uint32_t)((BUF) ? LDS_WIN1 : LDS_WIN0), *reinterpret_cast<const int4*>(sinfo + (JN) * 8 + 4), nv_, lane); \
+        const unsigned char* blk_ = blkB0 + (J) * BLK_SRC;                                                                \
+        X0 = reinterpret_cast<const float*>(blk_)[bB];                                                                    \
+        T = *reinterpret_cast<const float4*>(blk_ + 64);                                                                  \
     }
-        // one staged source: wait for its window, start the next one's, mix
-#define ODDIO_STAGED_SOURCE(J, SJ)                                                                                        \
+        if (cur >= 0) ODDIO_LANE_DATA(cur, cx0, ct)
+        // one staged source (== cur): wait for its window, start the next one's, mix
+        // VAR: 0 the common source (no FixedGain, non-negative cursor), 1 padded layout (resample ratio within PAD_EPS
+        // of 1), 2 FixedGain and/or a cursor that starts negative; -1: decided here (wave-uniform branches)
+#define ODDIO_VARIANT(INFO) ((((INFO) >> 3) & SFLAG_PAD) ? 1 : ((((INFO) >> 3) & (SFLAG_FG | SFLAG_NEG)) ? 2 : 0))
+#define ODDIO_STAGED_SOURCE(VAR)                                                                                          \
     {                                                                                                                     \
-        const int flags_j = __builtin_amdgcn_readfirstlane((SJ).y);                                                       \
-        const float fg = __int_as_float(__builtin_amdgcn_readfirstlane((SJ).w));                                          \
-        const float4 pe = epar[(J) * 2 + eB];             /* this lane's ear: {g0, dg, ds, -} */                          \
-        const int la = (J) * 4 + eB * 2 + cB;             /* (source, ear, chunk) stream of this lane */                  \
-        const int wrel = cinfo[la];                                                                                       \
-        const float x0 = ckpt[la * 16 + (bB ^ (la & 15))];                                                                \
+        const int flags_j = (int)((cur_info >> 3) & 31u);                                                                 \
+        const int var_j = (VAR) >= 0 ? (VAR) : ODDIO_VARIANT(cur_info);                                                   \
         unsigned char* win_bytes = smem + (buf ? LDS_WIN1 : LDS_WIN0);                                                    \
         window_wait();                                    /* this source's window has landed */                          \
-        {   /* start the next staged source of this group; lands while we compute */                                     \
-            const unsigned below = lds_mask & ((1u << (J)) - 1u);                                                         \
-            pending = below ? 31 - __builtin_clz(below) : -1;                                                             \
-            if (pending >= 0) ODDIO_ISSUE_WINDOW(pending, buf ^ 1)                                                        \
+        const unsigned below = lds_mask & ((1u << cur) - 1u);                                                             \
+        const int nxt = below ? 31 - __builtin_clz(below) : -1;                                                           \
+        uint32_t nxt_info = 0;                                                                                            \
+        float nx0 = 0.0f;                                                                                                 \
+        float4 nt = make_float4(0.0f, 0.0f, 0.0f, 0.0f);                                                                  \
+        if (nxt >= 0) {   /* start the next staged source of this group; lands while we compute */                       \
+            nxt_info = (uint32_t)__builtin_amdgcn_readlane((int)vdesc.w, nxt);                                            \
+            ODDIO_ISSUE_WINDOW(nxt, buf ^ 1)                                                                              \
+            ODDIO_LANE_DATA(nxt, nx0, nt)                                                                                 \
         }                                                                                                                 \
-        const float* win = reinterpret_cast<const float*>(win_bytes);                                                     \
-        if (flags_j & SFLAG_PAD) {                                                                                        \
-            const float frac0 = ckpt[la * 16 + (la & 15)];   /* checkpoint 0: the chunk's start offset */                 \
+        const int wrel4 = __float_as_int(ct.x);                                                                           \
+        if (var_j == 1) {                                                                                                 \
+            const float fg = (flags_j & SFLAG_FG) ? st[g * MIX_GROUP + (uint32_t)cur].fixed_gain : 1.0f;   /* v * 1.0 == v */ \
+            const float frac0_ = reinterpret_cast<const float*>(blkB0 + cur * BLK_SRC)[0];   /* checkpoint 0 */           \
             const int fast_e = eB ? (flags_j & SFLAG_FAST_R) : (flags_j & SFLAG_FAST_L);                                  \
-            window_repack_padded(win_bytes, __builtin_amdgcn_readfirstlane((SJ).z), lane);                                \
-            mix_source_lds<FULL, true, false, true>(win, wrel, x0, bB, fast_e, frac0, acc, fi, frame0, n_frames, fg, pe.x, pe.y, pe.z); \
-        } else if (fg == 1.0f && !(flags_j & SFLAG_NEG)) {   /* wave-uniform */                                           \
-            mix_source_lds<FULL, false, true, false>(win, wrel, x0, bB, 0, 0.0f, acc, fi, frame0, n_frames, fg, pe.x, pe.y, pe.z); \
+            window_repack_padded(win_bytes, (int)((cur_info >> 8) & 255u), lane);                                         \
+            mix_source_lds<FULL, true, false, true>(win_bytes, wrel4, cx0, bB, fast_e, frac0_, acc, fi, frame0, n_frames, fg, ct.y, ct.z, ct.w); \
+        } else if (var_j == 0) {                                                                                          \
+            mix_source_lds<FULL, false, true, false>(win_bytes, wrel4, cx0, bB, 0, 0.0f, acc, fi, frame0, n_frames, 1.0f, ct.y, ct.z, ct.w); \
         } else {                                                                                                          \
-            mix_source_lds<FULL, true, false, false>(win, wrel, x0, bB, 0, 0.0f, acc, fi, frame0, n_frames, fg, pe.x, pe.y, pe.z); \
+            const float fg = (flags_j & SFLAG_FG) ? st[g * MIX_GROUP + (uint32_t)cur].fixed_gain : 1.0f;                  \
+            mix_source_lds<FULL, true, false, false>(win_bytes, wrel4, cx0, bB, 0, 0.0f, acc, fi, frame0, n_frames, fg, ct.y, ct.z, ct.w); \
         }                                                                                                                 \
         buf ^= 1;                                                                                                         \
+        cur = nxt; cur_info = nxt_info; cx0 = nx0; ct = nt;                                                               \
     }
         // STORE: the accumulators hold exactly one source's contribution (0 + p); write the row, start the next from zero
         // (a skipped source -- stopped, or no frames in this tile -- leaves a row of zeros: x + 0.0 == x for every x the
         // running sum can hold, which is never -0.0)
 #define ODDIO_EMIT(J)                                                                                                     \
     if (STORE) {                                                                                                          \
-        const uint32_t src_ = g * MIX_GROUP + (uint32_t)(J);                                                              \
-        if (src_ < n_sources) {                                                                                           \
-            float4* row_ = reinterpret_cast<float4*>(contrib + ((((size_t)g * 2 + (size_t)eB) * contrib_ncb + (frame0 >> 4)) * MIX_GROUP + (size_t)(J)) * 16); \
-            _Pragma("unroll") for (int q = 0; q < 4; ++q) row_[q] = make_float4(acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]); \
-        }                                                                                                                 \
+        if (g * MIX_GROUP + (uint32_t)(J) < n_sources)                                                                    \
+            store_rows(acc, reinterpret_cast<unsigned char*>(contrib) + (size_t)g * 2u * contrib_ncb * (MIX_GROUP * 64u), row_off0 + 64u * (uint32_t)(J), lane); \
         _Pragma("unroll") for (int k = 0; k < 16; ++k) acc[k] = 0.0f;                                                     \
     }
-        if (pending >= 0) ODDIO_ISSUE_WINDOW(pending, buf)
-        if (rare_mask == 0) {
+        if (rare_mask == 0 && !STORE) {
             // the common group: staged sources only (kept apart so that the out-of-line paths' register
             // shuffling stays out of this loop)
+            // one loop per variant, each with nothing but its own body (runs of sources of one variant, in walk order):
+            // with the three bodies as arms of one loop hipcc keeps two copies of the 16 accumulators and moves them
+            // around every source
+            while (cur >= 0) {
 #pragma unroll 1
-            for (int j = MIX_GROUP - 1; j >= 0; --j) {
-                const int4 sj = *reinterpret_cast<const int4*>(sinfo + j * 8);
-                if (__builtin_amdgcn_readfirstlane(sj.x) != PATH_LDS) { ODDIO_EMIT(j) continue; }
-                ODDIO_STAGED_SOURCE(j, sj)
-                ODDIO_EMIT(j)
+                while (cur >= 0 && ODDIO_VARIANT(cur_info) == 0) ODDIO_STAGED_SOURCE(0)
+#pragma unroll 1
+                while (cur >= 0 && ODDIO_VARIANT(cur_info) == 1) ODDIO_STAGED_SOURCE(1)
+#pragma unroll 1
+                while (cur >= 0 && ODDIO_VARIANT(cur_info) == 2) ODDIO_STAGED_SOURCE(2)
             }
         } else {
 #pragma unroll 1
             for (int j = MIX_GROUP - 1; j >= 0; --j) {
-                const int4 sj = *reinterpret_cast<const int4*>(sinfo + j * 8);
-                const int path_j = __builtin_amdgcn_readfirstlane(sj.x);
-                if (path_j == PATH_SKIP) { ODDIO_EMIT(j) continue; }
-                if (path_j == PATH_LDS) {
-                    ODDIO_STAGED_SOURCE(j, sj)
-                } else {
+                if (j == cur) {
+                    ODDIO_STAGED_SOURCE(-1)
+                } else if ((rare_mask >> j) & 1u) {
                     // rare path: park the accumulators in LDS (over the window buffers: a window in flight is
                     // awaited first and fetched again afterwards), run out of line, fetch them back
+                    const int path_j = __builtin_amdgcn_readlane((int)vdesc.w, j) & 7;
                     float* park = reinterpret_cast<float*>(smem);
                     window_wait();
                     wave_sync();
@@ -958,15 +1071,17 @@ __global__ __launch_bounds__(64 * MIX_WG_WAVES, MIX_WAVES_PER_SIMD) void spatial
 #pragma unroll
                     for (int k = 0; k < 16; ++k) acc[k] = park[k * 64 + lane];
                     wave_sync();
-                    if (pending >= 0) ODDIO_ISSUE_WINDOW(pending, buf)
+                    if (cur >= 0) ODDIO_ISSUE_WINDOW(cur, buf)
                 }
                 ODDIO_EMIT(j)
             }
         }
 #undef ODDIO_EMIT
 #undef ODDIO_STAGED_SOURCE
+#undef ODDIO_VARIANT
+#undef ODDIO_LANE_DATA
 #undef ODDIO_ISSUE_WINDOW
-        wave_sync();   // before the next group's phase A overwrites ckpt/cinfo
+        wave_sync();   // before the next group's phase A overwrites the stream blocks
     }
 
     if (STORE) return;
@@ -1052,23 +1167,37 @@ __device__ __forceinline__ void reduce_partials_body(const float* __restrict__ p
 }
 
 // ORDERED mode at scale, second half: out[f][e] = ((init + row[len-1]) + row[len-2]) + ... + row[0] -- the
-// reference's sequential f32 sum in its reverse set walk (spatial.rs:204,460), one lane per output.  The chain of
-// `len` dependent adds per output IS the cost (~1 ms at 262 144 sources), so everything else stays off it: one
-// wavefront per (ear, column block of 16 frames); a tile is 8 source groups = 8 chunks of 1 KiB (16 rows of 16
-// frames), streamed HBM -> LDS through a ring of ORD_RING tiles (buffer_load ... lds, several tiles ahead of the
-// adds, no registers).  Rows of sources >= len (stale chunks of an earlier, longer set) are never added.
+// reference's sequential f32 sum in its reverse set walk (spatial.rs:204,460).  The chain of `len` dependent adds per
+// output IS the cost (one wave issues a dependent VALU op every ~4.6 cycles: ~0.5 ms at 262 144 sources), so the
+// wave that walks it issues as little else as possible: one wavefront per (ear, column block of 16 frames); lane
+// 4k + m holds frame k; a tile is 8 source groups = 8 chunks of 1 KiB (16 rows of 16 frames), streamed HBM -> LDS
+// through a ring of ORD_RING tiles (buffer_load ... lds, several tiles ahead of the adds, no registers).  One
+// ds_read2st64_b32 fetches rows 4i + m and 4i + 4 + m for the quad's lane m, and the adds take their operand from
+// the quad's lanes in turn (v_add_f32_dpp quad_perm:[m,m,m,m]): 8 adds per LDS instruction, every lane of a quad
+// carrying the same running sum.  Rows of sources >= len (stale chunks of an earlier, longer set) are never added.
 // grid = (column blocks, 2 ears), block = 64.
 constexpr int ORD_GROUPS = 8;                 // source groups per tile
 constexpr int ORD_ROWS = ORD_GROUPS * MIX_GROUP;   // 128 sources: 8 KiB = 8 DMA instructions
-constexpr int ORD_RING = 6;                   // tiles in the LDS ring (48 KiB), ORD_RING - 1 in flight
+constexpr int ORD_RING = 8;                   // tiles in the LDS ring (64 KiB), ORD_RING - 1 in flight (56 of the 63 VMEM slots)
+constexpr int ORD_Q = 8;                      // quad steps (4 rows each) per register batch: 4 batches per tile
+
+template <int K> __device__ __forceinline__ void chain_add(float& s, float v) {
+    // s = v[lane K of the quad] + s: the DPP operand is src0, the running sum stays in place
+    if (K == 3) asm("v_add_f32_dpp %0, %1, %0 quad_perm:[3,3,3,3] row_mask:0xf bank_mask:0xf" : "+v"(s) : "v"(v));
+    else if (K == 2) asm("v_add_f32_dpp %0, %1, %0 quad_perm:[2,2,2,2] row_mask:0xf bank_mask:0xf" : "+v"(s) : "v"(v));
+    else if (K == 1) asm("v_add_f32_dpp %0, %1, %0 quad_perm:[1,1,1,1] row_mask:0xf bank_mask:0xf" : "+v"(s) : "v"(v));
+    else asm("v_add_f32_dpp %0, %1, %0 quad_perm:[0,0,0,0] row_mask:0xf bank_mask:0xf" : "+v"(s) : "v"(v));
+}
+
 __global__ __launch_bounds__(64) void ordered_sum(const float* __restrict__ contrib, uint32_t contrib_ncb,
                                                   const uint32_t* __restrict__ n_sources_ptr, uint32_t n_frames,
                                                   const float* __restrict__ init, float* __restrict__ out, int postfx) {
     __shared__ __attribute__((aligned(16))) float ring[ORD_RING][ORD_ROWS][16];
     const int lane = threadIdx.x;
+    const int fk = lane >> 2, m = lane & 3;
     const uint32_t cb = blockIdx.x, e = blockIdx.y;
     const uint32_t n = *n_sources_ptr;
-    const uint32_t f = cb * 16 + (uint32_t)(lane & 15);
+    const uint32_t f = cb * 16 + (uint32_t)fk;
     float s = (init != nullptr && f < n_frames) ? init[2 * f + e] : 0.0f;   // the buffered set's sum (walked first, spatial.rs:395-438)
     asm volatile("" :: "v"(s));                                  // the load above is awaited here, before the DMA counter is in use
     const uint32_t group_stride = 2u * contrib_ncb * 1024u;      // bytes from a group's chunk to the next group's
@@ -1107,42 +1236,72 @@ __global__ __launch_bounds__(64) void ordered_sum(const float* __restrict__ cont
                      : "=&s"(keep) : "v"(voff2), "s"(rsrc), "s"(dst2), "s"(so0), "s"(2u * so0), "s"(3u * so0) : "memory");
     };
     static_assert(ORD_ROWS * 64 == 8192, "a tile is 8 DMA instructions of 1 KiB");
-    // k counts tiles from the top: tile index t = n_tiles - 1 - k
-    for (uint32_t k = 0; k < (uint32_t)(ORD_RING - 1) && k < n_tiles; ++k) issue(n_tiles - 1u - k);
-    for (uint32_t k = 0; k < n_tiles; ++k) {
-        const uint32_t t = n_tiles - 1u - k;
-        // keep ORD_RING - 1 tiles in flight: the ring slot of tile t - (ORD_RING - 1) is the one tile t + 1 was just read from
-        if (k + ORD_RING - 1 < n_tiles) {
+    static_assert(8 * (ORD_RING - 1) <= 63, "the tiles in flight fit the 6-bit VMEM counter");
+    // kk counts tiles from the top: tile index t = n_tiles - 1 - kk
+    for (uint32_t kk = 0; kk < (uint32_t)(ORD_RING - 1) && kk < n_tiles; ++kk) issue(n_tiles - 1u - kk);
+    uint32_t kk = 0;
+    if (n_tiles > 0 && (n % ORD_ROWS) != 0u) {
+        // top tile of a set whose length is not a whole number of tiles: rows of sources >= n are not part of the sum
+        const uint32_t t = n_tiles - 1u;
+        if (ORD_RING - 1 < n_tiles) {
+            asm volatile("s_waitcnt vmcnt(%0)" :: "n"(8 * (ORD_RING - 2)) : "memory");
             issue(t - (uint32_t)(ORD_RING - 1));
-            asm volatile("s_waitcnt vmcnt(%0)" :: "n"(8 * (ORD_RING - 1)) : "memory");     // everything but the newest ORD_RING-1 tiles has landed
         } else {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         wave_sync();
-        const float* tp = &ring[t % ORD_RING][0][lane & 15];
-        if (k == 0 && (n % ORD_ROWS) != 0u) {
-            // top tile of a set whose length is not a whole number of tiles: rows of sources >= n are not part of the sum
-            for (int r = (int)(n - t * ORD_ROWS) - 1; r >= 0; --r) s = s + tp[r * 16];
-        } else {
-            // rows in descending order; the reads of the next 16 rows are in flight while the current 16 are added
-            float v[16], w[16];
-#pragma unroll
-            for (int q = 0; q < 16; ++q) v[q] = tp[(ORD_ROWS - 1 - q) * 16];
-#pragma unroll
-            for (int r = ORD_ROWS - 32; r >= -16; r -= 16) {
-                if (r >= 0) {
-#pragma unroll
-                    for (int q = 0; q < 16; ++q) w[q] = tp[(r + 15 - q) * 16];
-                }
-#pragma unroll
-                for (int q = 0; q < 16; ++q) s = s + v[q];          // `out[i][ear] += sample * gain` in walk order
-#pragma unroll
-                for (int q = 0; q < 16; ++q) v[q] = w[q];
-            }
-        }
-        wave_sync();                                                // the adds above are done with this slot before it is refilled
+        const float* tp = &ring[t % ORD_RING][0][fk];
+        for (int r = (int)(n - t * ORD_ROWS) - 1; r >= 0; --r) s = s + tp[r * 16];
+        wave_sync();
+        kk = 1;
     }
-    if (lane < 16 && f < n_frames) out[2 * f + e] = postfx_apply(s, postfx);
+    // whole tiles, software pipelined over batches of ORD_Q quad steps: the LDS reads of batch b + 1 (of the next
+    // tile across a tile boundary, once that tile has landed) are in flight while batch b is added
+    float v[2][ORD_Q];
+    const uint32_t lane_off = (uint32_t)m * 16u + (uint32_t)fk;          // floats: row m, frame fk
+#define ODDIO_ORD_WAIT(KK)                                                                                                \
+    {   /* tile KK has landed; then keep ORD_RING - 1 tiles in flight (the slot refilled is the one tile KK - 1 was read from) */ \
+        if ((KK) + ORD_RING - 1 < n_tiles) {                                                                              \
+            asm volatile("s_waitcnt vmcnt(%0)" :: "n"(8 * (ORD_RING - 2)) : "memory");                                    \
+            issue(n_tiles - 1u - (KK) - (uint32_t)(ORD_RING - 1));                                                        \
+        } else {                                                                                                          \
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                              \
+        }                                                                                                                 \
+        wave_sync();                                                                                                      \
+    }
+    // batch B of a tile = quad steps i = 31 - 8B .. 24 - 8B (rows 4i + m), read in descending order
+#define ODDIO_ORD_LOAD(SET, TP, B)                                                                                        \
+    _Pragma("unroll") for (int q = 0; q < ORD_Q; ++q) v[SET][q] = (TP)[(31 - ORD_Q * (B) - q) * 64];
+#define ODDIO_ORD_ADD(SET)                                                                                                \
+    _Pragma("unroll") for (int q = 0; q < ORD_Q; ++q) {                                                                   \
+        chain_add<3>(s, v[SET][q]); chain_add<2>(s, v[SET][q]); chain_add<1>(s, v[SET][q]); chain_add<0>(s, v[SET][q]);   \
+    }
+    if (kk < n_tiles) {
+        ODDIO_ORD_WAIT(kk)
+        const float* tp = &ring[(n_tiles - 1u - kk) % ORD_RING][0][0] + lane_off;
+        ODDIO_ORD_LOAD(0, tp, 0)
+        for (; kk < n_tiles; ++kk) {
+            ODDIO_ORD_LOAD(1, tp, 1)
+            ODDIO_ORD_ADD(0)
+            ODDIO_ORD_LOAD(0, tp, 2)
+            ODDIO_ORD_ADD(1)
+            ODDIO_ORD_LOAD(1, tp, 3)
+            ODDIO_ORD_ADD(0)
+            // every read of this tile has been issued; they complete (in order) before the next tile's first read
+            // does, and its slot is refilled only by the `issue` at the top of the next-but-one wait
+            if (kk + 1 < n_tiles) {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // this tile's rows are in registers before its slot may be refilled
+                ODDIO_ORD_WAIT(kk + 1)
+                tp = &ring[(n_tiles - 2u - kk) % ORD_RING][0][0] + lane_off;
+                ODDIO_ORD_LOAD(0, tp, 0)
+            }
+            ODDIO_ORD_ADD(1)
+        }
+    }
+#undef ODDIO_ORD_ADD
+#undef ODDIO_ORD_LOAD
+#undef ODDIO_ORD_WAIT
+    if (m == 0 && f < n_frames) out[2 * f + e] = postfx_apply(s, postfx);
 }
 
 __global__ void postfx_kernel(float* __restrict__ buf, uint32_t n, int postfx) {
