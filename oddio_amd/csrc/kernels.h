@@ -258,6 +258,12 @@ __device__ __forceinline__ double f64_rem_euclid(double a, double b) {   // core
 #ifndef ODDIO_MIX_DEPTH
 #define ODDIO_MIX_DEPTH 1
 #endif
+#ifndef ODDIO_MIX_PREFETCH
+#define ODDIO_MIX_PREFETCH 1
+#endif
+#ifndef ODDIO_STORE_VARIANT
+#define ODDIO_STORE_VARIANT 0
+#endif
 
 constexpr int MIX_WG_WAVES = ODDIO_MIX_WG_WAVES;       // waves per workgroup
 constexpr int MIX_WAVES_PER_SIMD = ODDIO_MIX_WAVES;    // register budget: 512 / this
@@ -678,6 +684,9 @@ __device__ __forceinline__ void window_wait() { asm volatile("s_waitcnt vmcnt(0)
 // following sample so that a pair (w, w+1) is always two adjacent dwords).  One wave: the DS
 // operations execute in issue order, so every read below precedes every write.
 __device__ __forceinline__ void window_repack_padded(unsigned char* win_bytes, int nvec, int lane) {
+    // (the lane index is made opaque here: hipcc otherwise hoists this function's address arithmetic out of every
+    // loop of the kernel and parks it in ~10 VGPRs that the common path then lacks)
+    asm volatile("" : "+v"(lane));
     u32x4 v[WIN_PIECES];
 #pragma unroll
     for (int k = 0; k < WIN_PIECES; ++k)
@@ -857,10 +866,10 @@ template <int K> __device__ __forceinline__ float quad_bcast(float v) {
 // STORE (ORDERED mode at scale): one source's 16 accumulators of every lane -> its rows in `contrib`.
 // A lane's 16 values are one 64-byte row; written as they are, every store instruction would touch 64 separate
 // lines with 16 bytes each.  The four lanes of a quad (four adjacent column blocks) instead exchange 16-byte pieces
-// (DPP, registers only), so that store k writes the whole row of the quad's lane k: 64 contiguous bytes per quad.
-__device__ __forceinline__ void store_rows(const float (&acc)[16], unsigned char* group_base, uint32_t voff, int lane) {
+// (DPP, registers only), so that store k writes the whole row of the quad's lane k: 64 contiguous bytes per quad, and
+// the quad's four rows of one source sit next to each other (256 bytes = two full lines from four consecutive stores).
+__device__ __forceinline__ void rows_transpose(const float (&acc)[16], float4 (&o)[4], int lane) {
     const int i = lane & 3;
-    float4 o[4];
 #define ODDIO_PICK(K, M) \
     { const float c0 = quad_bcast<K>(acc[M]), c1 = quad_bcast<K>(acc[4 + M]), c2 = quad_bcast<K>(acc[8 + M]), c3 = quad_bcast<K>(acc[12 + M]); \
       const float v = i == 0 ? c0 : (i == 1 ? c1 : (i == 2 ? c2 : c3)); \
@@ -869,9 +878,18 @@ __device__ __forceinline__ void store_rows(const float (&acc)[16], unsigned char
     ODDIO_PICK4(0) ODDIO_PICK4(1) ODDIO_PICK4(2) ODDIO_PICK4(3)
 #undef ODDIO_PICK4
 #undef ODDIO_PICK
-    unsigned char* p = group_base + voff;
+}
+__device__ __forceinline__ void rows_store(const float4 (&o)[4], unsigned char* p) {
+#if ODDIO_STORE_VARIANT == 2      // experiment: no row stores at all (the kernel's compute floor; wrong results)
+    asm volatile("" :: "v"(o[0].x), "v"(o[1].y), "v"(o[2].z), "v"(o[3].w), "v"(p));
+#elif ODDIO_STORE_VARIANT == 1    // streaming (non-temporal) stores
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
 #pragma unroll
-    for (int k = 0; k < 4; ++k) *reinterpret_cast<float4*>(p + k * 1024) = o[k];
+    for (int k = 0; k < 4; ++k) { f32x4 t = {o[k].x, o[k].y, o[k].z, o[k].w}; __builtin_nontemporal_store(t, reinterpret_cast<f32x4*>(p + k * 64)); }
+#else
+#pragma unroll
+    for (int k = 0; k < 4; ++k) *reinterpret_cast<float4*>(p + k * 64) = o[k];
+#endif
 }
 
 // grid = (n_workgroups, tiles of this pass); block = 64 * MIX_WG_WAVES.  Wave w walks groups [g_lo, g_hi) of
@@ -880,10 +898,10 @@ __device__ __forceinline__ void store_rows(const float (&acc)[16], unsigned char
 // `recs`: the tile records of this pass, [blockIdx.y][rec_stride], made by the walk kernel (make_tile_rec);
 // `tile0`: the callback tile that blockIdx.y == 0 renders.
 // STORE (ORDERED mode at scale): instead of accumulating, every source's contribution `s * gain` (spatial.rs:459-460)
-// is written out -- layout contrib[group of 16 sources][ear][column block of 16 frames][source in group][16], i.e. a
-// lane's 16 accumulators are one 64-byte row, a group fills one 1-KiB chunk per (ear, column block) and everything a
-// wave writes while it walks a group lies within 2 * ncb KiB -- and ordered_sum then adds the rows in the reference's
-// order.  `partials` / `init` are unused there.  contrib_ncb = column blocks per ear.
+// is written out -- layout contrib[group of 16 sources][ear][quad of column blocks][source in group][column block of
+// the quad][16 frames], i.e. a lane's 16 accumulators are one 64-byte row, the four rows a quad of lanes holds for one
+// source are 256 contiguous bytes (two whole 128-byte lines per source, written back to back) and everything a wave
+// writes while it walks a group lies within 2 * ncb KiB -- and ordered_sum then adds the rows in the reference's order.  `partials` / `init` are unused there.  contrib_ncb = column blocks per ear.
 template <bool FULL, bool STORE = false>
 __global__ __launch_bounds__(64 * MIX_WG_WAVES, MIX_WAVES_PER_SIMD) void spatial_mix(SceneParams P, const SrcStatic* __restrict__ st,
                                                                                      const EarParams* __restrict__ ear,
@@ -923,50 +941,70 @@ __global__ __launch_bounds__(64 * MIX_WG_WAVES, MIX_WAVES_PER_SIMD) void spatial
     uint32_t g_hi = g_lo + groups_per_wave;
     if (g_hi > n_groups) g_hi = n_groups;
 
-    // phase-A role: source j of the group, ear e, chunk c
-    const int jA = lane >> 2, eA = (lane >> 1) & 1, cA = lane & 1;
     // this lane's stream block in phase B belongs to stream 4j + 2e + c: byte offset of source 0's, then 4 blocks per source
     unsigned char* const blkB0 = smem + LDS_STREAM + (eB * 2 + cB) * (STREAM_WORDS * 4);
     constexpr int BLK_SRC = 4 * STREAM_WORDS * 4;            // bytes of stream blocks per source
     // STORE: this lane's byte offset inside a group's rows for source 0 (store_rows)
-    const uint32_t row_off0 = (((uint32_t)eB * contrib_ncb + ((frame0 >> 4) & ~3u)) * MIX_GROUP) * 64u + 16u * (uint32_t)(lane & 3);
+    const uint32_t row_off0 = (((uint32_t)eB * contrib_ncb + ((frame0 >> 4) & ~3u)) * MIX_GROUP) * 64u + 16u * (uint32_t)(lane & 3);   // == ((e * ncb/4 + quad) * 16) * 256 + 16 * i
 
+    // The records of a group -- lanes 0-15: {descriptor words, info} of source `lane`; lane (j, e, c): the stream's
+    // {ds, g0, dg, wrel} and frac0 -- are fetched one group ahead (ODDIO_MIX_PREFETCH): the loads are issued during the
+    // first source of the group before and have landed long before the group boundary, and that group's last source
+    // starts the first window of this one, so a boundary costs the cursor scan and nothing else.
+#define ODDIO_LOAD_GROUP(GG, V, Q, F)                                                                                     \
+    {                                                                                                                     \
+        /* phase-A role: source j of the group, ear e, chunk c (from an opaque copy of the lane index, so that this */   \
+        /* once-per-group address arithmetic is redone here instead of living in VGPRs through phase B) */               \
+        int la_ = lane;                                                                                                   \
+        asm volatile("" : "+v"(la_));                                                                                     \
+        const TileRec* __restrict__ grec_ = trecs + (size_t)(GG) * MIX_GROUP;                                             \
+        V = make_uint4(0u, 0u, 0u, 0u); Q = make_float4(0.0f, 0.0f, 0.0f, 0.0f); F = 0.0f;                                \
+        if (la_ < MIX_GROUP && (GG) * MIX_GROUP + (uint32_t)la_ < n_sources) V = *reinterpret_cast<const uint4*>(grec_ + la_); \
+        if ((GG) * MIX_GROUP + (uint32_t)(la_ >> 2) < n_sources) {                                                        \
+            const TileRec* r_ = grec_ + (la_ >> 2);                                                                       \
+            Q = *reinterpret_cast<const float4*>(&r_->ear[(la_ >> 1) & 1]);     /* {ds, g0, dg, wrel} */                  \
+            F = r_->frac0[(la_ >> 1) & 1][la_ & 1];                                                                       \
+        }                                                                                                                 \
+    }
+    uint4 pv = make_uint4(0u, 0u, 0u, 0u);
+    float4 pq = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    float pf = 0.0f;
+    if (ODDIO_MIX_PREFETCH && g_hi > g_lo) ODDIO_LOAD_GROUP(g_hi - 1u, pv, pq, pf)
+    int buf = 0;
+    bool pre_issued = false;     // the last source of the previous group already started this group's first window
     for (uint32_t g = g_hi; g-- > g_lo;) {
-        const TileRec* __restrict__ grec = trecs + (size_t)g * MIX_GROUP;
         // ------------------------------ phase A ------------------------------
         // lanes 0-15 keep {descriptor words, info} of source `lane` for the whole group (read per source with
         // v_readlane: wave-uniform values without a trip through memory)
-        uint4 vdesc = make_uint4(0u, 0u, 0u, 0u);
-        float4 q = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-        float frac0 = 0.0f;
-        {
-            const uint32_t srcA = g * MIX_GROUP + (uint32_t)jA;
-            if (lane < MIX_GROUP && g * MIX_GROUP + (uint32_t)lane < n_sources) vdesc = *reinterpret_cast<const uint4*>(grec + lane);
-            if (srcA < n_sources) {
-                const TileRec* r = grec + jA;
-                q = *reinterpret_cast<const float4*>(&r->ear[eA]);     // {ds, g0, dg, wrel}
-                frac0 = r->frac0[eA][cA];
-            }
-        }
+        uint4 vdesc;
+        float4 q;
+        float frac0;
+        if (ODDIO_MIX_PREFETCH) { vdesc = pv; q = pq; frac0 = pf; }
+        else ODDIO_LOAD_GROUP(g, vdesc, q, frac0)
+        bool need_prefetch = ODDIO_MIX_PREFETCH && g > g_lo;
+        int laneA = lane;
+        asm volatile("" : "+v"(laneA));
+        const int cA = laneA & 1;
         // bit j of lds_mask: source j of the group takes the staged-window path; rare_mask: an out-of-line path
         const int pj = (int)(vdesc.w & 7u);
         const unsigned lds_mask = (unsigned)__ballot(pj == PATH_LDS);
         const unsigned rare_mask = (unsigned)__ballot(pj != PATH_LDS && pj != PATH_SKIP);
-        int buf = 0;
         // `cur`: the next staged source of the walk; its window is in flight to / sits in WIN[buf]
         int cur = lds_mask ? 31 - __builtin_clz(lds_mask) : -1;
         uint32_t cur_info = 0;
-#define ODDIO_ISSUE_WINDOW(JN, BUF)                                                                                       \
-    window_dma(lds_slice + (uint32_t)((BUF) ? LDS_WIN1 : LDS_WIN0), (uint32_t)__builtin_amdgcn_readlane((int)vdesc.x, (JN)),  \
-               (uint32_t)__builtin_amdgcn_readlane((int)vdesc.y, (JN)), (uint32_t)__builtin_amdgcn_readlane((int)vdesc.z, (JN)), \
-               (uint32_t)__builtin_amdgcn_readlane((int)vdesc.w, (JN)), lane16);
+#define ODDIO_ISSUE_WINDOW_OF(VD, JN, BUF)                                                                                \
+    window_dma(lds_slice + (uint32_t)((BUF) ? LDS_WIN1 : LDS_WIN0), (uint32_t)__builtin_amdgcn_readlane((int)(VD).x, (JN)),  \
+               (uint32_t)__builtin_amdgcn_readlane((int)(VD).y, (JN)), (uint32_t)__builtin_amdgcn_readlane((int)(VD).z, (JN)), \
+               (uint32_t)__builtin_amdgcn_readlane((int)(VD).w, (JN)), lane16);
+#define ODDIO_ISSUE_WINDOW(JN, BUF) ODDIO_ISSUE_WINDOW_OF(vdesc, JN, BUF)
         if (cur >= 0) {   // the first window is on its way while the cursors are scanned
             cur_info = (uint32_t)__builtin_amdgcn_readlane((int)vdesc.w, cur);
-            ODDIO_ISSUE_WINDOW(cur, buf)
+            if (!pre_issued) ODDIO_ISSUE_WINDOW(cur, buf)
         }
+        pre_issued = false;
         {
             // exact f32 cursor scan (frames.rs:189-196) of stream (j, e, c): checkpoints every 16 frames
-            float* blk = reinterpret_cast<float*>(smem + LDS_STREAM + lane * (STREAM_WORDS * 4));
+            float* blk = reinterpret_cast<float*>(smem + LDS_STREAM + laneA * (STREAM_WORDS * 4));
             const float ds = q.x;
             float x = frac0;
 #pragma unroll 1
@@ -996,12 +1034,17 @@ __global__ __launch_bounds__(64 * MIX_WG_WAVES, MIX_WAVES_PER_SIMD) void spatial
         // VAR: 0 the common source (no FixedGain, non-negative cursor), 1 padded layout (resample ratio within PAD_EPS
         // of 1), 2 FixedGain and/or a cursor that starts negative; -1: decided here (wave-uniform branches)
 #define ODDIO_VARIANT(INFO) ((((INFO) >> 3) & SFLAG_PAD) ? 1 : ((((INFO) >> 3) & (SFLAG_FG | SFLAG_NEG)) ? 2 : 0))
-#define ODDIO_STAGED_SOURCE(VAR)                                                                                          \
+#define ODDIO_STAGED_SOURCE(VAR, PRE)                                                                                        \
     {                                                                                                                     \
         const int flags_j = (int)((cur_info >> 3) & 31u);                                                                 \
         const int var_j = (VAR) >= 0 ? (VAR) : ODDIO_VARIANT(cur_info);                                                   \
         unsigned char* win_bytes = smem + (buf ? LDS_WIN1 : LDS_WIN0);                                                    \
         window_wait();                                    /* this source's window has landed */                          \
+        /* (so have the next group's records if an earlier source of this group fetched them: the empty asm makes */     \
+        /* hipcc put its own wait for those loads here, where it is free, instead of in front of the next window) */     \
+        asm volatile("" : "+v"(pv.x), "+v"(pv.y), "+v"(pv.z), "+v"(pv.w), "+v"(pq.x), "+v"(pq.y), "+v"(pq.z), "+v"(pq.w), "+v"(pf)); \
+        const bool fetched_before = !need_prefetch;                                                                       \
+        if (need_prefetch) { ODDIO_LOAD_GROUP(g - 1u, pv, pq, pf) need_prefetch = false; }                                \
         const unsigned below = lds_mask & ((1u << cur) - 1u);                                                             \
         const int nxt = below ? 31 - __builtin_clz(below) : -1;                                                           \
         uint32_t nxt_info = 0;                                                                                            \
@@ -1011,6 +1054,10 @@ __global__ __launch_bounds__(64 * MIX_WG_WAVES, MIX_WAVES_PER_SIMD) void spatial
             nxt_info = (uint32_t)__builtin_amdgcn_readlane((int)vdesc.w, nxt);                                            \
             ODDIO_ISSUE_WINDOW(nxt, buf ^ 1)                                                                              \
             ODDIO_LANE_DATA(nxt, nx0, nt)                                                                                 \
+        } else if ((PRE) && ODDIO_MIX_PREFETCH && g > g_lo && fetched_before) {                                           \
+            /* last staged source of the group: the other window buffer is free for the next group's first window */     \
+            const unsigned nm_ = (unsigned)__ballot((int)(pv.w & 7u) == PATH_LDS);                                        \
+            if (nm_) { ODDIO_ISSUE_WINDOW_OF(pv, 31 - __builtin_clz(nm_), buf ^ 1) pre_issued = true; }                   \
         }                                                                                                                 \
         const int wrel4 = __float_as_int(ct.x);                                                                           \
         if (var_j == 1) {                                                                                                 \
@@ -1028,66 +1075,84 @@ __global__ __launch_bounds__(64 * MIX_WG_WAVES, MIX_WAVES_PER_SIMD) void spatial
         buf ^= 1;                                                                                                         \
         cur = nxt; cur_info = nxt_info; cx0 = nx0; ct = nt;                                                               \
     }
-        // STORE: the accumulators hold exactly one source's contribution (0 + p); write the row, start the next from zero
+        // STORE: the accumulators hold exactly one source's contribution (0 + p); write the rows, start the next from zero
         // (a skipped source -- stopped, or no frames in this tile -- leaves a row of zeros: x + 0.0 == x for every x the
-        // running sum can hold, which is never -0.0)
+        // running sum can hold, which is never -0.0).  (Issuing the stores one source late, after the next window wait,
+        // so that nothing waits for them, changes nothing: the kernel moves 3.3 GB in 0.65 ms, it is HBM bound.)
 #define ODDIO_EMIT(J)                                                                                                     \
     if (STORE) {                                                                                                          \
-        if (g * MIX_GROUP + (uint32_t)(J) < n_sources)                                                                    \
-            store_rows(acc, reinterpret_cast<unsigned char*>(contrib) + (size_t)g * 2u * contrib_ncb * (MIX_GROUP * 64u), row_off0 + 64u * (uint32_t)(J), lane); \
+        if (g * MIX_GROUP + (uint32_t)(J) < n_sources) {                                                                  \
+            float4 o_[4];                                                                                                 \
+            rows_transpose(acc, o_, lane);                                                                                \
+            rows_store(o_, reinterpret_cast<unsigned char*>(contrib) + (size_t)g * 2u * contrib_ncb * (MIX_GROUP * 64u) + (row_off0 + 256u * (uint32_t)(J))); \
+        }                                                                                                                 \
         _Pragma("unroll") for (int k = 0; k < 16; ++k) acc[k] = 0.0f;                                                     \
     }
-        if (rare_mask == 0 && !STORE) {
-            // the common group: staged sources only (kept apart so that the out-of-line paths' register
-            // shuffling stays out of this loop)
-            // one loop per variant, each with nothing but its own body (runs of sources of one variant, in walk order):
-            // with the three bodies as arms of one loop hipcc keeps two copies of the 16 accumulators and moves them
-            // around every source
-            while (cur >= 0) {
+        // rare path: park the accumulators in LDS (over the window buffers: a window in flight is
+        // awaited first and fetched again afterwards), run out of line, fetch them back
+#define ODDIO_RARE_SOURCE(J)                                                                                              \
+    {                                                                                                                     \
+        const int path_j = __builtin_amdgcn_readlane((int)vdesc.w, (J)) & 7;                                              \
+        float* park = reinterpret_cast<float*>(smem);                                                                     \
+        window_wait();                                                                                                    \
+        wave_sync();                                                                                                      \
+        _Pragma("unroll") for (int k = 0; k < 16; ++k) park[k * 64 + lane] = acc[k];                                      \
+        wave_sync();                                                                                                      \
+        mix_source_rare(park, lane, frame0, n_frames, cB_abs, path_j, st, ear, g * MIX_GROUP + (uint32_t)(J), P.cycle_rows, P.cycle_plane); \
+        wave_sync();                                                                                                      \
+        _Pragma("unroll") for (int k = 0; k < 16; ++k) acc[k] = park[k * 64 + lane];                                      \
+        wave_sync();                                                                                                      \
+        if (cur >= 0) ODDIO_ISSUE_WINDOW(cur, buf)                                                                        \
+    }
+        if (!STORE) {
+            // The walk of a group, in descending slot order: runs of staged sources -- one loop per variant, each with
+            // nothing but its own body (with the three bodies as arms of one loop hipcc keeps two copies of the 16
+            // accumulators and moves them around every source) -- interrupted by the rare out-of-line sources.
+            unsigned rm = rare_mask;
+            while (cur >= 0 || rm) {
+                const int rj = rm ? 31 - __builtin_clz(rm) : -1;
+                if (rj > cur) {
+                    rm &= ~(1u << rj);
+                    ODDIO_RARE_SOURCE(rj)
+                    continue;
+                }
 #pragma unroll 1
-                while (cur >= 0 && ODDIO_VARIANT(cur_info) == 0) ODDIO_STAGED_SOURCE(0)
+                while (cur > rj && ODDIO_VARIANT(cur_info) == 0) ODDIO_STAGED_SOURCE(0, rm == 0)
 #pragma unroll 1
-                while (cur >= 0 && ODDIO_VARIANT(cur_info) == 1) ODDIO_STAGED_SOURCE(1)
+                while (cur > rj && ODDIO_VARIANT(cur_info) == 1) ODDIO_STAGED_SOURCE(1, rm == 0)
 #pragma unroll 1
-                while (cur >= 0 && ODDIO_VARIANT(cur_info) == 2) ODDIO_STAGED_SOURCE(2)
+                while (cur > rj && ODDIO_VARIANT(cur_info) == 2) ODDIO_STAGED_SOURCE(2, rm == 0)
             }
         } else {
 #pragma unroll 1
             for (int j = MIX_GROUP - 1; j >= 0; --j) {
                 if (j == cur) {
-                    ODDIO_STAGED_SOURCE(-1)
+                    ODDIO_STAGED_SOURCE(-1, false)
                 } else if ((rare_mask >> j) & 1u) {
-                    // rare path: park the accumulators in LDS (over the window buffers: a window in flight is
-                    // awaited first and fetched again afterwards), run out of line, fetch them back
-                    const int path_j = __builtin_amdgcn_readlane((int)vdesc.w, j) & 7;
-                    float* park = reinterpret_cast<float*>(smem);
-                    window_wait();
-                    wave_sync();
-#pragma unroll
-                    for (int k = 0; k < 16; ++k) park[k * 64 + lane] = acc[k];
-                    wave_sync();
-                    mix_source_rare(park, lane, frame0, n_frames, cB_abs, path_j, st, ear, g * MIX_GROUP + (uint32_t)j, P.cycle_rows, P.cycle_plane);
-                    wave_sync();
-#pragma unroll
-                    for (int k = 0; k < 16; ++k) acc[k] = park[k * 64 + lane];
-                    wave_sync();
-                    if (cur >= 0) ODDIO_ISSUE_WINDOW(cur, buf)
+                    ODDIO_RARE_SOURCE(j)
                 }
                 ODDIO_EMIT(j)
             }
         }
+#undef ODDIO_RARE_SOURCE
 #undef ODDIO_EMIT
 #undef ODDIO_STAGED_SOURCE
 #undef ODDIO_VARIANT
 #undef ODDIO_LANE_DATA
 #undef ODDIO_ISSUE_WINDOW
+#undef ODDIO_ISSUE_WINDOW_OF
+        if (need_prefetch) ODDIO_LOAD_GROUP(g - 1u, pv, pq, pf)   // a group without a staged source
         wave_sync();   // before the next group's phase A overwrites the stream blocks
     }
+#undef ODDIO_LOAD_GROUP
 
     if (STORE) return;
     // ---- cross-wave reduction through LDS, fixed order (wave 0 + wave 1 + ...), then one store ----
     // partial tile is planar: [ear][512 frames]; this lane owns frames 16*(lane&31).. of ear lane>>5
-    float* dst = partials + ((size_t)tile * gridDim.x + blockIdx.x) * PART_STRIDE + (size_t)eB * TILE_FRAMES + 16 * (lane & 31);
+    // (addresses derived from an opaque copy of the lane index: computed here, not carried through the walk in VGPRs)
+    int le = threadIdx.x & 63;
+    asm volatile("" : "+v"(le));
+    float* dst = partials + ((size_t)tile * gridDim.x + blockIdx.x) * PART_STRIDE + (size_t)(le >> 5) * TILE_FRAMES + 16 * (le & 31);
     if (MIX_WG_WAVES == 1) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) reinterpret_cast<float4*>(dst)[q] = make_float4(acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]);
@@ -1097,7 +1162,7 @@ __global__ __launch_bounds__(64 * MIX_WG_WAVES, MIX_WAVES_PER_SIMD) void spatial
     if (wv != 0) {
         float* mine = reinterpret_cast<float*>(smem);
 #pragma unroll
-        for (int k = 0; k < 16; ++k) mine[k * 64 + lane] = acc[k];
+        for (int k = 0; k < 16; ++k) mine[k * 64 + le] = acc[k];
     }
     __syncthreads();
     if (wv == 0) {
@@ -1105,7 +1170,7 @@ __global__ __launch_bounds__(64 * MIX_WG_WAVES, MIX_WAVES_PER_SIMD) void spatial
         for (int w = 1; w < MIX_WG_WAVES; ++w) {
             const float* other = reinterpret_cast<const float*>(smem_all + LDS_TOTAL * w);
 #pragma unroll
-            for (int k = 0; k < 16; ++k) acc[k] = acc[k] + other[k * 64 + lane];
+            for (int k = 0; k < 16; ++k) acc[k] = acc[k] + other[k * 64 + le];
         }
 #pragma unroll
         for (int q = 0; q < 4; ++q) reinterpret_cast<float4*>(dst)[q] = make_float4(acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]);
@@ -1171,114 +1236,163 @@ __device__ __forceinline__ void reduce_partials_body(const float* __restrict__ p
 // output IS the cost (one wave issues a dependent VALU op every ~4.6 cycles: ~0.5 ms at 262 144 sources), so the
 // wave that walks it issues as little else as possible: one wavefront per (ear, column block of 16 frames); lane
 // 4k + m holds frame k; a tile is 8 source groups = 8 chunks of 1 KiB (16 rows of 16 frames), streamed HBM -> LDS
-// through a ring of ORD_RING tiles (buffer_load ... lds, several tiles ahead of the adds, no registers).  One
+// through a ring of ORD_RING tiles (buffer_load ... lds, several tiles ahead of the adds, no registers) by a second
+// wave of the workgroup.  One
 // ds_read2st64_b32 fetches rows 4i + m and 4i + 4 + m for the quad's lane m, and the adds take their operand from
 // the quad's lanes in turn (v_add_f32_dpp quad_perm:[m,m,m,m]): 8 adds per LDS instruction, every lane of a quad
 // carrying the same running sum.  Rows of sources >= len (stale chunks of an earlier, longer set) are never added.
-// grid = (column blocks, 2 ears), block = 64.
+// grid = (column blocks, 2 ears), block = 128.
 constexpr int ORD_GROUPS = 8;                 // source groups per tile
 constexpr int ORD_ROWS = ORD_GROUPS * MIX_GROUP;   // 128 sources: 8 KiB = 8 DMA instructions
-constexpr int ORD_RING = 8;                   // tiles in the LDS ring (64 KiB), ORD_RING - 1 in flight (56 of the 63 VMEM slots)
-constexpr int ORD_Q = 8;                      // quad steps (4 rows each) per register batch: 4 batches per tile
+#ifndef ODDIO_ORD_LOADERS
+#define ODDIO_ORD_LOADERS 1
+#endif
+constexpr int ORD_LOADERS = ODDIO_ORD_LOADERS;     // loader waves per workgroup (tile kk is fetched by loader kk % ORD_LOADERS)
+constexpr int ORD_RING = 8 * ORD_LOADERS;     // tiles in the LDS ring (64 KiB per loader); each loader keeps up to 7 in flight (56 of its 63 VMEM slots)
+constexpr int ORD_Q = 8;                      // quad steps (4 rows each) per register batch: 4 batches per tile (chain_add8)
 
-template <int K> __device__ __forceinline__ void chain_add(float& s, float v) {
-    // s = v[lane K of the quad] + s: the DPP operand is src0, the running sum stays in place
-    if (K == 3) asm("v_add_f32_dpp %0, %1, %0 quad_perm:[3,3,3,3] row_mask:0xf bank_mask:0xf" : "+v"(s) : "v"(v));
-    else if (K == 2) asm("v_add_f32_dpp %0, %1, %0 quad_perm:[2,2,2,2] row_mask:0xf bank_mask:0xf" : "+v"(s) : "v"(v));
-    else if (K == 1) asm("v_add_f32_dpp %0, %1, %0 quad_perm:[1,1,1,1] row_mask:0xf bank_mask:0xf" : "+v"(s) : "v"(v));
-    else asm("v_add_f32_dpp %0, %1, %0 quad_perm:[0,0,0,0] row_mask:0xf bank_mask:0xf" : "+v"(s) : "v"(v));
+// s = (((s + v[lane 3 of the quad]) + v[lane 2]) + v[lane 1]) + v[lane 0] for eight registers in a row: the DPP operand
+// is src0, the running sum stays in place.  One asm statement for the whole batch: hipcc pads every inline-asm
+// statement with an s_nop (it cannot see that these adds need none: a DPP source written by an LDS read, the
+// VALU-written sum read as a plain operand), which would double the instructions on the chain.
+#define ODDIO_DPP4(V) \
+    "v_add_f32_dpp %0, " V ", %0 quad_perm:[3,3,3,3] row_mask:0xf bank_mask:0xf\n\t" \
+    "v_add_f32_dpp %0, " V ", %0 quad_perm:[2,2,2,2] row_mask:0xf bank_mask:0xf\n\t" \
+    "v_add_f32_dpp %0, " V ", %0 quad_perm:[1,1,1,1] row_mask:0xf bank_mask:0xf\n\t" \
+    "v_add_f32_dpp %0, " V ", %0 quad_perm:[0,0,0,0] row_mask:0xf bank_mask:0xf\n\t"
+#ifndef ODDIO_ORD_VARIANT
+#define ODDIO_ORD_VARIANT 0
+#endif
+__device__ __forceinline__ void chain_add8(float& s, const float (&v)[8]) {
+#if ODDIO_ORD_VARIANT == 2
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        asm("v_add_f32_dpp %0, %1, %0 quad_perm:[3,3,3,3] row_mask:0xf bank_mask:0xf" : "+v"(s) : "v"(v[q]));
+        asm("v_add_f32_dpp %0, %1, %0 quad_perm:[2,2,2,2] row_mask:0xf bank_mask:0xf" : "+v"(s) : "v"(v[q]));
+        asm("v_add_f32_dpp %0, %1, %0 quad_perm:[1,1,1,1] row_mask:0xf bank_mask:0xf" : "+v"(s) : "v"(v[q]));
+        asm("v_add_f32_dpp %0, %1, %0 quad_perm:[0,0,0,0] row_mask:0xf bank_mask:0xf" : "+v"(s) : "v"(v[q]));
+    }
+#elif ODDIO_ORD_VARIANT == 1
+    asm volatile(ODDIO_DPP4("%1") ODDIO_DPP4("%2") ODDIO_DPP4("%3") ODDIO_DPP4("%4") ODDIO_DPP4("%5") ODDIO_DPP4("%6") ODDIO_DPP4("%7") ODDIO_DPP4("%8")
+        : "+v"(s) : "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "v"(v[4]), "v"(v[5]), "v"(v[6]), "v"(v[7]));
+#else
+    asm(ODDIO_DPP4("%1") ODDIO_DPP4("%2") ODDIO_DPP4("%3") ODDIO_DPP4("%4") ODDIO_DPP4("%5") ODDIO_DPP4("%6") ODDIO_DPP4("%7") ODDIO_DPP4("%8")
+        : "+v"(s) : "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "v"(v[4]), "v"(v[5]), "v"(v[6]), "v"(v[7]));
+#endif
 }
+#undef ODDIO_DPP4
 
-__global__ __launch_bounds__(64) void ordered_sum(const float* __restrict__ contrib, uint32_t contrib_ncb,
-                                                  const uint32_t* __restrict__ n_sources_ptr, uint32_t n_frames,
-                                                  const float* __restrict__ init, float* __restrict__ out, int postfx) {
+__global__ __launch_bounds__(64 * (1 + ORD_LOADERS)) void ordered_sum(const float* __restrict__ contrib, uint32_t contrib_ncb,
+                                                   const uint32_t* __restrict__ n_sources_ptr, uint32_t n_frames,
+                                                   const float* __restrict__ init, float* __restrict__ out, int postfx) {
+    // Two waves: wave 1 streams the rows HBM -> LDS ring (every LDS-DMA instruction costs its issuer ~60 cycles, which
+    // would otherwise sit on the chain), wave 0 does nothing but the adds.  They meet in two LDS counters:
+    // `landed` = tiles (counted from the top) whose rows are in the ring, `consumed` = tiles whose rows are in the
+    // adder's registers.
     __shared__ __attribute__((aligned(16))) float ring[ORD_RING][ORD_ROWS][16];
-    const int lane = threadIdx.x;
-    const int fk = lane >> 2, m = lane & 3;
+    __shared__ uint32_t landed[ORD_LOADERS], consumed;   // landed[w]: tiles of loader w (its kk / ORD_LOADERS) in the ring
+    const int lane = threadIdx.x & 63;
+    const bool loader = threadIdx.x >= 64;
     const uint32_t cb = blockIdx.x, e = blockIdx.y;
     const uint32_t n = *n_sources_ptr;
+    const uint32_t n_tiles = (n + ORD_ROWS - 1) / ORD_ROWS;
+    if (threadIdx.x < (unsigned)ORD_LOADERS) landed[threadIdx.x] = 0u;
+    if (threadIdx.x == 0) consumed = 0u;
+    __syncthreads();
+    if (loader) {
+        const uint32_t group_stride = 2u * contrib_ncb * 1024u;      // bytes from a group's chunk to the next group's
+        // group 0: the 4-KiB chunk of this column block's quad, this column block's 64-byte rows 256 bytes apart
+        const unsigned char* chunk0 = reinterpret_cast<const unsigned char*>(contrib) + ((size_t)e * (contrib_ncb / 4u) + (cb >> 2)) * 4096u + (cb & 3u) * 64u;
+        const uint32_t lds0 = (uint32_t)(uintptr_t)&ring[0][0][0];
+        // the instruction offset (i * 1024) advances both the LDS and the memory address: the scalar offset adds the rest of i * group_stride
+        const uint32_t so = group_stride - 1024u;
+        const int voff = (lane >> 2) * 256 + (lane & 3) * 16;      // lane = (row of the group, 16-byte piece)
+        constexpr int IN_FLIGHT = 6;                                 // this loader's tiles in flight after each wait (one more right after an issue)
+        static_assert(8 * (IN_FLIGHT + 1) <= 63, "the tiles in flight fit the 6-bit VMEM counter");
+        static_assert((IN_FLIGHT + 2) * ORD_LOADERS <= ORD_RING, "ring slots for everything in flight");
+        const uint32_t me = (threadIdx.x >> 6) - 1u;                 // loader index
+        uint32_t mine = 0;                                           // tiles this loader has issued
+        // kk counts tiles from the top: tile index t = n_tiles - 1 - kk; all inside the allocation (sized in whole tiles)
+        for (uint32_t kk = me; kk < n_tiles; kk += (uint32_t)ORD_LOADERS, ++mine) {
+            const uint32_t t = n_tiles - 1u - kk;
+            // the slot of tile kk was read by tile kk - ORD_RING
+            while (kk >= (uint32_t)ORD_RING && __hip_atomic_load(&consumed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) + (uint32_t)ORD_RING <= kk)
+                __builtin_amdgcn_s_sleep(1);
+            wave_sync();
+            const uint64_t base = (uint64_t)(chunk0 + (size_t)t * ORD_GROUPS * group_stride);
+            u32x4 rsrc;
+            rsrc.x = (uint32_t)__builtin_amdgcn_readfirstlane((int)(base & 0xffffffffu));
+            rsrc.y = (uint32_t)__builtin_amdgcn_readfirstlane((int)((base >> 32) & 0xffffu));
+            rsrc.z = (uint32_t)__builtin_amdgcn_readfirstlane((int)(ORD_GROUPS * group_stride));
+            rsrc.w = 0x00020000u;
+            const uint32_t dst = (uint32_t)__builtin_amdgcn_readfirstlane((int)(lds0 + (kk % ORD_RING) * (ORD_ROWS * 64)));
+            const uint32_t so0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)so);
+            uint32_t keep;
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t"
+                         "buffer_load_dwordx4 %1, %2, 0 offen lds\n\t"
+                         "buffer_load_dwordx4 %1, %2, %4 offen offset:1024 lds\n\t"
+                         "buffer_load_dwordx4 %1, %2, %5 offen offset:2048 lds\n\t"
+                         "buffer_load_dwordx4 %1, %2, %6 offen offset:3072 lds\n\t"
+                         "s_mov_b32 m0, %0"
+                         : "=&s"(keep) : "v"(voff), "s"(rsrc), "s"(dst), "s"(so0), "s"(2u * so0), "s"(3u * so0) : "memory");
+            const uint32_t dst2 = dst + 4096u;
+            const int voff2 = voff + (int)(4u * group_stride);      // chunk 4 (8 * 128 KiB fits the 32-bit offset)
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t"
+                         "buffer_load_dwordx4 %1, %2, 0 offen lds\n\t"
+                         "buffer_load_dwordx4 %1, %2, %4 offen offset:1024 lds\n\t"
+                         "buffer_load_dwordx4 %1, %2, %5 offen offset:2048 lds\n\t"
+                         "buffer_load_dwordx4 %1, %2, %6 offen offset:3072 lds\n\t"
+                         "s_mov_b32 m0, %0"
+                         : "=&s"(keep) : "v"(voff2), "s"(rsrc), "s"(dst2), "s"(so0), "s"(2u * so0), "s"(3u * so0) : "memory");
+            if (mine >= (uint32_t)IN_FLIGHT) {
+                asm volatile("s_waitcnt vmcnt(%0)" :: "n"(8 * IN_FLIGHT) : "memory");      // everything but the newest IN_FLIGHT tiles has landed
+                wave_sync();
+                if (lane == 0) __hip_atomic_store(&landed[me], mine + 1u - (uint32_t)IN_FLIGHT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        wave_sync();
+        if (lane == 0) __hip_atomic_store(&landed[me], mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        return;
+    }
+    static_assert(ORD_ROWS * 64 == 8192, "a tile is 8 DMA instructions of 1 KiB");
+    // ---- the adder ----
+    const int fk = lane >> 2, m = lane & 3;
     const uint32_t f = cb * 16 + (uint32_t)fk;
     float s = (init != nullptr && f < n_frames) ? init[2 * f + e] : 0.0f;   // the buffered set's sum (walked first, spatial.rs:395-438)
-    asm volatile("" :: "v"(s));                                  // the load above is awaited here, before the DMA counter is in use
-    const uint32_t group_stride = 2u * contrib_ncb * 1024u;      // bytes from a group's chunk to the next group's
-    const unsigned char* chunk0 = reinterpret_cast<const unsigned char*>(contrib) + ((size_t)e * contrib_ncb + cb) * 1024u;   // group 0
-    const uint32_t lds0 = (uint32_t)(uintptr_t)&ring[0][0][0];
-    const uint32_t n_tiles = (n + ORD_ROWS - 1) / ORD_ROWS;
-    // the instruction offset (i * 1024) advances both the LDS and the memory address: the scalar offset adds the rest of i * group_stride
-    const uint32_t so = group_stride - 1024u;
-    const int voff = 16 * lane;
-    // tile t = groups [8t, 8t + 8), all inside the allocation (it is sized in whole tiles); issued from the top tile down
-    auto issue = [&](uint32_t t) {
-        const uint64_t base = (uint64_t)(chunk0 + (size_t)t * ORD_GROUPS * group_stride);
-        u32x4 rsrc;
-        rsrc.x = (uint32_t)__builtin_amdgcn_readfirstlane((int)(base & 0xffffffffu));
-        rsrc.y = (uint32_t)__builtin_amdgcn_readfirstlane((int)((base >> 32) & 0xffffu));
-        rsrc.z = (uint32_t)__builtin_amdgcn_readfirstlane((int)(ORD_GROUPS * group_stride));
-        rsrc.w = 0x00020000u;
-        const uint32_t dst = (uint32_t)__builtin_amdgcn_readfirstlane((int)(lds0 + (t % ORD_RING) * (ORD_ROWS * 64)));
-        const uint32_t so0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)so);
-        uint32_t keep;
-        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t"
-                     "buffer_load_dwordx4 %1, %2, 0 offen lds\n\t"
-                     "buffer_load_dwordx4 %1, %2, %4 offen offset:1024 lds\n\t"
-                     "buffer_load_dwordx4 %1, %2, %5 offen offset:2048 lds\n\t"
-                     "buffer_load_dwordx4 %1, %2, %6 offen offset:3072 lds\n\t"
-                     "s_mov_b32 m0, %0"
-                     : "=&s"(keep) : "v"(voff), "s"(rsrc), "s"(dst), "s"(so0), "s"(2u * so0), "s"(3u * so0) : "memory");
-        const uint32_t dst2 = dst + 4096u;
-        const int voff2 = voff + (int)(4u * group_stride);      // chunk 4 (8 * 128 KiB fits the 32-bit offset)
-        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t"
-                     "buffer_load_dwordx4 %1, %2, 0 offen lds\n\t"
-                     "buffer_load_dwordx4 %1, %2, %4 offen offset:1024 lds\n\t"
-                     "buffer_load_dwordx4 %1, %2, %5 offen offset:2048 lds\n\t"
-                     "buffer_load_dwordx4 %1, %2, %6 offen offset:3072 lds\n\t"
-                     "s_mov_b32 m0, %0"
-                     : "=&s"(keep) : "v"(voff2), "s"(rsrc), "s"(dst2), "s"(so0), "s"(2u * so0), "s"(3u * so0) : "memory");
-    };
-    static_assert(ORD_ROWS * 64 == 8192, "a tile is 8 DMA instructions of 1 KiB");
-    static_assert(8 * (ORD_RING - 1) <= 63, "the tiles in flight fit the 6-bit VMEM counter");
-    // kk counts tiles from the top: tile index t = n_tiles - 1 - kk
-    for (uint32_t kk = 0; kk < (uint32_t)(ORD_RING - 1) && kk < n_tiles; ++kk) issue(n_tiles - 1u - kk);
+#define ODDIO_ORD_WAIT(KK)                                                                                                \
+    {   /* tile KK (counted from the top) is in its ring slot */                                                          \
+        while (__hip_atomic_load(&landed[(KK) % ORD_LOADERS], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) <= (KK) / ORD_LOADERS) __builtin_amdgcn_s_sleep(1); \
+        wave_sync();                                                                                                      \
+    }
+#define ODDIO_ORD_DONE(KK)                                                                                                \
+    {   /* every row of tile KK is in registers: its slot may be refilled */                                              \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                                \
+        if (lane == 0) __hip_atomic_store(&consumed, (KK) + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);          \
+    }
     uint32_t kk = 0;
     if (n_tiles > 0 && (n % ORD_ROWS) != 0u) {
         // top tile of a set whose length is not a whole number of tiles: rows of sources >= n are not part of the sum
-        const uint32_t t = n_tiles - 1u;
-        if (ORD_RING - 1 < n_tiles) {
-            asm volatile("s_waitcnt vmcnt(%0)" :: "n"(8 * (ORD_RING - 2)) : "memory");
-            issue(t - (uint32_t)(ORD_RING - 1));
-        } else {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
-        wave_sync();
-        const float* tp = &ring[t % ORD_RING][0][fk];
-        for (int r = (int)(n - t * ORD_ROWS) - 1; r >= 0; --r) s = s + tp[r * 16];
-        wave_sync();
+        ODDIO_ORD_WAIT(0u)
+        const float* tp = &ring[0][0][fk];
+        for (int r = (int)(n - (n_tiles - 1u) * ORD_ROWS) - 1; r >= 0; --r) s = s + tp[r * 16];
+        ODDIO_ORD_DONE(0u)
         kk = 1;
     }
     // whole tiles, software pipelined over batches of ORD_Q quad steps: the LDS reads of batch b + 1 (of the next
     // tile across a tile boundary, once that tile has landed) are in flight while batch b is added
     float v[2][ORD_Q];
     const uint32_t lane_off = (uint32_t)m * 16u + (uint32_t)fk;          // floats: row m, frame fk
-#define ODDIO_ORD_WAIT(KK)                                                                                                \
-    {   /* tile KK has landed; then keep ORD_RING - 1 tiles in flight (the slot refilled is the one tile KK - 1 was read from) */ \
-        if ((KK) + ORD_RING - 1 < n_tiles) {                                                                              \
-            asm volatile("s_waitcnt vmcnt(%0)" :: "n"(8 * (ORD_RING - 2)) : "memory");                                    \
-            issue(n_tiles - 1u - (KK) - (uint32_t)(ORD_RING - 1));                                                        \
-        } else {                                                                                                          \
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                              \
-        }                                                                                                                 \
-        wave_sync();                                                                                                      \
-    }
     // batch B of a tile = quad steps i = 31 - 8B .. 24 - 8B (rows 4i + m), read in descending order
+    // (sched_barrier: the reads of the next batch are issued BEFORE the adds that cover their latency; hipcc otherwise
+    // sinks them below the adds and waits for them right after issuing them)
 #define ODDIO_ORD_LOAD(SET, TP, B)                                                                                        \
-    _Pragma("unroll") for (int q = 0; q < ORD_Q; ++q) v[SET][q] = (TP)[(31 - ORD_Q * (B) - q) * 64];
-#define ODDIO_ORD_ADD(SET)                                                                                                \
-    _Pragma("unroll") for (int q = 0; q < ORD_Q; ++q) {                                                                   \
-        chain_add<3>(s, v[SET][q]); chain_add<2>(s, v[SET][q]); chain_add<1>(s, v[SET][q]); chain_add<0>(s, v[SET][q]);   \
-    }
+    _Pragma("unroll") for (int q = 0; q < ORD_Q; ++q) v[SET][q] = (TP)[(31 - ORD_Q * (B) - q) * 64];                      \
+    __builtin_amdgcn_sched_barrier(0);
+#define ODDIO_ORD_ADD(SET) chain_add8(s, v[SET]); __builtin_amdgcn_sched_barrier(0);
     if (kk < n_tiles) {
         ODDIO_ORD_WAIT(kk)
-        const float* tp = &ring[(n_tiles - 1u - kk) % ORD_RING][0][0] + lane_off;
+        const float* tp = &ring[kk % ORD_RING][0][0] + lane_off;
         ODDIO_ORD_LOAD(0, tp, 0)
         for (; kk < n_tiles; ++kk) {
             ODDIO_ORD_LOAD(1, tp, 1)
@@ -1286,13 +1400,14 @@ __global__ __launch_bounds__(64) void ordered_sum(const float* __restrict__ cont
             ODDIO_ORD_LOAD(0, tp, 2)
             ODDIO_ORD_ADD(1)
             ODDIO_ORD_LOAD(1, tp, 3)
+            const uint32_t* next_landed = &landed[(kk + 1u) % ORD_LOADERS];
+            uint32_t seen = __hip_atomic_load(next_landed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // read under the adds below
             ODDIO_ORD_ADD(0)
-            // every read of this tile has been issued; they complete (in order) before the next tile's first read
-            // does, and its slot is refilled only by the `issue` at the top of the next-but-one wait
+            ODDIO_ORD_DONE(kk)
             if (kk + 1 < n_tiles) {
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // this tile's rows are in registers before its slot may be refilled
-                ODDIO_ORD_WAIT(kk + 1)
-                tp = &ring[(n_tiles - 2u - kk) % ORD_RING][0][0] + lane_off;
+                while (seen <= (kk + 1u) / ORD_LOADERS) { __builtin_amdgcn_s_sleep(1); seen = __hip_atomic_load(next_landed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+                wave_sync();
+                tp = &ring[(kk + 1u) % ORD_RING][0][0] + lane_off;
                 ODDIO_ORD_LOAD(0, tp, 0)
             }
             ODDIO_ORD_ADD(1)
@@ -1300,6 +1415,7 @@ __global__ __launch_bounds__(64) void ordered_sum(const float* __restrict__ cont
     }
 #undef ODDIO_ORD_ADD
 #undef ODDIO_ORD_LOAD
+#undef ODDIO_ORD_DONE
 #undef ODDIO_ORD_WAIT
     if (m == 0 && f < n_frames) out[2 * f + e] = postfx_apply(s, postfx);
 }
