@@ -31,7 +31,6 @@ import os
 import socket
 import subprocess
 import sys
-import threading
 import time
 
 import numpy as np
@@ -135,7 +134,86 @@ def _time_scene(oc, make_scene, cb_per_round, budget_s):
     return total_cb, t_total
 
 
-def cpu_baseline(seed: int, budget_s: float = 20.0) -> dict:
+def parity_check(oc, bank, seed: int, start: float, device: int, n_src: int) -> dict:
+    """Part of the cpu_baseline leg (the oracle is the checker): ONE callback of `n_src` sources of the bench generator
+    -- the headline source count, clips drawn from the baseline's bank -- rendered by the oracle (the reference's
+    sequential f32 sum, and the same contributions accumulated in f64) and by the HIP scene in both of its modes."""
+    import torch
+
+    import oddio_amd as oa
+    from oddio_amd import synth
+    sc = synth.make_scene(seed, n_src)
+    idx = ((np.arange(n_src, dtype=np.uint64) * np.uint64(0x9E3779B97F4A7C15)) >> np.uint64(20)) % np.uint64(bank.shape[0])
+    idx = idx.astype(np.uint32)
+    interval = np.float32(1.0) / np.float32(RATE)
+    ref = np.zeros((N_FRAMES, 2), dtype=np.float32)
+    scene = oc.SpatialScene()
+    scene.play_frames_bulk(RATE, bank, start, sc["position"], sc["velocity"], sc["radius"], clip_of=idx)
+    t0 = time.perf_counter()
+    oc.run(scene, RATE, ref)
+    t_ref = time.perf_counter() - t0
+    del scene
+    scene = oc.SpatialScene()
+    scene.play_frames_bulk(RATE, bank, start, sc["position"], sc["velocity"], sc["radius"], clip_of=idx)
+    ref64 = scene.sample_f64acc(interval, N_FRAMES)
+    del scene
+    dev_bank = torch.from_numpy(bank).to(torch.device("cuda", device))
+    clip_len = bank.shape[1]
+    frames = [oa.Frames.from_device_ptr(RATE, dev_bank.data_ptr() + 4 * clip_len * i, clip_len, device=device, copy=False) for i in range(bank.shape[0])]
+    got = {}
+    for mode, name in ((oa.MODE_FAST, "fast"), (oa.MODE_ORDERED, "ordered")):
+        control, hscene = oa.SpatialScene(device=device, max_sources=n_src, max_frames=N_FRAMES)
+        hscene.set_mode(mode)
+        control.play_frames_batch([frames[int(k)] for k in idx], np.full(n_src, start), sc["position"], sc["velocity"], sc["radius"])
+        got[name] = hscene.sample_n(interval, N_FRAMES)
+        del control, hscene
+    scale = float(np.abs(ref).max())
+    rel = lambda a, b: float(np.abs(a.astype(np.float64) - b.astype(np.float64)).max()) / scale   # noqa: E731
+    return {
+        "sources": n_src, "callbacks": 1, "max_abs_reference": scale,
+        "ordered_bit_exact": bool(np.array_equal(got["ordered"], ref)),
+        "fast_rel_err_vs_reference": rel(got["fast"], ref),
+        "fast_rel_err_vs_f64": rel(got["fast"], ref64),
+        "reference_rel_err_vs_f64": rel(ref, ref64),
+        "tolerance": 1e-5,
+        "note": "relative to max|reference|; the reference is the oracle's sequential f32 sum in the reference's walk order "
+                "(oracle/oddio_oracle.c), f64 = the same contributions accumulated in f64.  At this source count the reference's "
+                "own f32 sum is further than 1e-5 from the exact sum, so only the ORDERED mode (same order, bit-exact) can be within "
+                "1e-5 of it; FAST is the deterministic tree sum the throughput is quoted in.",
+        "oracle_seconds_per_callback_1_thread": t_ref,
+    }
+
+
+def cpu_worker(spec: str) -> None:
+    """One process of the all-cores leg: `per` sources of the bench generator starting at `first`, on a small clip bank
+    of its own (64 clips; sources share them, which flatters the CPU's caches, never the GPU)."""
+    from oddio_amd import synth
+    from oracle import oracle_c as oc
+    per, rounds, seed, first = (int(x) for x in spec.split(","))
+    base_len, reps, start, n_bank = 40960, 4, 0.6, 64
+    clip_len = base_len * reps
+    cb_per_round = (clip_len - int(start * RATE)) // N_FRAMES - 1
+    sc = synth.make_scene(seed, n_bank, first_index=first)
+    one = np.sin((2.0 * np.pi / RATE) * sc["freq_hz"][:, None].astype(np.float64) * np.arange(base_len, dtype=np.float64)[None, :]).astype(np.float32)
+    bank = np.tile(one, (1, reps))
+    out = np.zeros((N_FRAMES, 2), dtype=np.float32)
+    scenes = []
+    for _ in range(rounds):
+        scene = _oracle_scene(oc, bank, first, per, seed, start)
+        oc.run(scene, RATE, out)                     # insert queue drained, untimed
+        scenes.append(scene)
+    print("ready", flush=True)
+    sys.stdin.readline()
+    t0 = time.perf_counter()
+    acc = 0.0
+    for scene in scenes:
+        for _ in range(cb_per_round - 1):
+            oc.run(scene, RATE, out)
+        acc += float(np.abs(out).sum())
+    print(rounds * (cb_per_round - 1), time.perf_counter() - t0, acc, flush=True)
+
+
+def cpu_baseline(seed: int, budget_s: float = 20.0, parity_device: int | None = None, parity_sources: int = 0) -> dict:
     """single thread (the reference's execution model: one audio thread) on configs 1, 2
     and a 16 384-source slice of config 3, then ALL host cores by scene sharding (T independent partial
     scenes, partial buffers summed at the end -- what a user of the reference would have to do)."""
@@ -177,43 +255,49 @@ def cpu_baseline(seed: int, budget_s: float = 20.0) -> dict:
     cb, t = _time_scene(oc, lambda: _oracle_scene(oc, bank, 0, 16384, seed, start), cb_per_round, share)
     legs["config3_slice_16384_sources_1_thread"] = 16384 * N_FRAMES * cb / t
 
-    # all cores: T threads, each with its own partial scene of 1024 sources (ctypes releases the GIL)
-    T = os.cpu_count() or 1
-    per = 1024
-    scenes = [_oracle_scene(oc, bank, t_ * per, per, seed, start) for t_ in range(T)]
-    outs = [np.zeros((N_FRAMES, 2), dtype=np.float32) for _ in range(T)]
-    for sc_, o in zip(scenes, outs):
-        oc.run(sc_, RATE, o)                                   # insert queue drained, untimed
-    n_cb = max(2, min(cb_per_round - 1, int(share / (per * 5.5e-6)) or 2))
-    barrier = threading.Barrier(T + 1)
+    parity = parity_check(oc, bank, seed, start, parity_device, parity_sources) if parity_device is not None and parity_sources > 0 else None
 
-    def work(i):
-        barrier.wait()
-        for _ in range(n_cb):
-            oc.run(scenes[i], RATE, outs[i])
-        barrier.wait()
-    threads = [threading.Thread(target=work, args=(i,)) for i in range(T)]
-    for th in threads:
-        th.start()
-    barrier.wait()
+    # all cores: T PROCESSES, each with its own partial scene of 1024 sources (what a user of the reference would have
+    # to do: one audio thread per partial scene, partial buffers summed).  Processes, not threads: in-process threads
+    # around the C calls did not scale on either box (3.8 % parallel efficiency on the 256-thread GPU host), separate
+    # processes do.  Every worker sets up, reports ready, and all are released together.
+    # (the cores this process may run on: on the GPU box the job's affinity mask is a fraction of os.cpu_count())
+    T = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    per, rounds = 1024, 4
+    workers = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-worker", f"{per},{rounds},{seed},{t_ * per}"],
+                                stdin=subprocess.PIPE, stdout=subprocess.PIPE, text=True) for t_ in range(T)]
+    for w in workers:
+        assert w.stdout.readline().strip() == "ready", "cpu worker failed to start"
     t0 = time.perf_counter()
-    barrier.wait()
-    mix = np.sum(np.stack(outs), axis=0, dtype=np.float32)     # the partial buffers of the last callback, summed
+    for w in workers:
+        w.stdin.write("go\n")
+        w.stdin.flush()
+    done = [w.stdout.readline().split() for w in workers]       # "<callbacks> <seconds> <checksum>"
     t_all = time.perf_counter() - t0
-    for th in threads:
-        th.join()
-    assert np.isfinite(mix).all()
-    all_cores = T * per * N_FRAMES * n_cb / t_all
-    legs[f"all_cores_{T}_threads_x_{per}_sources"] = all_cores
+    for w in workers:
+        w.wait()
+    n_cb_all = sum(int(d[0]) for d in done)
+    assert all(np.isfinite(float(d[2])) for d in done)
+    all_cores = per * N_FRAMES * n_cb_all / t_all
+    slowest = max(float(d[1]) for d in done)
+    efficiency = all_cores / (T * single)
+    legs[f"all_cores_{T}_processes_x_{per}_sources"] = all_cores
+    if efficiency < 0.5:
+        print(f"bench.py: WARNING: the all-cores CPU baseline reached only {efficiency:.2f} of {T} x the single-thread rate "
+              f"(slowest worker {slowest:.2f} s of {t_all:.2f} s wall): not a usable baseline on this host", file=sys.stderr, flush=True)
     return {
         "value": single, "unit": "source-frames/s", "cores": 1, "kind": "port",
         "sample": f"4096-source slice of the workload (same generator), {cb_per_round}-callback rounds of {N_FRAMES} frames, "
                   f"C restatement of the reference (oracle/oddio_oracle.c, -O2 -ffp-contract=off, not rustc output), "
                   f"single thread = the reference's one audio thread",
-        "all_cores": {"value": all_cores, "cores": T, "sample": f"{T} threads x {per}-source partial scenes, {n_cb} callbacks, partial buffers summed"},
+        "all_cores": {"value": all_cores, "cores": T, "parallel_efficiency": efficiency, "valid": bool(efficiency >= 0.5),
+                      "sample": f"{T} processes x {per}-source partial scenes, {n_cb_all // T} callbacks each in {rounds} rounds, released together; "
+                                f"wall {t_all:.2f} s, slowest worker {slowest:.2f} s"},
         "legs": legs,
+        "parity": parity,
         "cpu_model": _cpu_model(),
         "host_cores_available": os.cpu_count(),
+        "cores_in_affinity_mask": T,
         "max_realtime_sources_per_core": single / RATE,
         "max_realtime_sources_all_cores": all_cores / RATE,
     }
@@ -261,13 +345,17 @@ def main():
     ap.add_argument("--share-devices", action="store_true", help="smoke-testing on a box with fewer GPUs than ranks: rank r uses device r %% count")
     ap.add_argument("--reset-every", type=int, default=320, help="callbacks between host-side motion resets of all sources")
     ap.add_argument("--precondition-ms", type=float, default=200.0,
-                    help="GPU clock pre-conditioning before the warm-up steps: this many ms of elementwise f32 work on a scratch "
-                         "tensor (not callbacks), so that a short warm-up starts from loaded clocks instead of the idle state the "
-                         "host-side set-up leaves behind (DESIGN.md section 5); 0 disables it")
+                    help="GPU clock pre-conditioning before the warm-up steps: this many ms of untimed callbacks of the workload "
+                         "itself, after which every source is put back to its starting state, so that a short warm-up starts from "
+                         "loaded clocks instead of the idle state the host-side set-up leaves behind (DESIGN.md section 5); 0 disables it")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-worker", default=None, help=argparse.SUPPRESS)
     ap.add_argument("--cpu-budget", type=float, default=20.0)
     args = ap.parse_args()
 
+    if args.cpu_worker:
+        cpu_worker(args.cpu_worker)
+        return
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(self_launch(args.gpus))
 
@@ -341,18 +429,22 @@ def main():
         torch.cuda.synchronize()
 
     if args.precondition_ms > 0:
-        # DVFS: after seconds of host-side set-up the chip sits in a low clock state and needs ~30 ms of load to
-        # leave it; the mix kernel is LDS/VALU-side bound enough to feel that (tools/ramp_probe.py).  Untimed, and
-        # not the hot path: plain elementwise work on a scratch tensor.
-        scratch = torch.rand((1 << 28,), dtype=torch.float32, device=torch.device("cuda", device))
+        # DVFS: after seconds of host-side set-up the chip sits in a low clock state and needs ~30 ms of load to leave it;
+        # the mix kernel is latency-bound enough to feel that (tools/ramp_probe.py).  Untimed callbacks of the workload
+        # itself, then every source is put back where BASELINE's workload starts: clip cursors rewound, Motion reset.
         t_pre = time.perf_counter()
-        k = 0
         while (time.perf_counter() - t_pre) * 1e3 < args.precondition_ms:
-            torch.sin(scratch)
-            k += 1
-            if k % 8 == 0:
-                torch.cuda.synchronize()
-        del scratch
+            for _ in range(32):
+                one_step()
+            scene.synchronize()
+        # the reset is host work (a batch set_motion of every source): ~25 ms of callbacks are queued first, so that the
+        # GPU stays loaded while the host prepares it, and the reset itself is applied in stream order right behind them
+        for _ in range(96):
+            one_step()
+        control.set_motion_batch(g["ids"], g["spec"]["position"], g["spec"]["velocity"], True)
+        scene.seek_all(-float((step_no % span) * N_FRAMES) / RATE)
+        scene.sample_device(interval, out.data_ptr(), 0)      # a zero-frame callback: the Motion updates are applied, no time passes
+        step_no = 0
     for _ in range(args.warmup):
         one_step()
     scene.set_profiling(2)     # two hipEvents per callback, around spatial_mix (the roofline kernel), inside the timed region
@@ -475,9 +567,11 @@ def main():
             },
         }
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(args.seed, args.cpu_budget)
+            line["cpu_baseline"] = cpu_baseline(args.seed, args.cpu_budget, parity_device=device, parity_sources=S)
+            line["parity"] = line["cpu_baseline"].pop("parity")
             line["cpu_baseline"]["gpu_over_cpu"] = value / line["cpu_baseline"]["value"]
-            line["cpu_baseline"]["gpu_over_cpu_all_cores"] = value / line["cpu_baseline"]["all_cores"]["value"]
+            if line["cpu_baseline"]["all_cores"]["valid"]:
+                line["cpu_baseline"]["gpu_over_cpu_all_cores"] = value / line["cpu_baseline"]["all_cores"]["value"]
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.barrier()

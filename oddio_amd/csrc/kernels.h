@@ -261,6 +261,10 @@ __device__ __forceinline__ double f64_rem_euclid(double a, double b) {   // core
 #ifndef ODDIO_MIX_PREFETCH
 #define ODDIO_MIX_PREFETCH 1
 #endif
+#ifndef ODDIO_WIN_POLICY
+#define ODDIO_WIN_POLICY " nt"    // cache policy of the window loads: streaming -- every sample is read once per callback (same box, spatial_mix:
+                                 // default policy 0.2343 / 0.2284 ms, nt 0.2253 / 0.2265, sc1 0.2337 / 0.2334; profiles/r03_ab_window_policy.txt)
+#endif
 #ifndef ODDIO_STORE_VARIANT
 #define ODDIO_STORE_VARIANT 0
 #endif
@@ -499,7 +503,7 @@ __device__ __forceinline__ int4 window_desc(const float* clip, int clip_len4, in
 //   s0 = t_c * rate (f64, :177), base = s0 as isize (:179), frac0 = (s0 - base) as f32 (:181/:189), ds (:178);
 //   the window = every sample index the tile's four streams can touch.  Its upper end only has to be an upper bound:
 //   the cursor after 255 sequentially rounded `offset += ds` steps is below frac0 + 255 * ds by at most
-//   255 half-ulps of its own magnitude, so the closed form plus that margin covers it.
+//   255 half-ulps of its own magnitude (1.6e-5 relative), so the f32 closed form plus a 1e-4 relative margin covers it.
 __device__ __forceinline__ TileRec make_tile_rec(const SceneParams& P, const SrcStatic& s, const EarParams& e0, const EarParams& e1, uint32_t tile) {
     TileRec r = {};                                  // info == 0: PATH_SKIP
     if (e0.flags & EAR_SKIP) return r;
@@ -538,9 +542,9 @@ __device__ __forceinline__ TileRec make_tile_rec(const SceneParams& P, const Src
                 int i0, i1;
                 if (fast) { i0 = (int)base; i1 = (int)base + 255; }
                 else {
-                    const double xb = (double)frac0 + 255.0 * (double)ds;
-                    const double xu = xb + fabs(xb) * 4.0e-5 + 1.0e-4;                    // >= the exactly rounded running sum
-                    if (!(xu < 8.0e6)) generic = 1;
+                    const float xb = frac0 + 255.0f * ds;
+                    const float xu = xb + fabsf(xb) * 1.0e-4f + 1.0e-2f;                  // >= the exactly rounded running sum (f32 is enough for a bound)
+                    if (!(xu < 8.0e6f)) generic = 1;
                     i0 = (int)base + (int)frac0;
                     i1 = (int)base + (int)xu;
                 }
@@ -669,11 +673,11 @@ __device__ __forceinline__ void window_dma(uint32_t lds_dst, uint32_t d0, uint32
     uint32_t keep;
     // pieces 0 and 1 from every lane: lanes past the window write zeros inside the buffer (harmless, no traffic)
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 4\n\t"
-                 "buffer_load_dwordx4 %1, %2, 0 offen lds\n\tbuffer_load_dwordx4 %1, %2, 0 offen offset:1024 lds\n\ts_mov_b32 m0, %0"
+                 "buffer_load_dwordx4 %1, %2, 0 offen" ODDIO_WIN_POLICY " lds\n\tbuffer_load_dwordx4 %1, %2, 0 offen offset:1024" ODDIO_WIN_POLICY " lds\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(voff), "s"(rsrc), "s"(lds_dst) : "memory");
     if (nvec > 128) {
         if (lane16 < 16 * WIN_LAST_LANES)
-            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen offset:2048 lds\n\ts_mov_b32 m0, %0"
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen offset:2048" ODDIO_WIN_POLICY " lds\n\ts_mov_b32 m0, %0"
                          : "=&s"(keep) : "v"(voff), "s"(rsrc), "s"(lds_dst) : "memory");
     }
     static_assert(WIN_PIECES == 3 && WIN_LAST_LANES > 0 && WIN_LAST_LANES <= 64, "three pieces cover a window buffer");

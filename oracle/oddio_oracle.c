@@ -985,3 +985,43 @@ void oo_run(oo_signal* s, uint32_t sample_rate, float* out, size_t n) { /* lib.r
     float interval = 1.0f / (float)sample_rate;
     oo_sample(s, interval, out, n);
 }
+
+
+/* ---- bench harness (not part of the restatement): T threads, each rendering its own scene -------------------------
+ * What a user of the reference would do to use every host core: T independent partial scenes, one audio thread each
+ * (the partial buffers summed afterwards).  Returns the wall time of the slowest thread's `n_callbacks` callbacks,
+ * all threads released together; each thread's seconds land in `per_thread` (may be NULL). */
+#include <pthread.h>
+#include <time.h>
+typedef struct {
+    oo_signal* scene; uint32_t rate; size_t n_frames, n_callbacks; float* out;
+    pthread_barrier_t* start; double seconds;
+} oo_bench_arg;
+static double oo_now(void) { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec; }
+static void* oo_bench_thread(void* p) {
+    oo_bench_arg* a = (oo_bench_arg*)p;
+    pthread_barrier_wait(a->start);
+    const double t0 = oo_now();
+    for (size_t k = 0; k < a->n_callbacks; k++) oo_run(a->scene, a->rate, a->out, a->n_frames);
+    a->seconds = oo_now() - t0;
+    return NULL;
+}
+double oo_bench_scenes(size_t n_threads, oo_signal** scenes, uint32_t rate, size_t n_frames, size_t n_callbacks, float* outs, double* per_thread) {
+    pthread_t* th = (pthread_t*)calloc(n_threads, sizeof(*th));
+    oo_bench_arg* args = (oo_bench_arg*)calloc(n_threads, sizeof(*args));
+    pthread_barrier_t start;
+    pthread_barrier_init(&start, NULL, (unsigned)n_threads + 1u);
+    for (size_t t = 0; t < n_threads; t++) {
+        args[t].scene = scenes[t]; args[t].rate = rate; args[t].n_frames = n_frames; args[t].n_callbacks = n_callbacks;
+        args[t].out = outs + t * n_frames * 2; args[t].start = &start;
+        pthread_create(&th[t], NULL, oo_bench_thread, &args[t]);
+    }
+    pthread_barrier_wait(&start);
+    const double t0 = oo_now();
+    for (size_t t = 0; t < n_threads; t++) pthread_join(th[t], NULL);
+    const double wall = oo_now() - t0;
+    for (size_t t = 0; t < n_threads; t++) if (per_thread) per_thread[t] = args[t].seconds;
+    pthread_barrier_destroy(&start);
+    free(th); free(args);
+    return wall;
+}

@@ -130,6 +130,10 @@ void  oo_ring_sample(const oo_ring* r, uint32_t rate, float t, float interval, f
 float oo_ring_write_cursor(const oo_ring* r);
 const float* oo_ring_buffer(const oo_ring* r, size_t* len);
 
+/* Bench harness (bench.py's cpu_baseline leg): n_threads pthreads, each running n_callbacks callbacks of its own scene;
+ * returns the wall time from the common start to the last thread's end. */
+double oo_bench_scenes(size_t n_threads, oo_signal** scenes, uint32_t rate, size_t n_frames, size_t n_callbacks, float* outs, double* per_thread);
+
 #ifdef __cplusplus
 }
 #endif

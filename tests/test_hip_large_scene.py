@@ -23,6 +23,15 @@ RATE = 48000
 INTERVAL = np.float32(1.0) / np.float32(RATE)
 N = 1024
 S_BIG = 262144
+# Tolerances of the FAST (tree-sum) mode, stated against what they are measured against:
+NORTH_STAR_TOL = 1e-5          # BASELINE.json north_star: relative to max|reference|
+FAST_VS_EXACT_TOL = 2e-6       # |gpu - f64-accumulated sum| (measured 2.4e-7 at 262 144 sources)
+# The reference's OWN sequential f32 sum is ~sqrt(S) * eps from the exact sum: measured 1.5e-5 / 1.8e-5 at
+# 262 144 sources, i.e. already outside NORTH_STAR_TOL of the exact value.  No sum order but the reference's can then be
+# within 1e-5 of the reference: FAST mode does NOT meet the north_star tolerance at this size (ORDERED mode, bit-exact,
+# does).  What FAST is held to against the reference here is this documented bound, not 1e-5:
+FAST_VS_REFERENCE_BOUND_262144 = 4e-5
+FAST_VS_REFERENCE_BOUND_65536 = 2e-5
 CLIP = 8192
 START = 0.06
 SEED = 4242
@@ -121,14 +130,16 @@ def test_config3_fast_mode_vs_sequential_and_f64_oracle(big):
         err_ref = float(np.abs(ref.astype(np.float64) - ref64).max())
         report.append((scale, d_ref / scale, err_gpu / scale, err_ref / scale))
         assert scale > 0
-        # (ii) never further from the exactly accumulated sum than 4x the reference's own rounding error
+        # (a) the tree sum against the exact (f64-accumulated) sum of the same contributions
+        assert err_gpu <= FAST_VS_EXACT_TOL * scale, report
+        # (b) ... and never further from it than 4x the reference's own rounding error
         assert err_gpu <= 4 * err_ref + 1e-7 * scale, report
-        # (i) north_star: 1e-5 relative to the reference CPU result.  The reference's own sequential f32 sum is
-        # ~sqrt(S) * eps away from the exact sum, so where THAT distance exceeds 1e-5 no sum
-        # order other than the reference's can meet (i); the bound then is the triangle inequality through the
-        # exact sum (|gpu - ref| <= err_gpu + err_ref).  ORDERED mode (next test) is the bit-exact statement.
-        assert d_ref <= max(1e-5 * scale, err_gpu + err_ref + 1e-7 * scale), report
-    print("config3 FAST: (max|ref|, |gpu-ref|/s, |gpu-f64|/s, |ref-f64|/s) per callback:", report)
+        # (c) against the reference itself: NOT the north_star's 1e-5 at this size (see FAST_VS_REFERENCE_BOUND_262144);
+        # the conforming statement is the ORDERED test below
+        assert d_ref <= FAST_VS_REFERENCE_BOUND_262144 * scale, report
+        fast_conforms = d_ref <= NORTH_STAR_TOL * scale
+        report[-1] = report[-1] + (fast_conforms,)
+    print("config3 FAST: (max|ref|, |gpu-ref|/s, |gpu-f64|/s, |ref-f64|/s, within 1e-5 of the reference) per callback:", report)
     assert len(scene) == S_BIG
 
 
@@ -171,8 +182,9 @@ def test_config4_per_gpu_scene_65536_vs_oracle(big):
         err_ref = float(np.abs(ref.astype(np.float64) - ref64).max())
         d_ref = float(np.abs(got - ref).max())
         assert scale > 0
+        assert err_gpu <= FAST_VS_EXACT_TOL * scale, (cb, err_gpu / scale)
         assert err_gpu <= 4 * err_ref + 1e-7 * scale, (cb, err_gpu / scale, err_ref / scale)
-        assert d_ref <= max(1e-5 * scale, err_gpu + err_ref + 1e-7 * scale), (cb, d_ref / scale)
+        assert d_ref <= FAST_VS_REFERENCE_BOUND_65536 * scale, (cb, d_ref / scale)      # documented bound, not the north_star's 1e-5 (top of file)
     assert len(scene) == S
     scene.close()
     control2, scene2, handles2, frames2 = play_shard(big, 0, S, mode=1)
