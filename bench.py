@@ -342,6 +342,9 @@ def main():
                     help="N>1: 'scenes' = one independent scene per GPU (configs[3] pattern, no collective); "
                          "'sharded' = ONE scene of N*sources split into contiguous index shards with an RCCL all-reduce "
                          "of the 8 KiB stereo buffer per callback (configs[4] pattern)")
+    ap.add_argument("--reduce", choices=["rccl", "p2p"], default="rccl",
+                    help="--mode sharded: the cross-rank sum of the stereo buffer -- RCCL all-reduce, or the library's deterministic "
+                         "peer-to-peer reduce (rank-ordered sum on rank 0; works with several ranks on one GPU)")
     ap.add_argument("--share-devices", action="store_true", help="smoke-testing on a box with fewer GPUs than ranks: rank r uses device r %% count")
     ap.add_argument("--reset-every", type=int, default=320, help="callbacks between host-side motion resets of all sources")
     ap.add_argument("--precondition-ms", type=float, default=200.0,
@@ -391,12 +394,12 @@ def main():
     if sharded:
         # ONE seeded scene of world * S sources; this rank owns the contiguous index shard [lo, hi)
         from oddio_amd import sharding
-        uid = sharding.exchange_unique_id(dist)
+        uid = sharding.exchange_unique_id(dist) if args.reduce == "rccl" else None
         lo, hi = sharding.shard_range(world * S, world, rank)
         holder = {}
 
         def factory():
-            holder["sh"] = sharding.ShardedSpatialScene(device, world * S, N_FRAMES, rank, world, uid)
+            holder["sh"] = sharding.ShardedSpatialScene(device, world * S, N_FRAMES, rank, world, uid, reduce=args.reduce, dist=dist)
             return holder["sh"].control, holder["sh"].scene
         g = build_gpu_scene(device, hi - lo, L, args.seed, start_seconds, args.clips, first_index=lo, scene_factory=factory)
     else:
@@ -432,11 +435,11 @@ def main():
         # DVFS: after seconds of host-side set-up the chip sits in a low clock state and needs ~30 ms of load to leave it;
         # the mix kernel is latency-bound enough to feel that (tools/ramp_probe.py).  Untimed callbacks of the workload
         # itself, then every source is put back where BASELINE's workload starts: clip cursors rewound, Motion reset.
-        t_pre = time.perf_counter()
-        while (time.perf_counter() - t_pre) * 1e3 < args.precondition_ms:
-            for _ in range(32):
-                one_step()
-            scene.synchronize()
+        # (a fixed number of callbacks, ~0.3 ms each: the ranks of a sharded scene must all make the same calls)
+        for k in range(int(args.precondition_ms / 0.3)):
+            one_step()
+            if k % 32 == 31:
+                scene.synchronize()
         # the reset is host work (a batch set_motion of every source): ~25 ms of callbacks are queued first, so that the
         # GPU stays loaded while the host prepares it, and the reset itself is applied in stream order right behind them
         for _ in range(96):
@@ -529,7 +532,8 @@ def main():
             shape = (f"BASELINE configs[2]: SpatialScene, {S} moving FramesSignal sources (own {L}-sample clip each), " if args.clips <= 0 or args.clips >= S
                      else f"real-time confirmation run: SpatialScene, {S} moving FramesSignal sources sharing {args.clips} clips of {L} samples, ")
         elif sharded:
-            shape = f"BASELINE configs[4] pattern: ONE SpatialScene of {world * S} moving FramesSignal sources in {world} contiguous index shards + RCCL all-reduce of the stereo buffer, "
+            red = "RCCL all-reduce" if args.reduce == "rccl" else "rank-ordered peer-to-peer reduce"
+            shape = f"BASELINE configs[4] pattern: ONE SpatialScene of {world * S} moving FramesSignal sources in {world} contiguous index shards + {red} of the stereo buffer, "
         else:
             shape = f"BASELINE configs[3] pattern: {world} independent SpatialScenes, one per GPU, {S} moving FramesSignal sources each (per-GPU work as at N=1), "
         line = {
@@ -548,7 +552,7 @@ def main():
             "config": {
                 "workload": shape + f"Doppler + propagation delay, 48 kHz stereo, {N_FRAMES}-frame callbacks",
                 "sources_per_gpu": S, "frames_per_callback": N_FRAMES, "sample_rate": RATE, "clip_len": L,
-                "parallelism": ("single-gpu" if world == 1 else ("source-sharded scene + RCCL stereo-buffer all-reduce" if sharded else "scene-parallel")),
+                "parallelism": ("single-gpu" if world == 1 else ((f"source-sharded scene + stereo-buffer reduce ({args.reduce})") if sharded else "scene-parallel")),
                 "ranks_seen": ranks_seen,
             },
             "max_realtime_sources": value / RATE,

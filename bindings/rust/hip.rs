@@ -74,6 +74,7 @@ extern "C" {
     fn oddio_hip_scene_set_mode(s: *mut RawScene, mode: c_int) -> c_int;
     fn oddio_hip_scene_sample(s: *mut RawScene, interval: f32, out: *mut f32, n_frames: usize) -> c_int;
     fn oddio_hip_scene_reduce_init(s: *mut RawScene, rank: c_int, world: c_int, unique_id: *const c_void, unique_id_bytes: usize) -> c_int;
+    fn oddio_hip_scene_reduce_init_p2p(s: *mut RawScene, rank: c_int, world: c_int, handle: *mut c_void, handle_bytes: usize) -> c_int;
     fn oddio_hip_mixer_create(device: c_int, max_sources: u32, max_frames: u32, out: *mut *mut RawMixer) -> c_int;
     fn oddio_hip_mixer_destroy(m: *mut RawMixer) -> c_int;
     fn oddio_hip_mixer_play_sine(m: *mut RawMixer, phase: f32, frequency_hz: f32, fixed_gain_db: f32, id: *mut u32) -> c_int;
@@ -165,6 +166,11 @@ impl HipSpatialScene {
     /// rank 0 (`oddio_hip_reduce_unique_id`) and handed to the others by the host program.
     pub fn join_reduce(&mut self, rank: i32, world: i32, unique_id: &[u8]) {
         check(unsafe { oddio_hip_scene_reduce_init((self.0).0, rank, world, unique_id.as_ptr() as *const c_void, unique_id.len()) });
+    }
+    /// The same reduction without RCCL, summed in rank order on rank 0 (deterministic; ranks may share a GPU).
+    /// Rank 0 calls it first and hands the filled `handle` (ODDIO_HIP_P2P_HANDLE_BYTES) to the other ranks.
+    pub fn join_reduce_p2p(&mut self, rank: i32, world: i32, handle: &mut [u8]) {
+        check(unsafe { oddio_hip_scene_reduce_init_p2p((self.0).0, rank, world, handle.as_mut_ptr() as *mut c_void, handle.len()) });
     }
 }
 

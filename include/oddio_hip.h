@@ -226,6 +226,16 @@ int oddio_hip_reduce_unique_id(void* unique_id, size_t unique_id_bytes);
 int oddio_hip_scene_reduce_init(oddio_hip_scene* scene, int rank, int world, const void* unique_id,
                                 size_t unique_id_bytes);
 int oddio_hip_scene_reduce_destroy(oddio_hip_scene* scene);
+/* The same reduction WITHOUT RCCL and with a fixed summation order: every peer writes its
+ * 2*n_frames-float partial into a slab in rank 0's device memory (hipIpc: peer-to-peer over xGMI, or the same HBM
+ * when ranks share a GPU), rank 0 adds  ((p0 + p1) + p2) + ...  and every rank copies the mix back -- run-to-run and
+ * rank-count deterministic, and usable with several ranks on ONE device.  One process per rank.
+ *   rank 0:      oddio_hip_scene_reduce_init_p2p(scene, 0, world, handle, ODDIO_HIP_P2P_HANDLE_BYTES)   fills `handle`
+ *   other ranks: oddio_hip_scene_reduce_init_p2p(scene, rank, world, handle, ...)                        with rank 0's bytes
+ * Replaces src/spatial.rs:456-463's sum across the shards like the RCCL variant; a rank that does not show up within
+ * ~2 s makes the next *_sample* call return ODDIO_HIP_ESTATE instead of hanging the device. */
+#define ODDIO_HIP_P2P_HANDLE_BYTES 128
+int oddio_hip_scene_reduce_init_p2p(oddio_hip_scene* scene, int rank, int world, void* handle, size_t handle_bytes);
 /* Block until everything enqueued on the scene's stream has finished. */
 int oddio_hip_scene_synchronize(oddio_hip_scene* scene);
 /* Make the scene enqueue on a caller-owned hipStream_t (e.g. the stream a framework's collectives

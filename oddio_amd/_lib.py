@@ -113,6 +113,7 @@ def lib():
         "oddio_hip_reduce_unique_id": (i32, [vp, sz]),
         "oddio_hip_scene_reduce_init": (i32, [vp, i32, i32, vp, sz]),
         "oddio_hip_scene_reduce_destroy": (i32, [vp]),
+        "oddio_hip_scene_reduce_init_p2p": (i32, [vp, i32, i32, vp, sz]),
         "oddio_hip_scene_stream": (i32, [vp, vpp]),
         "oddio_hip_scene_set_stream": (i32, [vp, vp]),
         "oddio_hip_scene_seek_all": (i32, [vp, f32]),

@@ -397,6 +397,17 @@ class _SceneSignal(Signal):
         buf = C.create_string_buffer(bytes(unique_id), len(unique_id))
         _lib.check(_lib.lib().oddio_hip_scene_reduce_init(self._h, int(rank), int(world), buf, len(unique_id)))
 
+    def reduce_init_p2p(self, rank: int, world: int, handle: bytes | None = None) -> bytes:
+        """Join the deterministic peer-to-peer reduce (include/oddio_hip.h): rank 0 passes no handle and gets the one
+        to hand to the other ranks; they pass rank 0's.  One process per rank."""
+        buf = C.create_string_buffer(P2P_HANDLE_BYTES)
+        if rank != 0:
+            if handle is None or len(handle) != P2P_HANDLE_BYTES:
+                raise ValueError("ranks > 0 need rank 0's handle")
+            buf.raw = handle
+        _lib.check(_lib.lib().oddio_hip_scene_reduce_init_p2p(self._h, int(rank), int(world), buf, P2P_HANDLE_BYTES))
+        return bytes(buf.raw)
+
     def reduce_destroy(self):
         _lib.check(_lib.lib().oddio_hip_scene_reduce_destroy(self._h))
 
@@ -562,6 +573,7 @@ class SpatialSceneControl:
 
 
 UNIQUE_ID_BYTES = 128
+P2P_HANDLE_BYTES = 128
 
 
 def reduce_unique_id() -> bytes:

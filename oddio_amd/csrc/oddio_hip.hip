@@ -5,6 +5,7 @@
 // prologue (src/spatial.rs:376-394).
 #include <hip/hip_runtime.h>
 #include <dlfcn.h>
+#include <unistd.h>
 #include <rccl/rccl.h>   // types only: the functions are resolved with dlopen on first use
 
 #include <algorithm>

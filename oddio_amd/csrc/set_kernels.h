@@ -25,6 +25,7 @@ __device__ __forceinline__ SrcDyn& dyn_common(BufDyn& d) { return d.common; }
 struct SetPublish {
     volatile uint64_t len_and_inserted[2];   // per set (0 seek, 1 buffered): live length | cumulative inserts << 32
     volatile uint32_t removed_total[2];      // per set: entries ever written to its removed-id ring
+    uint32_t reduce_timeouts;                // the P2P reduce gave up waiting for a rank (reported by the next sample call)
 };
 
 template <class S, class D>
@@ -176,6 +177,72 @@ __global__ void apply_control_by_id(const ControlById* __restrict__ up, uint32_t
         if (sl == SLOT_INVALID || !(sl & SLOT_BUFFERED_BIT)) continue;
         bdyn[sl & ~SLOT_BUFFERED_BIT].shared[up[i].index & (MAX_WRAP - 1)] = up[i].value;
     }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Sharded scene, deterministic reduce (SURVEY.md 8e's alternative to the RCCL all-reduce): every peer writes its
+// partial stereo buffer into a slab in rank 0's memory (opened through hipIpc: xGMI peer-to-peer writes, or plain
+// device writes when the ranks share one GPU), rank 0 adds the partials in FIXED rank order
+//     mix = ((p0 + p1) + p2) + ... + p(world-1)
+// and publishes the result, which every peer copies back.  One 8 KiB write, one 8 KiB read per peer and callback.
+// The slab is fine-grained memory; everything that crosses a process goes through system-scope atomics (the
+// per-XCD L2s and a peer's caches are not coherent for plain accesses inside a kernel).
+//   slab layout (floats after the header): [header 256 B: arrived[world] | done][result: stride][partial of rank 1..]
+// Waits are bounded (~2 s): a rank that never arrives must not hang the GPU; *err is set instead.
+// ---------------------------------------------------------------------------------------------------------------
+constexpr uint32_t P2P_HEADER_WORDS = 64;      // 256 bytes: arrived[r] at word r (r < 60), done at word 63
+constexpr uint32_t P2P_MAX_WORLD = 60;
+constexpr unsigned long long P2P_TIMEOUT_TICKS = 200000000ull;   // wall_clock64 ticks of 10 ns: 2 s
+
+__device__ __forceinline__ bool p2p_wait_equal(const uint32_t* flag, uint32_t epoch) {
+    const unsigned long long t0 = wall_clock64();
+    while (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != epoch) {
+        if (wall_clock64() - t0 > P2P_TIMEOUT_TICKS) return false;
+        __builtin_amdgcn_s_sleep(16);
+    }
+    return true;
+}
+
+// peer (rank > 0): partial -> its slab row, then arrived[rank] = epoch.  One block.
+__global__ __launch_bounds__(1024) void p2p_publish(const float* __restrict__ partial, uint32_t* slab, uint32_t stride, uint32_t rank, uint32_t n_out,
+                                                    uint32_t epoch) {
+    float* row = reinterpret_cast<float*>(slab + P2P_HEADER_WORDS) + (size_t)rank * stride;
+    for (uint32_t i = threadIdx.x; i < n_out; i += blockDim.x) __hip_atomic_store(row + i, partial[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_store(slab + rank, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+// rank 0: waits for every peer, adds in rank order (its own partial is `buf`), leaves the mix in `buf` and in the slab's
+// result row, then done = epoch.  One block.
+__global__ __launch_bounds__(1024) void p2p_sum(float* __restrict__ buf, uint32_t* slab, uint32_t stride, uint32_t world, uint32_t n_out, uint32_t epoch,
+                                                uint32_t* __restrict__ err) {
+    __shared__ int ok;
+    if (threadIdx.x == 0) {
+        bool all = true;
+        for (uint32_t r = 1; r < world; ++r) all = p2p_wait_equal(slab + r, epoch) && all;
+        ok = all ? 1 : 0;
+        if (!all) __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    __syncthreads();
+    float* rows = reinterpret_cast<float*>(slab + P2P_HEADER_WORDS);
+    for (uint32_t i = threadIdx.x; i < n_out; i += blockDim.x) {
+        float t = buf[i];
+        for (uint32_t r = 1; r < world; ++r) t = t + __hip_atomic_load(rows + (size_t)r * stride + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        buf[i] = t;
+        __hip_atomic_store(rows + i, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);       // row 0 = the result
+    }
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_store(slab + (P2P_HEADER_WORDS - 1), epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+// peer: waits for done == epoch, copies the mix into its own buffer.  One block.
+__global__ __launch_bounds__(1024) void p2p_fetch(float* __restrict__ buf, const uint32_t* slab, uint32_t n_out, uint32_t epoch, uint32_t* __restrict__ err) {
+    if (threadIdx.x == 0 && !p2p_wait_equal(slab + (P2P_HEADER_WORDS - 1), epoch)) __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __syncthreads();
+    const float* res = reinterpret_cast<const float*>(slab + P2P_HEADER_WORDS);
+    for (uint32_t i = threadIdx.x; i < n_out; i += blockDim.x) buf[i] = __hip_atomic_load(res + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 // Seek::seek on every live source (signal.rs:48-51)

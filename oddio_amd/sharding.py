@@ -59,24 +59,53 @@ def exchange_unique_id(dist=None, src: int = 0) -> bytes:
     return box[0]
 
 
+def exchange_p2p_handle(scene, rank: int, world: int, dist=None, src: int = 0) -> None:
+    """Join the deterministic peer-to-peer reduce (`oddio_hip_scene_reduce_init_p2p`): rank `src` creates the slab and
+    hands its handle to the other ranks over the host program's process group (any backend)."""
+    if dist is None:
+        import torch.distributed as dist
+    if rank == src:
+        handle = scene.reduce_init_p2p(0, world)
+        if dist.is_initialized() and dist.get_world_size() > 1:
+            dist.broadcast_object_list([handle], src=src)
+    else:
+        box = [None]
+        dist.broadcast_object_list(box, src=src)
+        scene.reduce_init_p2p(rank, world, box[0])
+
+
 class ShardedSpatialScene:
     """One logical SpatialScene whose sources are split into contiguous index shards, one per rank.
 
     `play_frames_batch` is called with the rank's OWN shard (`self.shard` = [lo, hi) of the global
-    source index); `sample_device` renders it on the HIP path, the library all-reduces the partial
-    stereo buffers over RCCL on the scene's stream and then applies the scene-level post filter, so
-    every rank ends up with the scene's mix."""
+    source index); `sample_device` renders it on the HIP path, the library sums the partial stereo
+    buffers on the scene's stream -- RCCL all-reduce (`reduce="rccl"`) or the rank-ordered peer-to-peer
+    reduce (`reduce="p2p"`) -- and then applies the scene-level post filter, so every rank ends up with
+    the scene's mix."""
 
     def __init__(self, device: int, n_sources_total: int, max_frames: int, rank: int, world: int, unique_id: bytes | None,
-                 postfx: int = 0):
-        import oddio_amd as oa
+                 postfx: int = 0, reduce: str = "rccl", dist=None, scene_factory=None):
+        """reduce: "rccl" (the library's all-reduce, needs `unique_id`), "p2p" (the library's rank-ordered reduce; the
+        handle travels over `dist`), or "dist" (the partial buffer is reduced by the host program's own
+        torch.distributed group -- any backend -- and the post filter applied afterwards with `postfx_host`; what the
+        gloo tests use).  `scene_factory(max_sources, max_frames) -> (control, scene)` replaces the HIP scene (tests)."""
         self.rank, self.world, self.device = rank, world, device
+        self.reduce, self.dist, self.postfx = reduce, dist, postfx
         self.shard = shard_range(n_sources_total, world, rank)
         lo, hi = self.shard
-        self.control, self.scene = oa.SpatialScene(device=device, max_sources=max(hi - lo, 1), max_frames=max_frames)
+        if scene_factory is None:
+            import oddio_amd as oa
+            self.control, self.scene = oa.SpatialScene(device=device, max_sources=max(hi - lo, 1), max_frames=max_frames)
+        else:
+            self.control, self.scene = scene_factory(max(hi - lo, 1), max_frames)
+        if reduce == "dist":
+            return                        # the scene-level filter follows the cross-rank sum: applied in sample()
         if postfx:
             self.scene.set_postfx(postfx)
-        if unique_id is not None:
+        if reduce == "p2p":
+            # summed in rank order on rank 0 (deterministic; the ranks may share one GPU)
+            exchange_p2p_handle(self.scene, rank, world, dist)
+        elif unique_id is not None:
             self.scene.reduce_init(rank, world, unique_id)
 
     def play_frames_batch(self, frames_list, start_seconds, positions, velocities, radii):
@@ -87,7 +116,25 @@ class ShardedSpatialScene:
                                               np.asarray(radii))
 
     def sample_device(self, interval, dev_ptr: int, n_frames: int):
+        assert self.reduce != "dist", "the host-side reduce works on host buffers: use sample()"
         self.scene.sample_device(interval, dev_ptr, n_frames)
 
     def sample(self, interval, out: np.ndarray):
-        return self.scene.sample(interval, out)
+        out = self.scene.sample(interval, out)
+        if self.reduce == "dist":
+            import torch
+            part = torch.from_numpy(out)
+            reduce_stereo(part, self.dist, dst=None)
+            out[...] = postfx_host(part.numpy(), self.postfx)
+        return out
+
+
+def postfx_host(x: np.ndarray, postfx: int) -> np.ndarray:
+    """The scene-level soft clip on a host buffer, in exact f32 operations: Reinhard `x / (1 + |x|)` (src/reinhard.rs:32),
+    Tanh `tanhf(x)` (src/tanh.rs:26)."""
+    x = np.asarray(x, dtype=np.float32)
+    if postfx == 1:
+        return (x / (np.float32(1.0) + np.abs(x))).astype(np.float32)
+    if postfx == 2:
+        return np.tanh(x).astype(np.float32)
+    return x

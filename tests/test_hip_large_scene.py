@@ -241,22 +241,81 @@ import numpy as np
 sys.path.insert(0, {root!r}); sys.path.insert(0, os.path.join({root!r}, "tests"))
 import torch, torch.distributed as dist
 rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
-torch.cuda.set_device(rank)
+device = rank if {own_gpu} else 0
+torch.cuda.set_device(device)
 os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
 dist.init_process_group("gloo", rank=rank, world_size=world)
 import oddio_amd as oa
 from oddio_amd import sharding, synth
 S, CLIP, N, RATE, START, SEED = 8192, 8192, 1024, 48000, 0.06, 99
-uid = sharding.exchange_unique_id(dist)
-sh = sharding.ShardedSpatialScene(rank, S, N, rank, world, uid, postfx=oa.POSTFX_REINHARD)
+uid = sharding.exchange_unique_id(dist) if {reduce!r} == "rccl" else None
+sh = sharding.ShardedSpatialScene(device, S, N, rank, world, uid, postfx=oa.POSTFX_REINHARD, reduce={reduce!r}, dist=dist)
 lo, hi = sh.shard
 sc = synth.make_scene(SEED, S, cube=10.0)
-frames = [oa.Frames.from_slice(RATE, synth.noise_clip(SEED, i, CLIP), device=rank) for i in range(lo, hi)]
+frames = [oa.Frames.from_slice(RATE, synth.noise_clip(SEED, i, CLIP), device=device) for i in range(lo, hi)]
 sh.play_frames_batch(frames, np.full(hi - lo, START), sc["position"][lo:hi], sc["velocity"][lo:hi], sc["radius"][lo:hi])
 outs = [sh.sample(np.float32(1.0) / np.float32(RATE), np.zeros((N, 2), np.float32)).copy() for _ in range(2)]
 np.save(os.path.join({tmp!r}, f"rank{{rank}}.npy"), np.stack(outs))
 dist.barrier(); dist.destroy_process_group()
 """
+
+
+def _run_sharded_workers(tmp_path, world, own_gpu, reduce):
+    script = tmp_path / "worker.py"
+    script.write_text(_WORKER.format(root=ROOT, tmp=str(tmp_path), own_gpu=own_gpu, reduce=reduce))
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    procs = [subprocess.Popen([sys.executable, str(script)],
+                              env=dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                                       HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0")))
+             for r in range(world)]
+    assert [p.wait(timeout=600) for p in procs] == [0] * world
+    return [np.load(tmp_path / f"rank{r}.npy") for r in range(world)]
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_scene_p2p_reduce_ranks_share_one_gpu(tmp_path, world):
+    """One seeded scene in `world` contiguous index shards, one PROCESS per rank, all on device 0, through the library's
+    deterministic peer-to-peer reduce (rank-ordered sum on rank 0) -- against the same scene unsharded on the HIP path,
+    and against the rank-ordered sum of separately rendered shards (bit for bit: the reduce is that sum)."""
+    import oddio_amd as oa
+    from oddio_amd.sharding import shard_range
+    S, CLIP2, SEED2 = 8192, 8192, 99
+    got = _run_sharded_workers(tmp_path, world, own_gpu=False, reduce="p2p")
+    for r in range(1, world):
+        np.testing.assert_array_equal(got[0], got[r])        # every rank holds the mix
+    sc = synth.make_scene(SEED2, S, cube=10.0)
+
+    def render(lo, hi, postfx):
+        control, scene = oa.SpatialScene(device=0, max_sources=hi - lo, max_frames=N)
+        if postfx:
+            scene.set_postfx(postfx)
+        frames = [oa.Frames.from_slice(RATE, synth.noise_clip(SEED2, i, CLIP2), device=0) for i in range(lo, hi)]
+        control.play_frames_batch(frames, np.full(hi - lo, START), sc["position"][lo:hi], sc["velocity"][lo:hi], sc["radius"][lo:hi])
+        return [scene.sample_n(INTERVAL, N).copy() for _ in range(2)]
+    whole = render(0, S, oa.POSTFX_REINHARD)
+    parts = [render(*shard_range(S, world, r), 0) for r in range(world)]
+    for cb in range(2):
+        assert np.abs(got[0][cb] - whole[cb]).max() <= 2e-6 * np.abs(whole[cb]).max()
+        total = parts[0][cb].copy()
+        for r in range(1, world):
+            total = total + parts[r][cb]                      # ((p0 + p1) + p2): the reduce's order
+        expect = (total / (np.float32(1.0) + np.abs(total))).astype(np.float32)   # Reinhard after the sum (reinhard.rs:32)
+        np.testing.assert_array_equal(got[0][cb], expect)
+
+
+def test_bench_self_launch_two_ranks_sharded():
+    """`python bench.py --gpus 2 --mode sharded --reduce p2p`: the sharded bench path end to end on ONE device."""
+    import json
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--share-devices", "--mode", "sharded", "--reduce", "p2p",
+                        "--sources", "4096", "--clip-len", "65536", "--steps", "4", "--warmup", "2", "--no-cpu-baseline"],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["ranks_seen"] == 2 and d["value"] > 0
+    assert "p2p" in d["config"]["parallelism"]
 
 
 def test_sharded_scene_two_gpus_rccl(tmp_path):
@@ -267,14 +326,7 @@ def test_sharded_scene_two_gpus_rccl(tmp_path):
     import oddio_amd as oa
     S, CLIP2, SEED2 = 8192, 8192, 99
     script = tmp_path / "worker.py"
-    script.write_text(_WORKER.format(root=ROOT, tmp=str(tmp_path)))
-    import socket
-    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
-    procs = [subprocess.Popen([sys.executable, str(script)],
-                              env=dict(os.environ, RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port)))
-             for r in range(2)]
-    assert [p.wait(timeout=600) for p in procs] == [0, 0]
-    got = [np.load(tmp_path / f"rank{r}.npy") for r in range(2)]
+    got = _run_sharded_workers(tmp_path, 2, own_gpu=True, reduce="rccl")
     np.testing.assert_array_equal(got[0], got[1])            # all-reduce: every rank holds the mix
     control, scene = oa.SpatialScene(device=0, max_sources=S, max_frames=N)
     scene.set_postfx(oa.POSTFX_REINHARD)

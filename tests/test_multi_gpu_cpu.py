@@ -59,6 +59,78 @@ def _worker(rank, world, port, seed, n_src, n_frames, n_cb, postfx, q):
     dist.destroy_process_group()
 
 
+class _OracleScene:
+    """Stand-in for the HIP scene behind ShardedSpatialScene on a box without a GPU: same control / sample surface,
+    rendered by the oracle."""
+
+    def __init__(self, ob):
+        self.ob = ob
+
+    def play_frames_batch(self, frames_list, start_seconds, positions, velocities, radii):
+        for f, st, p, v, r in zip(frames_list, start_seconds, positions, velocities, radii):
+            self.ob.play({"kind": "frames", "clip": f["clip"], "rate": f["rate"], "start": float(st), "pos": p, "vel": v, "radius": float(r), "gain_db": None})
+        return list(range(len(frames_list)))
+
+    def sample(self, interval, out):
+        out[...] = self.ob.sample(interval, out.shape[0])
+        return out
+
+
+def _sharded_worker(rank, world, port, seed, n_src, n_frames, n_cb, postfx, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import torch.distributed as dist
+
+    import scenario
+    from oddio_amd import sharding
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    spec = scenario.random_spec(seed, n_src, clip_len=9000, cube=10.0, start=0.06, kinds=("frames",), gain_db=(None,))
+
+    def factory(max_sources, max_frames):
+        sc = _OracleScene(scenario.OracleBackend())
+        return sc, sc
+    sh = sharding.ShardedSpatialScene(0, n_src, n_frames, rank, world, None, postfx=postfx, reduce="dist", dist=dist, scene_factory=factory)
+    lo, hi = sh.shard
+    src = spec["sources"][lo:hi]
+    sh.play_frames_batch([{"clip": s_["clip"], "rate": s_["rate"]} for s_ in src], [s_["start"] for s_ in src],
+                         [s_["pos"] for s_ in src], [s_["vel"] for s_ in src], [s_["radius"] for s_ in src])
+    interval = np.float32(1.0) / np.float32(48000)
+    outs = [sh.sample(interval, np.zeros((n_frames, 2), np.float32)).copy() for _ in range(n_cb)]
+    q.put((rank, lo, hi, np.stack(outs)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,n_src,postfx", [(2, 11, 1), (2, 1, 0)])
+def test_sharded_spatial_scene_control_flow_gloo(world, n_src, postfx):
+    """ShardedSpatialScene itself (shard bookkeeping, play_frames_batch of the rank's shard, sample + cross-rank sum +
+    post filter AFTER the sum), world 2 over gloo; the renderer behind it is the oracle (no GPU here)."""
+    import torch.multiprocessing as mp
+
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import scenario
+    seed, n_frames, n_cb = 78, 1024, 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_sharded_worker, args=(r, world, port, seed, n_src, n_frames, n_cb, postfx, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = sorted([q.get(timeout=120) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    spec = scenario.random_spec(seed, n_src, clip_len=9000, cube=10.0, start=0.06, kinds=("frames",), gain_db=(None,))
+    ob = scenario.play_all(scenario.OracleBackend(), spec)
+    interval = np.float32(1.0) / np.float32(48000)
+    ref = np.stack([apply_postfx_numpy(ob.sample(interval, n_frames).copy(), postfx) for _ in range(n_cb)])
+    np.testing.assert_array_equal(results[0][3], results[1][3])
+    assert np.abs(results[0][3] - ref).max() <= 1e-5 * max(np.abs(ref).max(), 1e-30)
+
+
 @pytest.mark.parametrize("world,n_src,postfx", [(2, 13, 0), (2, 8, 1)])
 def test_sharded_scene_reduce_gloo(world, n_src, postfx):
     import torch.multiprocessing as mp
