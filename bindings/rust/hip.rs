@@ -76,6 +76,7 @@ extern "C" {
     fn oddio_hip_scene_reduce_init(s: *mut RawScene, rank: c_int, world: c_int, unique_id: *const c_void, unique_id_bytes: usize) -> c_int;
     fn oddio_hip_scene_reduce_init_p2p(s: *mut RawScene, rank: c_int, world: c_int, handle: *mut c_void, handle_bytes: usize) -> c_int;
     fn oddio_hip_mixer_create(device: c_int, max_sources: u32, max_frames: u32, out: *mut *mut RawMixer) -> c_int;
+    fn oddio_hip_mixer_create_mono(device: c_int, max_sources: u32, max_frames: u32, out: *mut *mut RawMixer) -> c_int;
     fn oddio_hip_mixer_destroy(m: *mut RawMixer) -> c_int;
     fn oddio_hip_mixer_play_sine(m: *mut RawMixer, phase: f32, frequency_hz: f32, fixed_gain_db: f32, id: *mut u32) -> c_int;
     fn oddio_hip_mixer_play_frames(m: *mut RawMixer, f: *mut RawFrames, start_seconds: f64, fixed_gain_db: f32, id: *mut u32) -> c_int;
@@ -308,6 +309,25 @@ impl Signal for HipMixer {
     fn sample(&mut self, interval: f32, out: &mut [[Sample; 2]]) {
         // src/mixer.rs:92-119
         check(unsafe { oddio_hip_mixer_sample((self.0).0, interval, out.as_mut_ptr() as *mut f32, out.len()) });
+    }
+}
+
+/// Drop-in for `Mixer<f32>` (src/mixer.rs:46-81 with `impl Frame for f32`, src/frame.rs:53-61): mono signals only; the
+/// control half is the same `HipMixerControl` (its stereo-clip plays are refused by the library).
+pub struct HipMonoMixer(Arc<MixerHandle>);
+impl HipMonoMixer {
+    pub fn new(device: i32, max_sources: u32, max_frames: u32) -> (HipMixerControl, Self) {
+        let mut h = std::ptr::null_mut();
+        check(unsafe { oddio_hip_mixer_create_mono(device, max_sources, max_frames, &mut h) });
+        let h = Arc::new(MixerHandle(h));
+        (HipMixerControl(h.clone()), Self(h))
+    }
+}
+impl Signal for HipMonoMixer {
+    type Frame = Sample;
+    fn sample(&mut self, interval: f32, out: &mut [Sample]) {
+        // src/mixer.rs:92-119 with T = f32
+        check(unsafe { oddio_hip_mixer_sample((self.0).0, interval, out.as_mut_ptr(), out.len()) });
     }
 }
 impl HipMixerControl {

@@ -58,7 +58,7 @@ enum { /* oddio_hip_scene_set_mode */
 
 typedef struct oddio_hip_frames oddio_hip_frames; /* == Arc<Frames<f32>>, src/frames.rs:19-22 */
 typedef struct oddio_hip_scene oddio_hip_scene;   /* == SpatialScene + SpatialSceneControl */
-typedef struct oddio_hip_mixer oddio_hip_mixer;   /* == Mixer<[f32;2]> + MixerControl */
+typedef struct oddio_hip_mixer oddio_hip_mixer;   /* == Mixer<[f32;2]> or Mixer<f32>, + MixerControl */
 
 /* ---- library ---- */
 int oddio_hip_abi_version(void);
@@ -307,6 +307,11 @@ int oddio_hip_scene_play_buffered_stream(oddio_hip_scene* scene, oddio_hip_strea
 /* ---- Mixer<[f32;2]> (src/mixer.rs:70-81 `Mixer::new`) ---- */
 int oddio_hip_mixer_create(int device, uint32_t max_sources, uint32_t max_frames,
                            oddio_hip_mixer** out);
+/* Mixer<f32> (src/mixer.rs:46-81 is generic over `T: Frame`; `impl Frame for f32`, src/frame.rs:53-61): plays mono
+ * signals only (a clip / stream with two channels is ODDIO_HIP_EINVAL: the reference's type system rules it out), and
+ * *_sample / *_run write n_frames floats.  Everything else as for the stereo mixer. */
+int oddio_hip_mixer_create_mono(int device, uint32_t max_sources, uint32_t max_frames,
+                                oddio_hip_mixer** out);
 int oddio_hip_mixer_destroy(oddio_hip_mixer* mixer);
 /* MixerControl::play (src/mixer.rs:18-26) of MonoToStereo::new(inner) (src/signal.rs:61-91) with
  * inner = Sine / FramesSignal (optionally FixedGain-wrapped) / Constant, as above. */

@@ -123,6 +123,7 @@ def lib():
         "oddio_hip_scene_set_motion_batch": (i32, [vp, sz, u32p, fp, fp, i32]),
         "oddio_hip_debug_mix_occupancy": (i32, [i32, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]),
         "oddio_hip_mixer_create": (i32, [i32, u32, u32, vpp]),
+        "oddio_hip_mixer_create_mono": (i32, [i32, u32, u32, vpp]),
         "oddio_hip_mixer_destroy": (i32, [vp]),
         "oddio_hip_mixer_play_sine": (i32, [vp, f32, f32, f32, u32p]),
         "oddio_hip_mixer_play_frames": (i32, [vp, vp, f64, f32, u32p]),

@@ -174,8 +174,12 @@ class GainControl:
         self._target = None      # (scene or None, source id, filter index)
         self._ratio = np.float32(1.0)
 
-    def _bind(self, scene, sid, index):
+    def _bind(self, scene, sid, index, handle=None):
+        # `handle`: the Mixed / Spatial object of the source -- kept alive by its controls, so that the handle id is
+        # released (and may change owner) only once the handle AND every control of the signal are gone, like the Arc
+        # a GainControl holds on its signal's shared state in the reference
         self._target = (scene, sid, index)
+        self._handle = handle
 
     def set_amplitude_ratio(self, factor):
         self._ratio = np.float32(factor)
@@ -198,8 +202,9 @@ class SpeedControl:
         self._target = None
         self._speed = np.float32(1.0)
 
-    def _bind(self, scene, sid, index):
+    def _bind(self, scene, sid, index, handle=None):
         self._target = (scene, sid, index)
+        self._handle = handle          # see GainControl._bind
 
     def set_speed(self, factor):
         self._speed = np.float32(factor)
@@ -532,10 +537,11 @@ class SpatialSceneControl:
             _lib.check(L.oddio_hip_scene_play_buffered(s._h, args[0], args[1], args[2], args[3], args[4], C.cast(filt, C.c_void_p), len(chain),
                                                        _fp(pos), _fp(vel), np.float32(options.radius), np.float32(max_distance), int(rate),
                                                        np.float32(buffer_duration), C.byref(sid)))
+        spatial = Spatial(s, sid.value)
         for i, (_, _, control) in enumerate(chain):
             if control is not None:
-                control._bind(s, sid.value, i)
-        return Spatial(s, sid.value)
+                control._bind(s, sid.value, i, spatial)
+        return spatial
 
     def play_frames_batch(self, frames_list, start_seconds, positions, velocities, radii, fixed_gain_db=None):
         """Bulk `play(FramesSignal::new(frames[i], start[i]), SpatialOptions{..})` for large scenes."""
@@ -675,12 +681,14 @@ class Mixed:
 
 
 class _MixerSignal(Signal):
-    channels = 2
     seekable = False
 
-    def __init__(self, device, max_sources, max_frames):
+    def __init__(self, device, max_sources, max_frames, channels=2):
+        assert channels in (1, 2), "Mixer<f32> or Mixer<[f32; 2]>"
+        self.channels = channels
         self._h = C.c_void_p()
-        _lib.check(_lib.lib().oddio_hip_mixer_create(device, int(max_sources), int(max_frames), C.byref(self._h)))
+        create = _lib.lib().oddio_hip_mixer_create if channels == 2 else _lib.lib().oddio_hip_mixer_create_mono
+        _lib.check(create(device, int(max_sources), int(max_frames), C.byref(self._h)))
         self._keep = []
 
     def sample(self, interval, out):
@@ -689,7 +697,7 @@ class _MixerSignal(Signal):
         return out
 
     def sample_n(self, interval, n):
-        return self.sample(interval, np.zeros((n, 2), dtype=np.float32))
+        return self.sample(interval, np.zeros((n, 2) if self.channels == 2 else (n,), dtype=np.float32))
 
     def is_finished(self):
         return False
@@ -722,14 +730,13 @@ class _MixerSignal(Signal):
 
 
 class MixerControl:
-    """src/mixer.rs:7-27 for Mixer<[f32;2]>"""
+    """src/mixer.rs:7-27 for Mixer<[f32;2]> and Mixer<f32>"""
 
     def __init__(self, mixer):
         self._m = mixer
 
-    @staticmethod
-    def _parse(signal):
-        """-> (leaf, [(kind, param, control)] innermost first) for a stereo-output nest"""
+    def _parse(self, signal):
+        """-> (leaf, [(kind, param, control)] innermost first) for a nest whose output is the mixer's frame type"""
         chain, stereo_seen, sig = [], False, signal
         while isinstance(sig, (FixedGain, Gain, Speed, MonoToStereo)):
             if isinstance(sig, MonoToStereo):
@@ -746,7 +753,10 @@ class MixerControl:
         if not isinstance(sig, (FramesSignal, Sine, Constant, Cycle, Stream)):
             raise TypeError(f"{type(sig).__name__} is not implemented on the device path")
         leaf_channels = getattr(sig, "channels", 1)
-        if (leaf_channels == 1) != stereo_seen:
+        if self._m.channels == 1:
+            if stereo_seen or leaf_channels != 1:
+                raise TypeError("this is a Mixer<f32>: it plays Signal<Frame = f32> (no MonoToStereo, no stereo clips)")
+        elif (leaf_channels == 1) != stereo_seen:
             raise TypeError("the device Mixer is Mixer<[f32;2]>: mono signals need MonoToStereo::new, stereo clips must not have it")
         chain = chain[::-1]
         if len(chain) > 4:
@@ -778,10 +788,11 @@ class MixerControl:
             else:
                 args = _leaf_args(sig, m._keep)
                 _lib.check(L.oddio_hip_mixer_play_chain(m._h, args[0], args[1], args[2], args[3], args[4], C.cast(filt, C.c_void_p), len(chain), C.byref(sid)))
+        mixed = Mixed(m, sid.value)
         for i, (_, _, control) in enumerate(chain):
             if control is not None:
-                control._bind(m, sid.value, i)
-        return Mixed(m, sid.value)
+                control._bind(m, sid.value, i, mixed)
+        return mixed
 
 
 class FaderControl:
@@ -835,9 +846,10 @@ class Fader(Signal):
         return f.control, f
 
 
-def Mixer(device: int = 0, max_sources: int = 4096, max_frames: int = 4096):
-    """Mixer::new() -> (MixerControl, Mixer)  (src/mixer.rs:70-81)."""
-    m = _MixerSignal(device, max_sources, max_frames)
+def Mixer(device: int = 0, max_sources: int = 4096, max_frames: int = 4096, channels: int = 2):
+    """Mixer::new() -> (MixerControl, Mixer)  (src/mixer.rs:70-81); `channels` selects the frame type T = f32 or [f32; 2]
+    (a Mixer<f32> plays mono signals and fills `out` with n_frames floats)."""
+    m = _MixerSignal(device, max_sources, max_frames, channels)
     return MixerControl(m), m
 
 

@@ -3,13 +3,12 @@
 // filters that are not `Seek` and therefore only enter a scene this way: `Gain` (+ `Smoothed`,
 // src/gain.rs:58-127, src/smooth.rs) and `Speed` (src/speed.rs:26-40), besides `FixedGain`.
 //
-// Correctness first, not tuned: ONE THREAD PER BUFFERED SOURCE replays the reference's sequential
-// loops (ring write through the filter chain, then per ear / per 256-frame chunk ring reads with
-// the f32 cursor and its wrap rule) and writes the source's contribution to its own [N][2] slab;
-// `buffered_reduce` then adds the slabs in the reference's reverse-slot order, so the result is
-// bit-identical to the reference's `o[ear] += s * gain` sequence for FramesSignal/Constant leaves.
-// Thousands of buffered sources still run concurrently (one per lane); the latency of one source
-// (~50 k dependent instructions) is the cost.
+// Every source writes its contribution to its own [N][2] slab (ring write through the filter chain, then per ear /
+// per 256-frame chunk ring reads with the f32 cursor and its wrap rule); `buffered_reduce` then adds the slabs in the
+// reference's reverse-slot order, so the result is bit-identical to the reference's `o[ear] += s * gain` sequence for
+// FramesSignal/Constant leaves.  `buffered_sources_wave` renders the common shapes one WAVE per source (scanner lanes
+// replay the exact f32 running sums, 64 lanes expand them); `buffered_sources` is the one-thread-per-source form of the
+// same loops for the remaining shapes (Fader, Stream, stereo leaves).
 #pragma once
 #include "kernels.h"
 
@@ -718,19 +717,14 @@ __global__ void buffered_reduce_finish(const float* __restrict__ part, uint32_t 
     out_b[o] = s;
 }
 
-// one thread, send order: a later value for the same (slot, filter) wins, like the relaxed atomic stores
-__global__ void apply_control_updates_serial(const ControlUpdate* __restrict__ up, uint32_t n, BufDyn* __restrict__ dyn) {
-    for (uint32_t i = 0; i < n; ++i) dyn[up[i].slot].shared[up[i].index & (MAX_WRAP - 1)] = up[i].value;
+// GainControl / SpeedControl stores by slot: one thread per update.  The host keeps only the LAST value per (slot, filter)
+// of a callback (relaxed "latest value" stores, gain.rs:158-160), so the updates are independent.
+__global__ void apply_control_updates(const ControlUpdate* __restrict__ up, uint32_t n, BufDyn* __restrict__ dyn) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dyn[up[i].slot].shared[up[i].index & (MAX_WRAP - 1)] = up[i].value;
 }
 
 struct BufMove { uint32_t dst, src; };
-__global__ void apply_buf_moves(const BufMove* __restrict__ mv, uint32_t n, BufStatic* st, BufDyn* dyn, SrcPending* pend) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    st[mv[i].dst] = st[mv[i].src];
-    dyn[mv[i].dst] = dyn[mv[i].src];
-    pend[mv[i].dst] = pend[mv[i].src];
-}
 
 // The generation each Fader is playing, for the control thread (pinned host memory): clips handed over by
 // older fade_to commands can be released (the reference drops a retired signal at the next fade_to).

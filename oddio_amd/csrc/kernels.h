@@ -1438,6 +1438,8 @@ __global__ void postfx_kernel(float* __restrict__ buf, uint32_t n, int postfx) {
 struct AdaptParams { float alpha, one_minus_alpha, max_gain, low, high; };
 constexpr int ADAPT_CHUNK = 2048;
 
+// CHANNELS: the frame type of the signal Adapt wraps -- [f32; 2] (scenes, stereo mixers) or f32 (Mixer<f32>)
+template <int CHANNELS>
 __global__ __launch_bounds__(256) void adapt_kernel(float* __restrict__ buf, uint32_t n_frames, AdaptParams A,
                                                     float* __restrict__ avg_squared, int postfx) {
     __shared__ __attribute__((aligned(16))) float drive[ADAPT_CHUNK];
@@ -1446,10 +1448,9 @@ __global__ __launch_bounds__(256) void adapt_kernel(float* __restrict__ buf, uin
     for (uint32_t base = 0; base < n_frames; base += ADAPT_CHUNK) {
         const uint32_t cnt = (n_frames - base) < (uint32_t)ADAPT_CHUNK ? (n_frames - base) : (uint32_t)ADAPT_CHUNK;
         for (uint32_t i = tid; i < cnt; i += 256) {
-            const float2 x = reinterpret_cast<const float2*>(buf)[base + i];
             float sample = 0.0f;                              // x.channels().iter().sum::<f32>()
-            sample = sample + x.x;
-            sample = sample + x.y;
+#pragma unroll
+            for (int c = 0; c < CHANNELS; ++c) sample = sample + buf[(size_t)(base + i) * CHANNELS + c];
             drive[i] = sample * sample * A.alpha;
         }
         __syncthreads();
@@ -1472,14 +1473,22 @@ __global__ __launch_bounds__(256) void adapt_kernel(float* __restrict__ buf, uin
             float gain = 1.0f;
             if (avg_peak < A.low) gain = fminf(A.low / avg_peak, A.max_gain);   // f32::min: NaN-ignoring
             else if (avg_peak > A.high) gain = A.high / avg_peak;
-            float2 x = reinterpret_cast<float2*>(buf)[base + i];
-            x.x = postfx_apply(x.x * gain, postfx);
-            x.y = postfx_apply(x.y * gain, postfx);
-            reinterpret_cast<float2*>(buf)[base + i] = x;
+#pragma unroll
+            for (int c = 0; c < CHANNELS; ++c) {
+                float* x = buf + (size_t)(base + i) * CHANNELS + c;
+                *x = postfx_apply(*x * gain, postfx);
+            }
         }
         __syncthreads();
     }
     if (tid == 0) *avg_squared = avg;
+}
+
+// Mixer<f32>: the mono mix is the left channel of the stereo pipeline's (a mono source duplicated by the implicit
+// MonoToStereo adds the same value to both channels, signal.rs:73-80)
+__global__ void take_left_kernel(const float* __restrict__ stereo, float* __restrict__ mono, uint32_t n_frames) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_frames) mono[i] = stereo[2 * i];
 }
 
 __global__ void zero_kernel(float* __restrict__ buf, uint32_t n) {

@@ -313,14 +313,15 @@ static int adapt_configure(AdaptHost& a, int device, hipStream_t stream, int ena
     return 0;
 }
 
-// Launches the epilogue on `buf` (interleaved stereo, raw sum) and applies `postfx` after it.
-static int adapt_launch(const AdaptHost& a, hipStream_t stream, float interval, float* buf, size_t n_frames, int postfx) {
+// Launches the epilogue on `buf` (interleaved stereo, or mono frames with channels == 1; raw sum) and applies `postfx` after it.
+static int adapt_launch(const AdaptHost& a, hipStream_t stream, float interval, float* buf, size_t n_frames, int postfx, int channels = 2) {
     if (n_frames == 0) return 0;
     AdaptParams A;
     A.alpha = 1.0f - expf(-interval / a.tau);                                                   // adapt.rs:70
     A.one_minus_alpha = 1.0f - A.alpha;
     A.max_gain = a.max_gain; A.low = a.low; A.high = a.high;
-    hipLaunchKernelGGL(adapt_kernel, dim3(1), dim3(256), 0, stream, buf, (uint32_t)n_frames, A, a.d_state, postfx);
+    if (channels == 1) hipLaunchKernelGGL(adapt_kernel<1>, dim3(1), dim3(256), 0, stream, buf, (uint32_t)n_frames, A, a.d_state, postfx);
+    else hipLaunchKernelGGL(adapt_kernel<2>, dim3(1), dim3(256), 0, stream, buf, (uint32_t)n_frames, A, a.d_state, postfx);
     HIP_TRY(hipGetLastError());
     return 0;
 }

@@ -167,16 +167,18 @@ __global__ void apply_motion_by_id(const MotionById* __restrict__ up, uint32_t n
     if (sl & SLOT_BUFFERED_BIT) pend_b[sl & ~SLOT_BUFFERED_BIT] = p; else pend[sl] = p;
 }
 
-// GainControl / SpeedControl values by handle id; one thread, send order (a later value wins)
+// GainControl / SpeedControl values by handle id: one thread per update (the host has kept only the last value per
+// (id, filter) of the callback, so they are independent)
 struct ControlById { uint32_t id; uint32_t index; float value; uint32_t pad; };
 __global__ void apply_control_by_id(const ControlById* __restrict__ up, uint32_t n, const uint32_t* __restrict__ slot_of_id,
                                     BufDyn* __restrict__ bdyn) {
-    for (uint32_t i = 0; i < n; ++i) {
-        if (up[i].id == 0xffffffffu) continue;             // sent for the id's previous owner
-        const uint32_t sl = slot_of_id[up[i].id];
-        if (sl == SLOT_INVALID || !(sl & SLOT_BUFFERED_BIT)) continue;
-        bdyn[sl & ~SLOT_BUFFERED_BIT].shared[up[i].index & (MAX_WRAP - 1)] = up[i].value;
-    }
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const ControlById u = up[i];
+    if (u.id == 0xffffffffu) return;                        // sent for the id's previous owner
+    const uint32_t sl = slot_of_id[u.id];
+    if (sl == SLOT_INVALID || !(sl & SLOT_BUFFERED_BIT)) return;
+    bdyn[sl & ~SLOT_BUFFERED_BIT].shared[u.index & (MAX_WRAP - 1)] = u.value;
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -217,11 +219,9 @@ __global__ __launch_bounds__(1024) void p2p_publish(const float* __restrict__ pa
 // result row, then done = epoch.  One block.
 __global__ __launch_bounds__(1024) void p2p_sum(float* __restrict__ buf, uint32_t* slab, uint32_t stride, uint32_t world, uint32_t n_out, uint32_t epoch,
                                                 uint32_t* __restrict__ err) {
-    __shared__ int ok;
     if (threadIdx.x == 0) {
         bool all = true;
         for (uint32_t r = 1; r < world; ++r) all = p2p_wait_equal(slab + r, epoch) && all;
-        ok = all ? 1 : 0;
         if (!all) __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
     __syncthreads();
@@ -253,8 +253,5 @@ __global__ void seek_all_live(SrcDyn* __restrict__ dyn, const SrcStatic* __restr
     else if (st[i].kind == KIND_SINE) dyn[i].phase = fmodf(dyn[i].phase + seconds * st[i].freq_or_value, ODDIO_TAU);
     else if (st[i].kind == KIND_CYCLE) dyn[i].t = f64_rem_euclid(dyn[i].t + (double)seconds * (double)st[i].clip_rate, (double)st[i].clip_len);
 }
-
-// FaderControl::fade_to: the flushed command of one Fader (swap.rs keeps the latest)
-__global__ void apply_fade(const FaderPending* __restrict__ cmd, FaderRec* __restrict__ rec) { rec->pend = *cmd; }
 
 }  // namespace oddio_hip

@@ -230,3 +230,151 @@ def test_mixer_general_many_sources(mode):
         assert len(mixer) == len(cm)
     assert len(cm) < 303      # some clips ended inside the run
     mixer.close()
+
+
+@pytest.mark.parametrize("mode,n_frames", [(1, 1024), (1, 700), (0, 1024)])
+def test_mono_mixer_is_mixer_f32(mode, n_frames):
+    """Mixer<f32> (mixer.rs:46-81 with `impl Frame for f32`): mono signals, n_frames floats out; Reinhard after it.
+    ORDERED: bit-exact vs the oracle's Mixer(channels=1); FAST: only the sum order differs."""
+    import oddio_amd as oa
+    control, mixer = oa.Mixer(max_sources=256, max_frames=2048, channels=1)
+    mixer.set_mode(mode)
+    mixer.set_postfx(oa.POSTFX_REINHARD)
+    cm = oc.Mixer(1)
+    top = oc.Reinhard(cm)
+    hs, hc = [], []
+    for i in range(120):
+        clip = synth.noise_clip(31, i, 3000 + 41 * i)
+        rate = (48000, 44100, 22050)[i % 3]
+        if i % 5 == 0:
+            hs.append(control.play(oa.FixedGain(oa.FramesSignal(oa.Frames.from_slice(rate, clip), 0.0), -4.0)))
+            hc.append(cm.play(oc.FixedGain(oc.FramesSignal(oc.Frames(rate, clip), 0.0), -4.0)))
+        else:
+            hs.append(control.play(oa.FramesSignal(oa.Frames.from_slice(rate, clip), 0.0)))
+            hc.append(cm.play(oc.FramesSignal(oc.Frames(rate, clip), 0.0)))
+    control.play(oa.Constant(0.25)); cm.play(oc.Constant(0.25))
+    interval = np.float32(1.0) / np.float32(48000)
+    for cb in range(5):
+        if cb == 2:
+            hs[7].stop(); hc[7].stop()
+        got = mixer.sample_n(interval, n_frames)
+        ref = top.sample_n(interval, n_frames)
+        assert got.shape == (n_frames,) and ref.shape == (n_frames,)
+        if mode == 1:
+            np.testing.assert_array_equal(got, ref, err_msg=f"callback {cb}")
+        else:
+            assert np.abs(got - ref).max() <= 1e-5 * np.abs(ref).max()
+        assert len(mixer) == len(cm)
+    mixer.close()
+
+
+def test_mono_mixer_with_filters_and_adapt():
+    """Gain / Speed chains and Adapt's channel sum over ONE channel (adapt.rs:71) in a Mixer<f32>."""
+    import oddio_amd as oa
+    control, mixer = oa.Mixer(max_sources=64, max_frames=1024, channels=1)
+    mixer.set_mode(oa.MODE_ORDERED)
+    mixer.set_adapt(True, initial_rms=0.1, options=oa.AdaptOptions(tau=0.05, max_gain=10.0, low=0.1, high=0.5))
+    cm = oc.Mixer(1)
+    top = oc.Adapt(cm, 0.1, oc.AdaptOptions(tau=0.05, max_gain=10.0, low=0.1, high=0.5))
+    ctl = []
+    for i in range(20):
+        clip = synth.noise_clip(33, i, 9000)
+        gh, sig = oa.Gain.new(oa.FramesSignal(oa.Frames.from_slice(48000, clip), 0.0))
+        og = oc.Gain(oc.FramesSignal(oc.Frames(48000, clip), 0.0))
+        ctl.append((gh, og))
+        control.play(sig); cm.play(og)
+    interval = np.float32(1.0) / np.float32(48000)
+    for cb in range(4):
+        if cb == 1:
+            for gh, og in ctl[::3]:
+                gh.set_amplitude_ratio(0.4); og.set_amplitude_ratio(0.4)
+        np.testing.assert_array_equal(mixer.sample_n(interval, 1024), top.sample_n(interval, 1024), err_msg=f"callback {cb}")
+    mixer.close()
+
+
+def test_mono_mixer_refuses_stereo_signals():
+    import oddio_amd as oa
+    control, mixer = oa.Mixer(max_sources=4, max_frames=64, channels=1)
+    stereo = np.stack([synth.noise_clip(1, 0, 100), synth.noise_clip(1, 1, 100)], axis=1)
+    with pytest.raises(TypeError):
+        control.play(oa.FramesSignal(oa.Frames.from_slice(48000, stereo), 0.0))
+    with pytest.raises(TypeError):
+        control.play(oa.MonoToStereo(oa.Sine(0.0, 440.0)))
+    mixer.close()
+
+
+def test_stop_of_a_finished_source_does_not_reach_the_next_owner_of_its_id():
+    """Advisor finding: play, finish, stop (a second, idempotent stop), drop the handle, play again -- the new source is
+    handed the recycled id and must NOT inherit the stop.  Same for a value sent to a Gain of the old source."""
+    import oddio_amd as oa
+    control, mixer = oa.Mixer(max_sources=8, max_frames=64)
+    cm = oc.Mixer(2)
+    interval = np.float32(1.0) / np.float32(48000)
+    gh, sig = oa.Gain.new(oa.MonoToStereo(oa.FramesSignal(oa.Frames.from_slice(48000, synth.noise_clip(2, 0, 40)), 0.0)))
+    old = control.play(sig)
+    oold = cm.play(oc.Gain(oc.MonoToStereo(oc.FramesSignal(oc.Frames(48000, synth.noise_clip(2, 0, 40)), 0.0))))
+    for _ in range(3):                       # 40 samples: finished and removed within three 32-frame callbacks
+        np.testing.assert_array_equal(mixer.sample_n(interval, 32), cm.sample_n(interval, 32))
+    assert old.is_stopped() and oold.is_stopped() and len(mixer) == 0
+    old.stop()                               # harmless in the reference (mixer.rs:34-37)
+    gh.set_amplitude_ratio(0.0)              # a GainControl that outlived its signal
+    old_id = old.id
+    del old, gh, sig                         # the handle id is released once the Mixed AND its controls are gone
+    import gc
+    gc.collect()
+    gh2, sig2 = oa.Gain.new(oa.MonoToStereo(oa.FramesSignal(oa.Frames.from_slice(48000, synth.noise_clip(2, 1, 4000)), 0.0)))
+    new = control.play(sig2)
+    og2 = oc.Gain(oc.MonoToStereo(oc.FramesSignal(oc.Frames(48000, synth.noise_clip(2, 1, 4000)), 0.0)))
+    cm.play(og2)
+    assert new.id == old_id                  # the id was recycled: the case under test
+    for _ in range(4):
+        got, ref = mixer.sample_n(interval, 64), cm.sample_n(interval, 64)
+        np.testing.assert_array_equal(got, ref)
+        assert np.abs(ref).max() > 0
+    assert not new.is_stopped() and len(mixer) == 1
+    mixer.close()
+
+
+def test_mixer_control_calls_race_with_sample():
+    """Control calls from another thread while the audio thread samples (signal.rs:11-13): plays, stops and gain values
+    arrive through the SPSC ring; nothing is lost, nothing deadlocks, every played source ends up stopped."""
+    import threading
+
+    import oddio_amd as oa
+    control, mixer = oa.Mixer(max_sources=512, max_frames=256)
+    interval = np.float32(1.0) / np.float32(48000)
+    handles, errors = [], []
+    done = threading.Event()
+
+    def control_thread():
+        try:
+            rng = np.random.default_rng(3)
+            frames = oa.Frames.from_slice(48000, synth.noise_clip(5, 0, 48000))
+            for k in range(400):
+                gh, sig = oa.Gain.new(oa.MonoToStereo(oa.FramesSignal(frames, float(rng.uniform(0.0, 0.1)))))
+                h = control.play(sig)
+                handles.append(h)
+                gh.set_amplitude_ratio(float(rng.uniform(0.1, 1.0)))
+                if k % 3 == 0 and handles:
+                    handles[int(rng.integers(0, len(handles)))].stop()
+        except Exception as e:          # noqa: BLE001
+            errors.append(e)
+        finally:
+            done.set()
+    t = threading.Thread(target=control_thread)
+    t.start()
+    n_calls = 0
+    while not done.is_set() or n_calls < 20:
+        out = mixer.sample_n(interval, 256)
+        assert np.isfinite(out).all()
+        n_calls += 1
+        if done.is_set():
+            n_calls += 0
+    t.join()
+    assert not errors, errors
+    for h in handles:
+        h.stop()
+    mixer.sample_n(interval, 256)
+    mixer.sample_n(interval, 256)
+    assert len(mixer) == 0 and all(h.is_stopped() for h in handles)
+    mixer.close()
