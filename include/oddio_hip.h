@@ -37,6 +37,7 @@ enum {
     ODDIO_HIP_ENOMEM = -2,    /* capacity (max_sources / max_frames) exceeded or allocation failed */
     ODDIO_HIP_ENODEV = -3,    /* no usable HIP device */
     ODDIO_HIP_ESTATE = -4,    /* unknown / released handle */
+    ODDIO_HIP_EBOUNDS = -5,   /* libodd_hip_debug.so only: a device-side bounds check failed during the previous callback */
 };
 
 enum { /* oddio_hip_scene_set_postfx */
@@ -62,6 +63,8 @@ typedef struct oddio_hip_mixer oddio_hip_mixer;   /* == Mixer<[f32;2]> or Mixer<
 
 /* ---- library ---- */
 int oddio_hip_abi_version(void);
+/* 1 for the bounds-checked build (libodd_hip_debug.so, `make -C oddio_amd/csrc debug`), 0 for the product library. */
+int oddio_hip_bounds_checked(void);
 const char* oddio_hip_last_error(void);
 int oddio_hip_device_count(int* count);
 

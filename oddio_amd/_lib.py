@@ -25,6 +25,20 @@ def build(force: bool = False) -> str:
     return SO_PATH
 
 
+DEBUG_SO_PATH = os.path.join(_HERE, "libodd_hip_debug.so")
+
+
+def build_debug(force: bool = False) -> str:
+    """The bounds-checked build (`make debug`): same sources with -DODDIO_HIP_BOUNDS; used by tests/test_hip_bounds_build.py
+    through ODDIO_HIP_LIB, never by default."""
+    src_dir = os.path.join(_HERE, "csrc")
+    newest = max(os.path.getmtime(os.path.join(src_dir, f)) for f in os.listdir(src_dir))
+    newest = max(newest, os.path.getmtime(HEADER))
+    if force or not os.path.exists(DEBUG_SO_PATH) or os.path.getmtime(DEBUG_SO_PATH) < newest:
+        subprocess.check_call(["make", "-C", src_dir, "-s", "debug"])
+    return DEBUG_SO_PATH
+
+
 def declared_symbols() -> list[str]:
     """Every function include/oddio_hip.h declares."""
     text = open(HEADER).read()
@@ -61,6 +75,7 @@ def lib():
     fp, u32p, vpp = C.POINTER(C.c_float), C.POINTER(C.c_uint32), C.POINTER(C.c_void_p)
     sig = {
         "oddio_hip_abi_version": (i32, []),
+        "oddio_hip_bounds_checked": (i32, []),
         "oddio_hip_last_error": (C.c_char_p, []),
         "oddio_hip_device_count": (i32, [C.POINTER(i32)]),
         "oddio_hip_frames_from_slice": (i32, [i32, u32, fp, sz, vpp]),

@@ -100,7 +100,20 @@ struct SceneParams {
     float* cycle_rows;      // Seek-set Cycle contribution rows: [row][ear][cycle_plane] (null: none played)
     uint32_t cycle_plane;   // floats per ear plane (= max_frames)
     uint32_t pad;
+    uint32_t* bounds_err;   // debug build (-DODDIO_HIP_BOUNDS): {count, first code, first value, first source}; null otherwise
 };
+
+// The bounds-checked build (`make debug` -> libodd_hip_debug.so): every index into a staged window, every padded
+// re-layout position and every record the walk kernel packs is checked; a violation is counted, its first instance
+// recorded, and the access skipped -- the next sample call returns ODDIO_HIP_EBOUNDS.  (The reference runs miri in CI
+// and debug_assert!s its ring indices, ring.rs:24-27,52-56; this is the device path's counterpart.)
+enum : uint32_t { BOUNDS_WINDOW_INDEX = 1, BOUNDS_PAD_INDEX = 2, BOUNDS_REPACK = 3, BOUNDS_RECORD = 4, BOUNDS_WINDOW_BYTES = 5 };
+#ifdef ODDIO_HIP_BOUNDS
+#define ODDIO_BOUNDS_CHECK(ERR, OK, CODE, VALUE, SRC)                                                         \
+    ((OK) ? true : (oddio_hip::bounds_fail((ERR), (CODE), (uint32_t)(VALUE), (uint32_t)(SRC)), false))
+#else
+#define ODDIO_BOUNDS_CHECK(ERR, OK, CODE, VALUE, SRC) true
+#endif
 
 // Mixer<[f32;2]> of MonoToStereo<mono source> (mixer.rs, signal.rs:61-91)
 struct alignas(16) MixStatic {

@@ -47,6 +47,13 @@ namespace oddio_hip {
 #define ODDIO_HEAD_RADIUS 0.1075f
 #define ODDIO_POSITION_SMOOTHING_PERIOD 0.5f
 
+#ifdef ODDIO_HIP_BOUNDS
+__device__ __noinline__ void bounds_fail(uint32_t* err, uint32_t code, uint32_t value, uint32_t src) {
+    if (err == nullptr) return;
+    if (atomicAdd(err, 1u) == 0u) { err[1] = code; err[2] = value; err[3] = src; }
+}
+#endif
+
 // ---------------------------------------------------------------------------------------------
 // math/mod.rs:33-94 on plain floats (same evaluation order as the reference)
 // ---------------------------------------------------------------------------------------------
@@ -580,6 +587,8 @@ __device__ __forceinline__ TileRec make_tile_rec(const SceneParams& P, const Src
     // a window that starts before the clip: the descriptor base is the clip start and the first -ws/4 vectors are out
     // of range (zeros); one that lies entirely before it has a zero-byte descriptor, any offset reads zeros
     const int negvec = (d.z > 0) ? ((-d.w) >> 4) : 0;
+    (void)ODDIO_BOUNDS_CHECK(P.bounds_err, nvec >= 1 && nvec * 4 <= WIN_CAP && negvec >= 0 && negvec <= 255 && d.z >= 0 && d.z <= nvec * 16 &&
+                             wbase[0][0] - ws >= 0 && wbase[1][1] - ws <= 65535, BOUNDS_RECORD, nvec, tile);
     r.info = (uint32_t)path | ((uint32_t)fl << 3) | ((uint32_t)nvec << 8) | ((uint32_t)negvec << 16);
 #pragma unroll
     for (int e = 0; e < 2; ++e) {
@@ -669,6 +678,9 @@ __device__ __forceinline__ void window_dma(uint32_t lds_dst, uint32_t d0, uint32
     rsrc.w = 0x00020000u;
     const int nvec = (int)((info >> 8) & 255u);
     const int neg = -16 * (int)((info >> 16) & 255u);
+#ifdef ODDIO_HIP_BOUNDS
+    if (nvec * 16 > WIN_BYTES || (int)d2 > nvec * 16 + neg + 16) asm volatile("s_trap 2");   // a window larger than its buffer would overwrite a neighbour's LDS
+#endif
     const int voff = neg + lane16;   // negative offsets wrap to huge unsigned values: out of range -> 0
     uint32_t keep;
     // pieces 0 and 1 from every lane: lanes past the window write zeros inside the buffer (harmless, no traffic)
@@ -687,7 +699,7 @@ __device__ __forceinline__ void window_wait() { asm volatile("s_waitcnt vmcnt(0)
 // Near-unit sources: plain -> padded layout in place (slot(s) = s + s/16; the pad slot repeats the
 // following sample so that a pair (w, w+1) is always two adjacent dwords).  One wave: the DS
 // operations execute in issue order, so every read below precedes every write.
-__device__ __forceinline__ void window_repack_padded(unsigned char* win_bytes, int nvec, int lane) {
+__device__ __forceinline__ void window_repack_padded(unsigned char* win_bytes, int nvec, int lane, uint32_t* err) {
     // (the lane index is made opaque here: hipcc otherwise hoists this function's address arithmetic out of every
     // loop of the kernel and parks it in ~10 VGPRs that the common path then lacks)
     asm volatile("" : "+v"(lane));
@@ -703,6 +715,7 @@ __device__ __forceinline__ void window_repack_padded(unsigned char* win_bytes, i
         if (q < nvec) {
             const int li = 4 * q;
             const int pos = li + (li >> 4);
+            if (!ODDIO_BOUNDS_CHECK(err, pos + 3 < WIN_CAP, BOUNDS_REPACK, pos, nvec)) continue;
             win[pos + 0] = v[k].x; win[pos + 1] = v[k].y; win[pos + 2] = v[k].z; win[pos + 3] = v[k].w;
             if ((li & 15) == 0 && li > 0) win[pos - 1] = v[k].x;
         }
@@ -725,12 +738,13 @@ __device__ __forceinline__ void acc_add(float& acc, float p, bool on) {
 template <bool FULL, bool HAS_FG, bool NONNEG, bool PAD>
 __device__ __forceinline__ void mix_source_lds(const unsigned char* win_bytes, int wrel4, float x, int b, int fast, float frac0, float (&acc)[16],
                                                const float (&fi)[16], uint32_t frame0, uint32_t n_frames, float fixed_gain, float g0, float dg,
-                                               float ds) {
+                                               float ds, int win_samples, uint32_t* err) {
     if (!FULL && frame0 >= n_frames) return;   // this lane's 16 frames lie past the end of `out`
     const float* win = reinterpret_cast<const float*>(win_bytes);
     if (PAD && fast) {
         // frames.rs:180-187 (|ds - 1| <= EPSILON): constant fract, consecutive pairs
         const int w0 = (wrel4 >> 2) + 16 * b;
+        if (!ODDIO_BOUNDS_CHECK(err, w0 >= 0 && w0 + 16 < win_samples && (w0 + 16) + ((w0 + 16) >> 4) < WIN_CAP, BOUNDS_PAD_INDEX, w0, win_samples)) return;
         float a = win[w0 + (w0 >> 4)];
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
@@ -755,7 +769,9 @@ __device__ __forceinline__ void mix_source_lds(const unsigned char* win_bytes, i
         const int tr = (int)x;                                  /* v_cvt_i32_f32 (toward zero) */ \
         fr[I] = NONNEG ? __builtin_amdgcn_fractf(x) : x - (float)tr;   /* frames.rs:192 */          \
         int w = tr;                                                                     \
-        if (PAD) { w = wrel + tr; w = w + (w >> 4); a[I] = win[w]; bb[I] = win[w + 1]; } \
+        const bool in_ = ODDIO_BOUNDS_CHECK(err, wrel + tr >= 0 && wrel + tr + 1 < win_samples, BOUNDS_WINDOW_INDEX, wrel + tr, win_samples); \
+        if (!in_) { a[I] = 0.0f; bb[I] = 0.0f; }                                        \
+        else if (PAD) { w = wrel + tr; w = w + (w >> 4); (void)ODDIO_BOUNDS_CHECK(err, w + 1 < WIN_CAP, BOUNDS_PAD_INDEX, w, win_samples); a[I] = win[w]; bb[I] = win[w + 1]; } \
         else { a[I] = wbase[w]; bb[I] = wbase[w + 1]; }         /* one ds_read2_b32 */   \
         x = x + ds;                                             /* frames.rs:194 */      \
     }
@@ -1068,13 +1084,13 @@ __global__ __launch_bounds__(64 * MIX_WG_WAVES, MIX_WAVES_PER_SIMD) void spatial
             const float fg = (flags_j & SFLAG_FG) ? st[g * MIX_GROUP + (uint32_t)cur].fixed_gain : 1.0f;   /* v * 1.0 == v */ \
             const float frac0_ = reinterpret_cast<const float*>(blkB0 + cur * BLK_SRC)[0];   /* checkpoint 0 */           \
             const int fast_e = eB ? (flags_j & SFLAG_FAST_R) : (flags_j & SFLAG_FAST_L);                                  \
-            window_repack_padded(win_bytes, (int)((cur_info >> 8) & 255u), lane);                                         \
-            mix_source_lds<FULL, true, false, true>(win_bytes, wrel4, cx0, bB, fast_e, frac0_, acc, fi, frame0, n_frames, fg, ct.y, ct.z, ct.w); \
+            window_repack_padded(win_bytes, (int)((cur_info >> 8) & 255u), lane, P.bounds_err);                                         \
+            mix_source_lds<FULL, true, false, true>(win_bytes, wrel4, cx0, bB, fast_e, frac0_, acc, fi, frame0, n_frames, fg, ct.y, ct.z, ct.w, 4 * (int)((cur_info >> 8) & 255u), P.bounds_err); \
         } else if (var_j == 0) {                                                                                          \
-            mix_source_lds<FULL, false, true, false>(win_bytes, wrel4, cx0, bB, 0, 0.0f, acc, fi, frame0, n_frames, 1.0f, ct.y, ct.z, ct.w); \
+            mix_source_lds<FULL, false, true, false>(win_bytes, wrel4, cx0, bB, 0, 0.0f, acc, fi, frame0, n_frames, 1.0f, ct.y, ct.z, ct.w, 4 * (int)((cur_info >> 8) & 255u), P.bounds_err); \
         } else {                                                                                                          \
             const float fg = (flags_j & SFLAG_FG) ? st[g * MIX_GROUP + (uint32_t)cur].fixed_gain : 1.0f;                  \
-            mix_source_lds<FULL, true, false, false>(win_bytes, wrel4, cx0, bB, 0, 0.0f, acc, fi, frame0, n_frames, fg, ct.y, ct.z, ct.w); \
+            mix_source_lds<FULL, true, false, false>(win_bytes, wrel4, cx0, bB, 0, 0.0f, acc, fi, frame0, n_frames, fg, ct.y, ct.z, ct.w, 4 * (int)((cur_info >> 8) & 255u), P.bounds_err); \
         }                                                                                                                 \
         buf ^= 1;                                                                                                         \
         cur = nxt; cur_info = nxt_info; cx0 = nx0; ct = nt;                                                               \

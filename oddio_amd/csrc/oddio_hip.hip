@@ -252,6 +252,13 @@ extern "C" int oddio_hip_stream_drop(oddio_hip_stream* st) {
 // library
 // ---------------------------------------------------------------------------------------------
 extern "C" int oddio_hip_abi_version(void) { return ODDIO_HIP_ABI_VERSION; }
+extern "C" int oddio_hip_bounds_checked(void) {
+#ifdef ODDIO_HIP_BOUNDS
+    return 1;
+#else
+    return 0;
+#endif
+}
 extern "C" const char* oddio_hip_last_error(void) { return g_last_error.c_str(); }
 extern "C" int oddio_hip_device_count(int* count) {
     if (!count) return fail(ODDIO_HIP_EINVAL, "count is NULL");

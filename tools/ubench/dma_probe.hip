@@ -15,7 +15,11 @@ __global__ __launch_bounds__(64) void probe(const float* clip, int clip_len4, in
     wave_sync();
     int4 desc = window_desc(clip, clip_len4, ws, nvec);
     if (cut_bytes) desc.z -= cut_bytes;                                // a record count that is not a multiple of 16
-    window_dma((uint32_t)(uintptr_t)win, desc, nvec, lane);
+    // what make_tile_rec packs into the TileRec: descriptor words 0-2, info = nvec << 8 | negvec << 16
+    const int negvec = desc.z > 0 ? ((-desc.w) >> 4) : 0;
+    const uint32_t info = ((uint32_t)nvec << 8) | ((uint32_t)negvec << 16);
+    window_dma((uint32_t)(uintptr_t)win, (uint32_t)__builtin_amdgcn_readfirstlane(desc.x), (uint32_t)__builtin_amdgcn_readfirstlane(desc.y),
+               (uint32_t)__builtin_amdgcn_readfirstlane(desc.z), (uint32_t)__builtin_amdgcn_readfirstlane((int)info), 16 * lane);
     window_wait();
     wave_sync();
     for (int k = lane; k < WIN_CAP; k += 64) out[k] = win[k];
