@@ -430,12 +430,15 @@ __device__ __forceinline__ void wg_sync() {
 }
 
 // inner.sample(interval, out[0..n]) for the chain above; every lane holds the same `s` / `d`.
-__device__ void inner_sample_wave(const BufStatic& s, BufDyn& d, float interval, float* out, uint32_t n, float (*ck)[64], int lane) {
+__device__ __forceinline__ void inner_sample_wave(const BufStatic& s, BufDyn& d, float interval, float* out, uint32_t n, float (*ck)[64], int lane) {
+    // (every loop over the filter chain is unrolled over MAX_WRAP with compile-time indices: arrays indexed by a runtime
+    // filter number live in scratch memory, 256 bytes per lane before)
     float level_interval[MAX_WRAP];
     float cur = interval;
-    for (int w = (int)s.n_wrap - 1; w >= 0; --w) {
+#pragma unroll
+    for (int w = MAX_WRAP - 1; w >= 0; --w) {
         level_interval[w] = cur;
-        if (s.wrap_kind[w] == WRAP_SPEED) cur = cur * d.shared[w];   // speed.rs:32-35
+        if ((uint32_t)w < s.n_wrap && s.wrap_kind[w] == WRAP_SPEED) cur = cur * d.shared[w];   // speed.rs:32-35
     }
     // leaf: frames.rs:176-201, or cycle.rs:26-53 (d.common.t is then the cursor in samples; ck row 5 holds `base`)
     const bool cyc = s.kind == KIND_CYCLE;
@@ -449,6 +452,7 @@ __device__ void inner_sample_wave(const BufStatic& s, BufDyn& d, float interval,
     // Gain: Smoothed::set when the shared target moved (gain.rs:106-109), then ramp or constant
     bool ramp[MAX_WRAP];
     float gconst[MAX_WRAP], step[MAX_WRAP];
+#pragma unroll
     for (uint32_t w = 0; w < MAX_WRAP; ++w) {
         ramp[w] = false; gconst[w] = 1.0f; step[w] = 0.0f;
         if (w < s.n_wrap && s.wrap_kind[w] == WRAP_GAIN) {
@@ -467,6 +471,7 @@ __device__ void inner_sample_wave(const BufStatic& s, BufDyn& d, float interval,
     const bool is_gain = lane >= 1 && lane <= MAX_WRAP;
     float scan = 0.0f, inc = 0.0f;
     if (lane == 0) { scan = frac0; inc = ds; }
+#pragma unroll
     for (int w = 0; w < MAX_WRAP; ++w) if (lane == 1 + w) { scan = d.sm_progress[w]; inc = step[w]; }
     for (uint32_t p0 = 0; p0 < n; p0 += 1024u) {
         const uint32_t m = (n - p0) < 1024u ? (n - p0) : 1024u;
@@ -495,6 +500,7 @@ __device__ void inner_sample_wave(const BufStatic& s, BufDyn& d, float interval,
             float off = ck[0][lane];
             uint32_t cb_ = cyc ? __float_as_uint(ck[5][lane]) : 0u;
             float pr[MAX_WRAP];
+#pragma unroll
             for (int w = 0; w < MAX_WRAP; ++w) pr[w] = ck[1 + w][lane];
             for (uint32_t k = 0; k < cnt; ++k) {
                 float a, b, fr;
@@ -509,7 +515,9 @@ __device__ void inner_sample_wave(const BufStatic& s, BufDyn& d, float interval,
                     a = clip_ch(s.clip, s.clip_len, 1u, 0u, idx); b = clip_ch(s.clip, s.clip_len, 1u, 0u, idx + 1);
                 }
                 float v = a + fr * (b - a);
-                for (uint32_t w = 0; w < s.n_wrap; ++w) {
+#pragma unroll
+                for (uint32_t w = 0; w < MAX_WRAP; ++w) {
+                    if (w >= s.n_wrap) continue;
                     if (s.wrap_kind[w] == WRAP_FIXED_GAIN) v = v * s.wrap_param[w];              // gain.rs:32-37
                     else if (s.wrap_kind[w] == WRAP_GAIN) {                                       // gain.rs:110-121
                         if (ramp[w]) {
@@ -524,6 +532,7 @@ __device__ void inner_sample_wave(const BufStatic& s, BufDyn& d, float interval,
         }
         wg_sync();   // before the next pass overwrites the checkpoints
     }
+#pragma unroll
     for (int w = 0; w < MAX_WRAP; ++w) {
         const float fin = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(scan), 1 + w));
         if (ramp[w]) d.sm_progress[w] = fin;

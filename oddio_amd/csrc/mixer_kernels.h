@@ -350,7 +350,11 @@ __global__ __launch_bounds__(64) void mixer_general_sources_wave(uint32_t n_sour
         const uint32_t len = (n_frames - done) < 1024u ? (n_frames - done) : 1024u;
         inner_sample_wave(s, d, interval, my + done, len, ck, lane);
     }
-    if (lane == 0) dyn[i] = d;
+    if (lane == 0) {   // what inner_sample_wave advances (a whole-struct store keeps the untouched fields alive in scratch)
+        dyn[i].common.t = d.common.t;
+#pragma unroll
+        for (int w = 0; w < MAX_WRAP; ++w) { dyn[i].sm_prev[w] = d.sm_prev[w]; dyn[i].sm_next[w] = d.sm_next[w]; dyn[i].sm_progress[w] = d.sm_progress[w]; }
+    }
 }
 
 __global__ void mixer_general_reduce(const float* __restrict__ slabs, const uint32_t* __restrict__ skip, const BufStatic* __restrict__ st,
