@@ -7,23 +7,28 @@
 //
 // Kernels
 //   spatial_prepass   1 thread / source (table rows moved through LDS a wavefront at a time)
-//                                         walk_set + EarState + cursor bookkeeping
-//                                         (spatial.rs:191-265, :445-469 scalar part, :501-549)
+//                                         walk_set + EarState + cursor bookkeeping + the tile records
+//                                         (spatial.rs:191-265, :445-469 scalar part, :501-549; frames.rs:176-201 set-up)
+//   tile_records      the tile records of the later passes of a callback longer than REC_TILES tiles
 //   cycle_sources     1 wave / Seek-set Cycle source: serial cursor scan + 64-lane render (cycle.rs:26-60)
 //   spatial_mix       2-wave workgroups, 16 sources per phase-A group; the per-sample loop
 //                                         (spatial.rs:456-463 + frames.rs:176-201 + sine.rs:34-40);
 //                                         <.., STORE>: per-source contribution rows for ORDERED mode at scale
 //   reduce_partials   fixed-order sum of the workgroup partial tiles + Reinhard/Tanh epilogue
 //                                         (reinhard.rs:32, tanh.rs:26); set_kernels.h adds the set compaction
-//   ordered_sum       the reference's sequential sum over the contribution rows (spatial.rs:204,460)
+//   ordered_sum       the reference's sequential sum over the contribution rows (spatial.rs:204,460):
+//                                         a loader wave (HBM -> LDS ring) and an adder wave (DPP add chain) per column block
 //
 // Mix kernel work decomposition (why it is not "one lane = one output frame"):
 //   FramesSignal's slow path advances its f32 cursor by a *sequentially rounded* `offset += ds`
 //   (frames.rs:189-196) restarted from the f64 clock every <=256-frame chunk (spatial.rs:456).
 //   A closed form offset0 + k*ds is not within tolerance, so the running sum must
 //   be reproduced exactly.  A tile is 512 output frames (two 256-frame chunks).
-//   Phase A: 64 lanes = 16 sources x 2 ears x 2 chunks each run the exact 255-step f32 scan once
-//   and leave 16 checkpoints (every 16 frames) in xor-swizzled LDS.
+//   The walk kernel leaves one TileRec per (source, tile): window descriptor, per-ear {ds, g0, dg, wrel}, per-chunk
+//   start offsets -- everything of frames.rs:176-201 that needs f64 or does not depend on the output frame.
+//   Phase A: 64 lanes = 16 sources x 2 ears x 2 chunks each take their stream's record words (loaded one group ahead),
+//   run the exact 255-step f32 scan once and leave 16 checkpoints (every 16 frames) + {4*wrel, g0, dg, ds} in a
+//   20-word LDS block per stream.
 //   Phase B: for one source at a time, lanes 0-31 are the left ear and 32-63 the right ear; lane l
 //   owns 16 consecutive output frames of its ear (16 register accumulators), restarts from its
 //   checkpoint and replays 15 exact adds.  The source's sample window (~N*ds + 32 floats) is

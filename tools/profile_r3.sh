@@ -15,6 +15,7 @@ python bench.py --no-cpu-baseline --steps 20 --warmup 5 --precondition-ms 0 > "$
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof" -o final -- python "$ROOT/bench.py" --steps 20 --warmup 5 --no-cpu-baseline > "$OUT/bench_under_rocprof.json" 2> "$OUT/prof.log"
 cd "$ROOT"
+python tools/timed_launches.py "$OUT/prof/final_kernel_trace.csv" 20 16 > "$OUT/mix_launches.csv" 2> "$OUT/mix_launches.txt"
 tools/profile_pmc.sh $TAG/pmc --steps 8 --warmup 2 --no-cpu-baseline --precondition-ms 0 > "$OUT/pmc.log" 2>&1
 python tools/make_pmc_json.py "$OUT/pmc/summary.json" 262144 "$OUT/pmc_latest.json" >> "$OUT/pmc.log" 2>&1
 python tools/ordered_probe.py > "$OUT/ordered_probe.txt" 2>/dev/null
