@@ -100,7 +100,7 @@ int oddio_hip_scene_destroy(oddio_hip_scene* scene);
  *   Constant::new(value)                      (src/constant.rs);
  *   Cycle::new(frames)                        (src/cycle.rs:17-23; Seek: src/cycle.rs:56-61), optionally
  *   inside FixedGain.  A Cycle's cursor is a serial rounding chain through both ears
- *   (src/cycle.rs:52 inside src/spatial.rs:446-468), so it is rendered one thread per source; at most
+ *   (src/cycle.rs:52 inside src/spatial.rs:446-468): one wavefront per Cycle replays it; at most
  *   1024 per scene (environment ODDIO_HIP_MAX_CYCLE), ODDIO_HIP_ENOMEM beyond that.
  * `*source_id` is the handle (== the returned `Spatial`). */
 int oddio_hip_scene_play_frames(oddio_hip_scene* scene, oddio_hip_frames* frames,
@@ -326,7 +326,7 @@ int oddio_hip_mixer_play_constant(oddio_hip_mixer* mixer, float value, uint32_t*
 /* MixerControl::play of any supported signal: leaf (ODDIO_HIP_LEAF_*, arguments as above; mono
  * leaves are implicitly MonoToStereo'd, stereo clips play as is) inside up to 4 filters, innermost
  * first (FixedGain / Gain / Speed; see oddio_hip_filter).  A mixer that has ever been given a Gain,
- * Speed, Cycle, a stereo clip or more than one filter renders through the general (one thread per
+ * Speed, Cycle, a stereo clip or more than one filter renders through the general (one wavefront per
  * source) path from then on and holds at most 1024 sources. */
 int oddio_hip_mixer_play_chain(oddio_hip_mixer* mixer, int leaf_kind, oddio_hip_frames* frames,
                                double start_seconds, float phase, float frequency_hz_or_value,

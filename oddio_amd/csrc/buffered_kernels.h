@@ -6,9 +6,8 @@
 // Every source writes its contribution to its own [N][2] slab (ring write through the filter chain, then per ear /
 // per 256-frame chunk ring reads with the f32 cursor and its wrap rule); `buffered_reduce` then adds the slabs in the
 // reference's reverse-slot order, so the result is bit-identical to the reference's `o[ear] += s * gain` sequence for
-// FramesSignal/Constant leaves.  `buffered_sources_wave` renders the common shapes one WAVE per source (scanner lanes
-// replay the exact f32 running sums, 64 lanes expand them); `buffered_sources` is the one-thread-per-source form of the
-// same loops for the remaining shapes (Fader, Stream, stereo leaves).
+// FramesSignal/Constant leaves.  `buffered_sources_wave` renders every shape one WAVE per source (scanner lanes
+// replay the exact f32 running sums, 64 lanes expand them).
 #pragma once
 #include "kernels.h"
 
@@ -68,137 +67,7 @@ __device__ __forceinline__ float clip_ch(const float* clip, uint32_t len, uint32
     return (i >= 0 && i < (long long)len) ? clip[(size_t)i * C + ch] : 0.0f;   // frames.rs:105-123
 }
 
-__device__ void leaf_sample(const BufStatic& s, SrcDyn& d, uint32_t& bd_stream_len, uint32_t& bd_stream_stopping, float interval, float* out, uint32_t n) {
-    const uint32_t C = s.channels ? s.channels : 1u;
-    if (s.kind == KIND_FRAMES) {   // frames.rs:176-201
-        const double s0 = d.t * (double)s.clip_rate;
-        const float ds = interval * (float)s.clip_rate;
-        const long long base = f64_as_isize(s0);
-        if (fabsf(ds - 1.0f) <= FLT_EPSILON) {
-            const float fract = (float)(s0 - (double)base);
-            for (uint32_t i = 0; i < n; ++i)
-                for (uint32_t ch = 0; ch < C; ++ch) {
-                    const float a = clip_ch(s.clip, s.clip_len, C, ch, base + (long long)i), b = clip_ch(s.clip, s.clip_len, C, ch, base + (long long)i + 1);
-                    out[i * C + ch] = a + fract * (b - a);
-                }
-        } else {
-            float offset = (float)(s0 - (double)base);
-            for (uint32_t i = 0; i < n; ++i) {
-                const long long tr = (long long)offset;
-                const float fract = offset - (float)tr;
-                for (uint32_t ch = 0; ch < C; ++ch) {
-                    const float a = clip_ch(s.clip, s.clip_len, C, ch, base + tr), b = clip_ch(s.clip, s.clip_len, C, ch, base + tr + 1);
-                    out[i * C + ch] = a + fract * (b - a);
-                }
-                offset = offset + ds;
-            }
-        }
-        d.t = d.t + (double)interval * (double)n;
-    } else if (s.kind == KIND_CYCLE) {   // cycle.rs:26-53 ; d.t is the cursor in samples
-        const size_t len = s.clip_len;
-        const float ds = interval * (float)s.clip_rate;
-        size_t base = (size_t)f64_as_isize(d.t);
-        float offset = (float)(d.t - (double)base);
-        for (uint32_t i = 0; i < n; ++i) {
-            const size_t trunc = (size_t)offset;
-            const float fract = offset - (float)trunc;
-            const size_t x = base + trunc;
-            size_t ia, ib;
-            if (x < len - 1) { ia = x; ib = x + 1; }
-            else if (x < len) { ia = x; ib = 0; }
-            else {
-                base = 0;
-                offset = (float)(x % len) + fract;
-                const size_t x2 = (size_t)offset;
-                if (x2 < len - 1) { ia = x2; ib = x2 + 1; } else { ia = x2; ib = 0; }
-            }
-            for (uint32_t ch = 0; ch < C; ++ch) {
-                const float a = s.clip[ia * C + ch], b = s.clip[ib * C + ch];
-                out[i * C + ch] = a + fract * (b - a);
-            }
-            offset = offset + ds;
-        }
-        d.t = (double)base + (double)offset;
-    } else if (s.kind == KIND_STREAM) {   // stream.rs:69-85 over the spsc ring in pinned host memory
-        StreamHeader* hdr = reinterpret_cast<StreamHeader*>(const_cast<float*>(s.clip)) - 1;
-        const uint32_t size = s.clip_len;                                    // capacity + 1 (spsc.rs:12)
-        const uint32_t read = hdr->read;                                     // only this thread ever stores it
-        const uint32_t write = __hip_atomic_load(&hdr->write, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);
-        uint32_t len = write >= read ? write - read : write + size - read;  // update(): readable_len, spsc.rs:218-225
-        if (len < bd_stream_len) len = bd_stream_len;                        // never shrinks (debug_assert, spsc.rs:131)
-        if (__hip_atomic_load(&hdr->closed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)) bd_stream_stopping = 1u;   // :71-73
-        const float s0 = d.phase;                                            // Stream::t
-        const float ds = interval * (float)s.clip_rate;
-        for (uint32_t i = 0; i < n; ++i) {
-            const float sv = s0 + ds * (float)i;                             // :78
-            const float x0f = truncf(sv);
-            const long long x0 = f64_as_isize((double)x0f);                  // s.trunc() as isize
-            const float fract = sv - x0f;                                    // f32::fract
-            for (uint32_t ch = 0; ch < C; ++ch) {
-                float a = 0.0f, b = 0.0f;                                    // Stream::get: zero outside [0, len)
-                if (x0 >= 0 && x0 < (long long)len) a = s.clip[(size_t)((read + (uint32_t)x0) % size) * C + ch];
-                if (x0 + 1 >= 0 && x0 + 1 < (long long)len) b = s.clip[(size_t)((read + (uint32_t)(x0 + 1)) % size) * C + ch];
-                out[i * C + ch] = a + fract * (b - a);
-            }
-        }
-        {   // advance(interval * out.len() as f32), stream.rs:59-64
-            const float next = d.phase + (interval * (float)n) * (float)s.clip_rate;
-            const float t = fminf(next, (float)len);
-            uint32_t rel = (uint32_t)f32_as_usize(t);
-            if (rel > len) rel = len;
-            if (rel) __hip_atomic_store(&hdr->read, (read + rel) % size, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);   // release(), spsc.rs:227-235
-            len -= rel;
-            d.phase = t - truncf(t);
-        }
-        bd_stream_len = len;
-    } else if (s.kind == KIND_SINE) {   // sine.rs:34-40
-        for (uint32_t i = 0; i < n; ++i) {
-            const float t = interval * (float)i;
-            out[i] = sinf(t * s.freq_or_value + d.phase);
-        }
-        d.phase = fmodf(d.phase + (interval * (float)n) * s.freq_or_value, ODDIO_TAU);
-    } else {   // constant.rs:16-18
-        for (uint32_t i = 0; i < n * C; ++i) out[i] = s.freq_or_value;
-    }
-}
-
-__device__ void inner_sample(const BufStatic& s, BufDyn& d, float interval, float* out, uint32_t n) {
-    // interval as each filter level sees it (outermost first); Speed rescales it on the way in
-    const uint32_t C = s.channels ? s.channels : 1u;
-    float level_interval[MAX_WRAP];
-    float cur = interval;
-    for (int w = (int)s.n_wrap - 1; w >= 0; --w) {
-        level_interval[w] = cur;
-        if (s.wrap_kind[w] == WRAP_SPEED) cur = cur * d.shared[w];   // speed.rs:32-35
-    }
-    leaf_sample(s, d.common, d.stream_len, d.stream_stopping, cur, out, n);
-    for (uint32_t w = 0; w < s.n_wrap; ++w) {
-        if (s.wrap_kind[w] == WRAP_FIXED_GAIN) {                      // gain.rs:32-37
-            const float g = s.wrap_param[w];
-            for (uint32_t i = 0; i < n * C; ++i) out[i] = out[i] * g;
-        } else if (s.wrap_kind[w] == WRAP_GAIN) {                     // gain.rs:103-122
-            const float shared = d.shared[w];
-            if (d.sm_next[w] != shared) {                             // Smoothed::set, smooth.rs:57-64
-                d.sm_prev[w] = d.sm_prev[w] + d.sm_progress[w] * (d.sm_next[w] - d.sm_prev[w]);
-                d.sm_next[w] = shared;
-                d.sm_progress[w] = 0.0f;
-            }
-            if (d.sm_progress[w] == 1.0f) {
-                const float g = d.sm_prev[w] + d.sm_progress[w] * (d.sm_next[w] - d.sm_prev[w]);
-                if (g != 1.0f) for (uint32_t i = 0; i < n * C; ++i) out[i] = out[i] * g;
-            } else {
-                const float step = level_interval[w] / 0.1f;          // SMOOTHING_PERIOD, gain.rs:163
-                for (uint32_t i = 0; i < n; ++i) {
-                    const float g = d.sm_prev[w] + d.sm_progress[w] * (d.sm_next[w] - d.sm_prev[w]);
-                    for (uint32_t ch = 0; ch < C; ++ch) out[i * C + ch] = out[i * C + ch] * g;
-                    d.sm_progress[w] = fminf(d.sm_progress[w] + step, 1.0f);   // Smoothed::advance, smooth.rs:47-49
-                }
-            }
-        }
-    }
-}
-
-// ---- Fader (fader.rs:10-93) around a leaf + filter chain (general, thread-per-source paths) -----
+// ---- Fader (fader.rs:10-93) around a leaf + filter chain -----
 // `next` is what swap::Receiver::received() holds after a refresh (the signal being faded to, or the
 // retired one after a completed fade); `pend` is the control's flushed, not yet refreshed Command.
 // Only the SIGNAL part of a BufStatic / BufDyn pair takes part (leaf, filters, clocks, smoothers);
@@ -224,6 +93,7 @@ __device__ __forceinline__ void signal_assign(BufStatic& st, BufDyn& dyn, const 
     st.clip = from_st.clip; st.clip_len = from_st.clip_len; st.clip_rate = from_st.clip_rate;
     st.freq_or_value = from_st.freq_or_value; st.kind = from_st.kind; st.channels = from_st.channels;
     st.n_wrap = from_st.n_wrap;
+#pragma unroll
     for (int w = 0; w < MAX_WRAP; ++w) {
         st.wrap_kind[w] = from_st.wrap_kind[w]; st.wrap_param[w] = from_st.wrap_param[w];
         dyn.shared[w] = from_dyn.shared[w]; dyn.sm_prev[w] = from_dyn.sm_prev[w];
@@ -233,206 +103,28 @@ __device__ __forceinline__ void signal_assign(BufStatic& st, BufDyn& dyn, const 
     dyn.stream_len = from_dyn.stream_len; dyn.stream_stopping = from_dyn.stream_stopping;
 }
 
-// Fader::sample (fader.rs:36-73).  `scratch` holds FADER_BUF frames of the source's channel count.
-__device__ void fader_sample(BufStatic& st, BufDyn& dyn, FaderRec& F, float* scratch, float interval, float* out, uint32_t n) {
-    const uint32_t C = st.channels ? st.channels : 1u;
-    if (F.progress >= 1.0f) {
-        if (F.pend.fresh) {                               // self.next.refresh()
-            F.next_st = F.pend.st; F.next_dyn = F.pend.dyn; F.duration = F.pend.duration;
-            F.next_gen = F.pend.gen;
-            F.pend.fresh = 0u;
-            F.progress = 0.0f;
-        } else {
-            inner_sample(st, dyn, interval, out, n);      // fast path
-            return;
-        }
-    }
-    const float increment = interval / F.duration;
-    BufStatic nst = F.next_st;                            // private copies, written back once
-    BufDyn ndyn = F.next_dyn;
-    float progress = F.progress;
-    uint32_t off = 0;
-    while (off < n) {
-        const uint32_t rem = n - off;
-        const uint32_t m = rem < FADER_BUF ? rem : FADER_BUF;
-        inner_sample(st, dyn, interval, scratch, FADER_BUF);                    // the whole buffer, fader.rs:53
-        inner_sample(nst, ndyn, interval, out + (size_t)off * C, rem);          // all that is left, :54
-        for (uint32_t k = 0; k < m; ++k) {
-            const float fade_out = sqrtf(1.0f - progress);
-            const float fade_in = sqrtf(progress);
-            for (uint32_t ch = 0; ch < C; ++ch) {
-                float* o = out + (size_t)(off + k) * C + ch;
-                *o = scratch[k * C + ch] * fade_out + *o * fade_in;             // frame::mix(scale(x), scale(o))
-            }
-            progress = fminf(progress + increment, 1.0f);
-        }
-        off += m;
-    }
-    F.progress = progress;
-    if (progress >= 1.0f) {   // mem::swap(&mut self.inner, &mut next.fade_to)
-        const BufStatic old_st = st;
-        const BufDyn old_dyn = dyn;
-        signal_assign(st, dyn, nst, ndyn);
-        signal_assign(F.next_st, F.next_dyn, old_st, old_dyn);
-        const uint32_t g = F.cur_gen; F.cur_gen = F.next_gen; F.next_gen = g;
-    } else {
-        F.next_dyn = ndyn;
-    }
-}
-
-// the shapes the wave-per-source kernels render: FixedGain / Gain / Speed over a mono FramesSignal or a mono Cycle
-// (whose 32-bit cursor arithmetic, cycle_step in kernels.h, wants clips of fewer than 2^30 samples)
-__host__ __device__ __forceinline__ bool buffered_wave_shape(uint32_t kind, uint32_t channels, uint32_t fader, uint32_t clip_len) {
-    return (kind == KIND_FRAMES || (kind == KIND_CYCLE && clip_len < (1u << 30))) && channels <= 1u && fader == 0u;
-}
-
-// One thread per buffered slot: walk_set (spatial.rs:191-265) + the buffered mix closure
-// (spatial.rs:402-431).  contrib is [slot][n_frames][2]; skip[slot] != 0 means "not mixed".
-__global__ __launch_bounds__(64) void buffered_sources(SceneParams P, const uint32_t* __restrict__ d_len_b, BufStatic* __restrict__ st,
-                                                       BufDyn* __restrict__ dyn, SrcPending* __restrict__ pend,
-                                                       float* __restrict__ contrib, uint32_t* __restrict__ skip,
-                                                       uint32_t* __restrict__ stopped_hdr, uint32_t stopped_cap,
-                                                       FaderRec* __restrict__ faders, float* __restrict__ fader_scratch, int skip_wave_shapes) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= d_len_b[0]) return;
-    BufDyn d = dyn[i];
-    BufStatic s = st[i];
-    if (skip_wave_shapes && buffered_wave_shape(s.kind, s.channels, s.fader, s.clip_len)) return;   // buffered_sources_wave renders these
-    SrcDyn& c = d.common;
-    if (c.flags & DYN_STOPPED) { skip[i] = 1; return; }
-    const float elapsed = P.elapsed;
-    const uint32_t n = P.n_frames;
-    const float nf = (float)n;
-    V3 tpos = {c.tgt_pos[0], c.tgt_pos[1], c.tgt_pos[2]};
-    V3 tvel = {c.tgt_vel[0], c.tgt_vel[1], c.tgt_vel[2]};
-    V3 ppos = {c.prev_pos[0], c.prev_pos[1], c.prev_pos[2]};
-    const SrcPending pm = pend[i];
-    if (pm.flags & PEND_FRESH) {   // spatial.rs:216-226
-        V3 npos = {pm.pos[0], pm.pos[1], pm.pos[2]};
-        V3 nvel = {pm.vel[0], pm.vel[1], pm.vel[2]};
-        ppos = (pm.flags & PEND_DISCONTINUITY) ? npos : smoothed_position(ppos, c.state_dt, 0.0f, tpos, tvel);
-        tpos = npos; tvel = nvel;
-        c.state_dt = 0.0f;
-        pend[i].flags = 0;
-    }
-    const Quat prev_rot = {P.prev_rot[0], P.prev_rot[1], P.prev_rot[2], P.prev_rot[3]};
-    const Quat rot = {P.rot[0], P.rot[1], P.rot[2], P.rot[3]};
-    const V3 p0 = quat_rotate(prev_rot, smoothed_position(ppos, c.state_dt, 0.0f, tpos, tvel));
-    const V3 p1 = quat_rotate(rot, smoothed_position(ppos, c.state_dt, elapsed, tpos, tvel));
-    c.state_dt = c.state_dt + elapsed;
-    c.tgt_pos[0] = tpos.x; c.tgt_pos[1] = tpos.y; c.tgt_pos[2] = tpos.z;
-    c.tgt_vel[0] = tvel.x; c.tgt_vel[1] = tvel.y; c.tgt_vel[2] = tvel.z;
-    c.prev_pos[0] = ppos.x; c.prev_pos[1] = ppos.y; c.prev_pos[2] = ppos.z;
-    // spatial.rs:243-261
-    const float distance = v3_norm(p0);
-    if (c.flags & DYN_HAS_FINISHED_FOR) {
-        if (c.finished_for > distance / ODDIO_SPEED_OF_SOUND) c.flags |= DYN_STOPPED;
-        else c.finished_for = c.finished_for + elapsed;
-    } else {
-        bool fin = false;
-        if (!s.fader) {   // Fader::is_finished is always false (fader.rs:76-79)
-            if (s.kind == KIND_FRAMES) fin = c.t >= (double)(s.clip_len - 1u) / (double)s.clip_rate;   // is_finished passes through the filters
-            if (s.kind == KIND_STREAM) fin = d.stream_stopping && c.phase == (float)d.stream_len;       // stream.rs:88-90
-        }
-        if (fin) { c.flags |= DYN_HAS_FINISHED_FOR; c.finished_for = elapsed; }
-    }
-    if (c.flags & DYN_STOPPED) {
-        const uint32_t k = atomicAdd(&stopped_hdr[0], 1u);
-        if (k < stopped_cap) stopped_hdr[1 + k] = c.id;
-        skip[i] = 1;
-        dyn[i] = d;
-        return;
-    }
-    skip[i] = 0;
-    float* ring = s.ring;
-    const uint32_t len = s.ring_len;
-    {   // Ring::write (ring.rs:18-41): extend the delay queue with new data
-        const float end = fmodf(d.ring_write + elapsed * (float)s.rate, (float)len);
-        const size_t start_idx = f32_as_usize(ceilf(d.ring_write));
-        const size_t end_idx = f32_as_usize(ceilf(end));
-        const float interval = 1.0f / (float)s.rate;
-        FaderRec* F = s.fader ? &faders[s.fader - 1u] : nullptr;
-        float* fscr = s.fader ? fader_scratch + (size_t)(s.fader - 1u) * FADER_BUF : nullptr;
-        if (end_idx > start_idx) {
-            if (F) fader_sample(s, d, *F, fscr, interval, ring + start_idx, (uint32_t)(end_idx - start_idx));
-            else inner_sample(s, d, interval, ring + start_idx, (uint32_t)(end_idx - start_idx));
-        } else {
-            if (F) {
-                fader_sample(s, d, *F, fscr, interval, ring + start_idx, (uint32_t)(len - start_idx));
-                fader_sample(s, d, *F, fscr, interval, ring, (uint32_t)end_idx);
-            } else {
-                inner_sample(s, d, interval, ring + start_idx, (uint32_t)(len - start_idx));
-                inner_sample(s, d, interval, ring, (uint32_t)end_idx);
-            }
-        }
-        if (F) st[i] = s;   // a completed fade swapped the signals
-        d.ring_write = end;
-    }
-    __threadfence_block();
-    float* my = contrib + (size_t)i * 2 * n;
-    float buf[32];
-    for (int e = 0; e < 2; ++e) {   // spatial.rs:409-430
-        float off0, g0, off1, g1;
-        ear_state(p0, e, s.radius, off0, g0);
-        ear_state(p1, e, s.radius, off1, g1);
-        const float prev_offset = fmaxf(off0 - elapsed, -s.max_delay);
-        const float next_offset = fmaxf(off1, -s.max_delay);
-        const float dt = (next_offset - prev_offset) / nf;
-        const float d_gain = (g1 - g0) / nf;
-        uint32_t idx = 0;
-        for (uint32_t done = 0; done < n; done += 256u) {
-            const uint32_t clen = (n - done) < 256u ? (n - done) : 256u;
-            const float t = prev_offset + (float)idx * dt;
-            // the 256-frame chunk restarts the cursor (ring.rs:57); inside it, consume in pieces of 32
-            float offset = f32_rem_euclid(d.ring_write + t * (float)s.rate, (float)len);
-            const float ds = dt * (float)s.rate;
-            for (uint32_t k0 = 0; k0 < clen; k0 += 32u) {
-                const uint32_t m = (clen - k0) < 32u ? (clen - k0) : 32u;
-                for (uint32_t k = 0; k < m; ++k) {   // ring.rs:59-78
-                    size_t x = (size_t)offset;
-                    const float fract = offset - (float)x;
-                    float a, b;
-                    if (x < (size_t)len - 1) { a = ring[x]; b = ring[x + 1]; }
-                    else if (x < (size_t)len) { a = ring[x]; b = ring[0]; }
-                    else {
-                        x = x % len;
-                        offset = (float)x + fract;
-                        if (x < (size_t)len - 1) { a = ring[x]; b = ring[x + 1]; }
-                        else { a = ring[x]; b = ring[0]; }
-                    }
-                    buf[k] = a + fract * (b - a);
-                    offset = offset + ds;
-                }
-                for (uint32_t k = 0; k < m; ++k) {
-                    const float gain = g0 + (float)idx * d_gain;   // spatial.rs:426
-                    my[2 * (done + k0 + k) + e] = buf[k] * gain;
-                    idx += 1;
-                }
-            }
-        }
-    }
-    dyn[i] = d;
-}
-
-// ---- wave-per-source formulation for the common buffered shape --------------------------------------
-// play_buffered(filters(FramesSignal<f32>)) with any FixedGain / Gain / Speed chain (what Gain and Speed
-// sources, the reason the buffered path exists, look like).  The reference's loops are sequential only in
+// ---- wave-per-source formulation of the buffered set and of the Mixer's general path ------------------
+// play_buffered(filters(leaf)) with any FixedGain / Gain / Speed chain (what Gain and Speed sources, the reason
+// the buffered path exists, look like), optionally inside a Fader.  The reference's loops are sequential only in
 // their f32 running sums -- the leaf's cursor `offset += ds` (frames.rs:189-196), each Gain's
 // `progress = min(progress + step, 1)` (gain.rs:114-120, smooth.rs:47-49) and Ring::sample's cursor with its
 // wrap rewrite (ring.rs:59-78).  One lane per running sum replays it exactly and drops a checkpoint every 16
 // steps in LDS; then all 64 lanes restart from their checkpoints and produce 16 frames each, like the mix
-// kernel's phase A / phase B.  Bit-identical to the thread-per-source kernel, ~100x shorter critical path.
-__device__ __forceinline__ bool buffered_wave_eligible(const BufStatic& s) { return buffered_wave_shape(s.kind, s.channels, s.fader, s.clip_len); }
+// kernel's phase A / phase B.  Stream, Sine and Constant leaves and the FramesSignal fast path have closed-form
+// cursors and need no scan at all.  (Rounds 1-2 rendered these one thread per source: same bits, ~100x the critical path.)
 __device__ __forceinline__ void wg_sync() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
 
-// inner.sample(interval, out[0..n]) for the chain above; every lane holds the same `s` / `d`.
+// inner.sample(interval, out[0..n]) for leaf + filter chain; every lane holds the same `s` / `d`.
+// Leaves: FramesSignal and Cycle (mono or interleaved stereo clip), Stream, Sine, Constant.  `out` holds n frames of
+// C = s.channels interleaved floats.  ck rows: 0 leaf cursor, 1-4 Gain progress, 5 Cycle base (6: the Fader's progress).
 __device__ __forceinline__ void inner_sample_wave(const BufStatic& s, BufDyn& d, float interval, float* out, uint32_t n, float (*ck)[64], int lane) {
     // (every loop over the filter chain is unrolled over MAX_WRAP with compile-time indices: arrays indexed by a runtime
     // filter number live in scratch memory, 256 bytes per lane before)
+    const uint32_t C = s.channels == 2u ? 2u : 1u;
     float level_interval[MAX_WRAP];
     float cur = interval;
 #pragma unroll
@@ -440,18 +132,33 @@ __device__ __forceinline__ void inner_sample_wave(const BufStatic& s, BufDyn& d,
         level_interval[w] = cur;
         if ((uint32_t)w < s.n_wrap && s.wrap_kind[w] == WRAP_SPEED) cur = cur * d.shared[w];   // speed.rs:32-35
     }
-    // leaf: frames.rs:176-201, or cycle.rs:26-53 (d.common.t is then the cursor in samples; ck row 5 holds `base`)
-    const bool cyc = s.kind == KIND_CYCLE;
+    const bool frm = s.kind == KIND_FRAMES, cyc = s.kind == KIND_CYCLE, strm = s.kind == KIND_STREAM, sine = s.kind == KIND_SINE;
+    // leaf FramesSignal: frames.rs:176-201, Cycle: cycle.rs:26-53 (d.common.t is then the cursor in samples; ck row 5 holds `base`)
     const double s0 = d.common.t * (double)s.clip_rate;
     const float ds = cur * (float)s.clip_rate;
     const long long base = f64_as_isize(s0);
-    const bool fast = !cyc && fabsf(ds - 1.0f) <= FLT_EPSILON;
+    const bool fast = frm && fabsf(ds - 1.0f) <= FLT_EPSILON;
     const float frac0 = (float)(s0 - (double)base);
     uint32_t cbase = cyc ? (uint32_t)f64_as_isize(d.common.t) : 0u;        // cycle.rs:28
     float coff = cyc ? (float)(d.common.t - (double)cbase) : 0.0f;          // :29
+    // leaf Stream (stream.rs:69-85): the spsc ring in pinned host memory.  The header words are taken from lane 0:
+    // its loads follow its own release store of `read` in an earlier call, and every lane must see the same producer state.
+    StreamHeader* hdr = nullptr;
+    uint32_t q_size = 0, q_read = 0, q_len = 0;
+    const float phase0 = d.common.phase;                                     // Stream::t / Sine::phase at the start of the call
+    if (strm) {
+        hdr = reinterpret_cast<StreamHeader*>(const_cast<float*>(s.clip)) - 1;
+        q_size = s.clip_len;                                                 // capacity + 1 (spsc.rs:12)
+        q_read = (uint32_t)__builtin_amdgcn_readfirstlane((int)hdr->read);   // only lane 0 ever stores it
+        const uint32_t write = (uint32_t)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(&hdr->write, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM));
+        q_len = write >= q_read ? write - q_read : write + q_size - q_read; // update(): readable_len, spsc.rs:218-225
+        if (q_len < d.stream_len) q_len = d.stream_len;                      // never shrinks (debug_assert, spsc.rs:131)
+        if (__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(&hdr->closed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM))) d.stream_stopping = 1u;   // :71-73
+    }
     // Gain: Smoothed::set when the shared target moved (gain.rs:106-109), then ramp or constant
     bool ramp[MAX_WRAP];
     float gconst[MAX_WRAP], step[MAX_WRAP];
+    bool any_ramp = false;
 #pragma unroll
     for (uint32_t w = 0; w < MAX_WRAP; ++w) {
         ramp[w] = false; gconst[w] = 1.0f; step[w] = 0.0f;
@@ -463,11 +170,15 @@ __device__ __forceinline__ void inner_sample_wave(const BufStatic& s, BufDyn& d,
                 d.sm_progress[w] = 0.0f;
             }
             ramp[w] = d.sm_progress[w] != 1.0f;
+            any_ramp = any_ramp || ramp[w];
             gconst[w] = d.sm_prev[w] + d.sm_progress[w] * (d.sm_next[w] - d.sm_prev[w]);
             step[w] = level_interval[w] / 0.1f;                       // SMOOTHING_PERIOD, gain.rs:163
         }
     }
-    // running sums: lane 0 the leaf cursor, lane 1 + w the progress of Gain w
+    // running sums: lane 0 the leaf cursor (FramesSignal slow path, Cycle), lane 1 + w the progress of Gain w; a chain
+    // with no running sum at all (fast path, Stream, Sine, Constant, settled gains) skips the scan
+    const bool cursor = (frm && !fast) || cyc;
+    const bool any_scan = cursor || any_ramp;                                // wave-uniform
     const bool is_gain = lane >= 1 && lane <= MAX_WRAP;
     float scan = 0.0f, inc = 0.0f;
     if (lane == 0) { scan = frac0; inc = ds; }
@@ -476,61 +187,84 @@ __device__ __forceinline__ void inner_sample_wave(const BufStatic& s, BufDyn& d,
     for (uint32_t p0 = 0; p0 < n; p0 += 1024u) {
         const uint32_t m = (n - p0) < 1024u ? (n - p0) : 1024u;
         const uint32_t nb = (m + 15u) / 16u;
-        if (lane == 0 && cyc) {
-            for (uint32_t b = 0; b < nb; ++b) {
-                ck[0][b] = coff;
-                ck[5][b] = __uint_as_float(cbase);
-                const uint32_t cnt = (m - 16u * b) < 16u ? (m - 16u * b) : 16u;
-                for (uint32_t i = 0; i < cnt; ++i) { uint32_t ia, ib; float fr; cycle_step(cbase, coff, s.clip_len, ds, ia, ib, fr); }
-            }
-        } else if (lane <= MAX_WRAP) {
-            for (uint32_t b = 0; b < nb; ++b) {
-                ck[lane][b] = scan;
-                const uint32_t cnt = (m - 16u * b) < 16u ? (m - 16u * b) : 16u;
-                for (uint32_t i = 0; i < cnt; ++i) {
-                    const float v = scan + inc;
-                    scan = is_gain ? fminf(v, 1.0f) : v;
+        if (any_scan) {
+            if (lane == 0 && cyc) {
+                for (uint32_t b = 0; b < nb; ++b) {
+                    ck[0][b] = coff;
+                    ck[5][b] = __uint_as_float(cbase);
+                    const uint32_t cnt = (m - 16u * b) < 16u ? (m - 16u * b) : 16u;
+                    for (uint32_t i = 0; i < cnt; ++i) { uint32_t ia, ib; float fr; cycle_step(cbase, coff, s.clip_len, ds, ia, ib, fr); }
+                }
+            } else if (lane <= MAX_WRAP) {
+                for (uint32_t b = 0; b < nb; ++b) {
+                    ck[lane][b] = scan;
+                    const uint32_t cnt = (m - 16u * b) < 16u ? (m - 16u * b) : 16u;
+                    for (uint32_t i = 0; i < cnt; ++i) {
+                        const float v = scan + inc;
+                        scan = is_gain ? fminf(v, 1.0f) : v;
+                    }
                 }
             }
+            wg_sync();
         }
-        wg_sync();
         if (16u * (uint32_t)lane < m) {
             const uint32_t f0 = p0 + 16u * (uint32_t)lane;
             const uint32_t cnt = (m - 16u * (uint32_t)lane) < 16u ? (m - 16u * (uint32_t)lane) : 16u;
-            float off = ck[0][lane];
+            float off = cursor ? ck[0][lane] : 0.0f;
             uint32_t cb_ = cyc ? __float_as_uint(ck[5][lane]) : 0u;
             float pr[MAX_WRAP];
 #pragma unroll
-            for (int w = 0; w < MAX_WRAP; ++w) pr[w] = ck[1 + w][lane];
+            for (int w = 0; w < MAX_WRAP; ++w) pr[w] = ramp[w] ? ck[1 + w][lane] : 1.0f;
             for (uint32_t k = 0; k < cnt; ++k) {
-                float a, b, fr;
+                float v0, v1 = 0.0f;
                 if (cyc) {                                                                         // cycle.rs:30-50
                     uint32_t ia, ib;
+                    float fr;
                     cycle_step(cb_, off, s.clip_len, ds, ia, ib, fr);
-                    a = s.clip[ia]; b = s.clip[ib];
-                } else {
+                    const float a = s.clip[(size_t)ia * C], b = s.clip[(size_t)ib * C];
+                    v0 = a + fr * (b - a);
+                    if (C == 2u) { const float a1 = s.clip[(size_t)ia * 2 + 1], b1 = s.clip[(size_t)ib * 2 + 1]; v1 = a1 + fr * (b1 - a1); }
+                } else if (frm) {
                     long long idx;
+                    float fr;
                     if (fast) { idx = base + (long long)(f0 + k); fr = frac0; }                   // frames.rs:180-187
                     else { const long long tr = (long long)off; idx = base + tr; fr = off - (float)tr; off = off + ds; }   // :189-196
-                    a = clip_ch(s.clip, s.clip_len, 1u, 0u, idx); b = clip_ch(s.clip, s.clip_len, 1u, 0u, idx + 1);
+                    const float a = clip_ch(s.clip, s.clip_len, C, 0u, idx), b = clip_ch(s.clip, s.clip_len, C, 0u, idx + 1);
+                    v0 = a + fr * (b - a);
+                    if (C == 2u) { const float a1 = clip_ch(s.clip, s.clip_len, 2u, 1u, idx), b1 = clip_ch(s.clip, s.clip_len, 2u, 1u, idx + 1); v1 = a1 + fr * (b1 - a1); }
+                } else if (strm) {                                                                 // stream.rs:76-84
+                    const float sv = phase0 + ds * (float)(f0 + k);                                // :78
+                    const float x0f = truncf(sv);
+                    const long long x0 = f64_as_isize((double)x0f);                                // s.trunc() as isize
+                    const float fr = sv - x0f;                                                     // f32::fract
+                    const bool ina = x0 >= 0 && x0 < (long long)q_len, inb = x0 + 1 >= 0 && x0 + 1 < (long long)q_len;   // Stream::get: zero outside [0, len)
+                    const size_t xa = (size_t)((q_read + (uint32_t)x0) % q_size), xb = (size_t)((q_read + (uint32_t)(x0 + 1)) % q_size);
+                    const float a = ina ? s.clip[xa * C] : 0.0f, b = inb ? s.clip[xb * C] : 0.0f;
+                    v0 = a + fr * (b - a);
+                    if (C == 2u) { const float a1 = ina ? s.clip[xa * 2 + 1] : 0.0f, b1 = inb ? s.clip[xb * 2 + 1] : 0.0f; v1 = a1 + fr * (b1 - a1); }
+                } else if (sine) {                                                                 // sine.rs:34-38
+                    const float t = cur * (float)(f0 + k);
+                    v0 = sinf(t * s.freq_or_value + phase0);
+                } else {                                                                           // constant.rs:16-18
+                    v0 = s.freq_or_value; v1 = s.freq_or_value;
                 }
-                float v = a + fr * (b - a);
 #pragma unroll
                 for (uint32_t w = 0; w < MAX_WRAP; ++w) {
                     if (w >= s.n_wrap) continue;
-                    if (s.wrap_kind[w] == WRAP_FIXED_GAIN) v = v * s.wrap_param[w];              // gain.rs:32-37
+                    if (s.wrap_kind[w] == WRAP_FIXED_GAIN) { v0 = v0 * s.wrap_param[w]; v1 = v1 * s.wrap_param[w]; }   // gain.rs:32-37
                     else if (s.wrap_kind[w] == WRAP_GAIN) {                                       // gain.rs:110-121
                         if (ramp[w]) {
                             const float g = d.sm_prev[w] + pr[w] * (d.sm_next[w] - d.sm_prev[w]);
-                            v = v * g;
+                            v0 = v0 * g; v1 = v1 * g;
                             pr[w] = fminf(pr[w] + step[w], 1.0f);
-                        } else if (gconst[w] != 1.0f) v = v * gconst[w];
+                        } else if (gconst[w] != 1.0f) { v0 = v0 * gconst[w]; v1 = v1 * gconst[w]; }
                     }
                 }
-                out[f0 + k] = v;
+                if (C == 2u) { out[(size_t)(f0 + k) * 2] = v0; out[(size_t)(f0 + k) * 2 + 1] = v1; }
+                else out[f0 + k] = v0;
             }
         }
-        wg_sync();   // before the next pass overwrites the checkpoints
+        wg_sync();   // before the next pass overwrites the checkpoints; `out` is read back by other lanes (ring reads, Fader)
     }
 #pragma unroll
     for (int w = 0; w < MAX_WRAP; ++w) {
@@ -541,22 +275,117 @@ __device__ __forceinline__ void inner_sample_wave(const BufStatic& s, BufDyn& d,
         const uint32_t fb = (uint32_t)__builtin_amdgcn_readlane((int)cbase, 0);
         const float fo = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(coff), 0));
         d.common.t = (double)fb + (double)fo;
-    } else {
+    } else if (frm) {
         d.common.t = d.common.t + (double)cur * (double)n;                                        // frames.rs:198
+    } else if (strm) {   // advance(interval * out.len() as f32), stream.rs:59-64
+        const float next = phase0 + (cur * (float)n) * (float)s.clip_rate;
+        const float t = fminf(next, (float)q_len);
+        uint32_t rel = (uint32_t)f32_as_usize(t);
+        if (rel > q_len) rel = q_len;
+        if (rel && lane == 0) __hip_atomic_store(&hdr->read, (q_read + rel) % q_size, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);   // release(), spsc.rs:227-235
+        d.stream_len = q_len - rel;
+        d.common.phase = t - truncf(t);
+    } else if (sine) {
+        d.common.phase = fmodf(phase0 + (cur * (float)n) * s.freq_or_value, ODDIO_TAU);           // sine.rs:39
     }
 }
 
-// One wave per buffered slot; slots of other shapes are left to buffered_sources (skip_wave_shapes = 1 there).
+// Fader::sample (fader.rs:36-73), one wave.  Returns false when no fade is running and none is waiting: the caller
+// renders the plain signal (the fast path, fader.rs:37-45).  `scratch` holds FADER_BUF frames of the source's channel
+// count.  The fade's progress is a running f32 sum like a Gain's: lane 0 replays it and drops a checkpoint every 16
+// frames (ck row 6), the lanes then cross-fade the 16 frames they rendered themselves.
+__device__ __forceinline__ bool fader_sample_wave(BufStatic& st, BufDyn& dyn, FaderRec& F, float* scratch, float interval, float* out, uint32_t n,
+                                                  float (*ck)[64], int lane) {
+    const uint32_t C = st.channels == 2u ? 2u : 1u;
+    float progress = F.progress;
+    const bool refresh = progress >= 1.0f;
+    if (refresh && !F.pend.fresh) return false;
+    BufStatic nst;                                        // private copies, written back once
+    BufDyn ndyn;
+    float duration;
+    uint32_t next_gen;
+    if (refresh) { nst = F.pend.st; ndyn = F.pend.dyn; duration = F.pend.duration; next_gen = F.pend.gen; progress = 0.0f; }   // self.next.refresh()
+    else { nst = F.next_st; ndyn = F.next_dyn; duration = F.duration; next_gen = F.next_gen; }
+    wg_sync();                                            // every lane has read the record before lane 0 rewrites it
+    if (refresh && lane == 0) {
+        // received = pending, record to record in 16-byte pieces (assigned from the register copies, hipcc stages the
+        // structs through scratch memory)
+        const uint4* from_st = reinterpret_cast<const uint4*>(&F.pend.st);
+        const uint4* from_dyn = reinterpret_cast<const uint4*>(&F.pend.dyn);
+        uint4* to_st = reinterpret_cast<uint4*>(&F.next_st);
+        uint4* to_dyn = reinterpret_cast<uint4*>(&F.next_dyn);
+        for (uint32_t q = 0; q < sizeof(BufStatic) / 16; ++q) to_st[q] = from_st[q];
+        for (uint32_t q = 0; q < sizeof(BufDyn) / 16; ++q) to_dyn[q] = from_dyn[q];
+        F.duration = duration; F.next_gen = next_gen; F.pend.fresh = 0u;
+    }
+    const float increment = interval / duration;
+    uint32_t off = 0;
+    while (off < n) {
+        const uint32_t rem = n - off;
+        const uint32_t m = rem < FADER_BUF ? rem : FADER_BUF;
+        inner_sample_wave(st, dyn, interval, scratch, FADER_BUF, ck, lane);                    // the whole buffer, fader.rs:53
+        inner_sample_wave(nst, ndyn, interval, out + (size_t)off * C, rem, ck, lane);          // all that is left, :54
+        float pscan = progress;
+        if (lane == 0) {
+            for (uint32_t b = 0; 16u * b < m; ++b) {
+                ck[6][b] = pscan;
+                const uint32_t cnt = (m - 16u * b) < 16u ? (m - 16u * b) : 16u;
+                for (uint32_t i = 0; i < cnt; ++i) pscan = fminf(pscan + increment, 1.0f);
+            }
+        }
+        wg_sync();
+        if (16u * (uint32_t)lane < m) {
+            const uint32_t cnt = (m - 16u * (uint32_t)lane) < 16u ? (m - 16u * (uint32_t)lane) : 16u;
+            float p = ck[6][lane];
+            for (uint32_t k = 0; k < cnt; ++k) {
+                const uint32_t f = 16u * (uint32_t)lane + k;
+                const float fade_out = sqrtf(1.0f - p);
+                const float fade_in = sqrtf(p);
+                for (uint32_t ch = 0; ch < C; ++ch) {
+                    float* o = out + (size_t)(off + f) * C + ch;
+                    *o = scratch[(size_t)f * C + ch] * fade_out + *o * fade_in;                    // frame::mix(scale(x), scale(o))
+                }
+                p = fminf(p + increment, 1.0f);
+            }
+        }
+        progress = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(pscan)));
+        wg_sync();                                        // the next pass renders over what this one mixed
+        off += m;
+    }
+    if (lane == 0) F.progress = progress;
+    if (progress >= 1.0f) {   // mem::swap(&mut self.inner, &mut next.fade_to)
+        const BufStatic old_st = st;
+        const BufDyn old_dyn = dyn;
+        signal_assign(st, dyn, nst, ndyn);
+        if (lane == 0) {
+            signal_assign(F.next_st, F.next_dyn, old_st, old_dyn);
+            const uint32_t g = F.cur_gen; F.cur_gen = next_gen; F.next_gen = g;
+        }
+    } else if (lane == 0) {
+        // next.fade_to keeps what its sampler advanced (the record already holds every other field; a whole-struct store
+        // keeps those alive in scratch memory)
+        F.next_dyn.common.t = ndyn.common.t; F.next_dyn.common.phase = ndyn.common.phase;
+        F.next_dyn.stream_len = ndyn.stream_len; F.next_dyn.stream_stopping = ndyn.stream_stopping;
+#pragma unroll
+        for (int w = 0; w < MAX_WRAP; ++w) {
+            F.next_dyn.sm_prev[w] = ndyn.sm_prev[w]; F.next_dyn.sm_next[w] = ndyn.sm_next[w]; F.next_dyn.sm_progress[w] = ndyn.sm_progress[w];
+        }
+    }
+    return true;
+}
+
+// One wave per buffered slot, every shape the ABI accepts (leaf FramesSignal / Cycle / Stream / Sine / Constant under any
+// FixedGain / Gain / Speed chain, optionally inside a Fader).
 __global__ __launch_bounds__(64) void buffered_sources_wave(SceneParams P, const uint32_t* __restrict__ d_len_b, BufStatic* __restrict__ st,
                                                             BufDyn* __restrict__ dyn, SrcPending* __restrict__ pend,
                                                             float* __restrict__ contrib, uint32_t* __restrict__ skip,
-                                                            uint32_t* __restrict__ stopped_hdr, uint32_t stopped_cap) {
+                                                            uint32_t* __restrict__ stopped_hdr, uint32_t stopped_cap,
+                                                            FaderRec* __restrict__ faders, float* __restrict__ fader_scratch) {
     __shared__ float ck[8][64];
     const uint32_t i = blockIdx.x;
     const int lane = threadIdx.x;
     if (i >= d_len_b[0]) return;
-    const BufStatic s = st[i];
-    if (!buffered_wave_eligible(s)) return;
+    BufStatic s = st[i];
     BufDyn d = dyn[i];
     SrcDyn& c = d.common;
     if (c.flags & DYN_STOPPED) { if (lane == 0) skip[i] = 1; return; }
@@ -587,8 +416,13 @@ __global__ __launch_bounds__(64) void buffered_sources_wave(SceneParams P, const
     if (c.flags & DYN_HAS_FINISHED_FOR) {
         if (c.finished_for > distance / ODDIO_SPEED_OF_SOUND) c.flags |= DYN_STOPPED;
         else c.finished_for = c.finished_for + elapsed;
-    } else if (s.kind == KIND_FRAMES && c.t >= (double)(s.clip_len - 1u) / (double)s.clip_rate) {   // is_finished passes through the filters (a Cycle never finishes)
-        c.flags |= DYN_HAS_FINISHED_FOR; c.finished_for = elapsed;
+    } else {
+        bool fin = false;
+        if (!s.fader) {   // Fader::is_finished is always false (fader.rs:76-79); is_finished passes through the filters; a Cycle never finishes
+            if (s.kind == KIND_FRAMES) fin = c.t >= (double)(s.clip_len - 1u) / (double)s.clip_rate;
+            if (s.kind == KIND_STREAM) fin = d.stream_stopping && c.phase == (float)d.stream_len;       // stream.rs:88-90
+        }
+        if (fin) { c.flags |= DYN_HAS_FINISHED_FOR; c.finished_for = elapsed; }
     }
     __builtin_amdgcn_wave_barrier();
     if (lane == 0 && (pm.flags & PEND_FRESH)) pend[i].flags = 0;
@@ -609,12 +443,16 @@ __global__ __launch_bounds__(64) void buffered_sources_wave(SceneParams P, const
         const size_t start_idx = f32_as_usize(ceilf(d.ring_write));
         const size_t end_idx = f32_as_usize(ceilf(end));
         const float interval = 1.0f / (float)s.rate;
-        if (end_idx > start_idx) {
-            inner_sample_wave(s, d, interval, ring + start_idx, (uint32_t)(end_idx - start_idx), ck, lane);
-        } else {
-            inner_sample_wave(s, d, interval, ring + start_idx, (uint32_t)(len - start_idx), ck, lane);
-            inner_sample_wave(s, d, interval, ring, (uint32_t)end_idx, ck, lane);
+        // one or (when the write wraps) two stretches of the ring; one call site, so that the sampler is inlined once
+        const int n_seg = end_idx > start_idx ? 1 : 2;
+        for (int sg = 0; sg < n_seg; ++sg) {
+            float* o = sg == 0 ? ring + start_idx : ring;
+            const uint32_t cnt = n_seg == 1 ? (uint32_t)(end_idx - start_idx) : (sg == 0 ? (uint32_t)(len - start_idx) : (uint32_t)end_idx);
+            bool faded = false;
+            if (s.fader) faded = fader_sample_wave(s, d, faders[s.fader - 1u], fader_scratch + (size_t)(s.fader - 1u) * FADER_BUF, interval, o, cnt, ck, lane);
+            if (!faded) inner_sample_wave(s, d, interval, o, cnt, ck, lane);
         }
+        if (s.fader && lane == 0) st[i] = s;   // a completed fade swapped the signals
         d.ring_write = end;
     }
     wg_sync();   // the ring samples written above are read back by other lanes below

@@ -11,13 +11,13 @@
 
 namespace oddio_hip {
 
-// KIND_CYCLE: Mixer general path and the buffered set sample it thread-per-source; in the Seek set it is
+// KIND_CYCLE: Mixer general path and the buffered set sample it one wave per source; in the Seek set it is
 // rendered serially by `cycle_sources` into a contribution row that the mix kernel adds in set order
 // (SrcStatic::freq_or_value holds the row index as raw bits, SrcDyn::t the cursor in samples).
 // KIND_DOWNMIX: Downmix<FramesSignal<[f32;2]>> (downmix.rs) in the Seek set: interleaved stereo clip, each
 // channel interpolated and the two summed; rendered by the per-lane global-memory path of spatial_mix.
 // KIND_STREAM: Stream<T> (stream.rs): the SPSC ring lives in pinned, GPU-visible host memory (StreamHeader
-// followed by the samples); general (thread-per-source) paths only.
+// followed by the samples); general paths (Mixer, buffered set) only.
 enum : uint32_t { KIND_FRAMES = 0, KIND_SINE = 1, KIND_CONSTANT = 2, KIND_CYCLE = 3, KIND_DOWNMIX = 4, KIND_STREAM = 5 };
 
 // spsc.rs Header (:246-249) plus the "sender dropped" flag that Arc::strong_count provides there (:165-167).

@@ -276,64 +276,28 @@ __global__ __launch_bounds__(1024) void mixer_reduce(const float* __restrict__ p
     }
 }
 
-// ---- general path: any leaf (FramesSignal mono/stereo, Sine, Constant, Cycle) inside any chain of
-// FixedGain / Gain / Speed filters.  One thread per source replays Mixer::sample's per-source work
-// (mixer.rs:100-117) through the filter chain into the source's own slab; mixer_general_reduce then
-// adds the slabs in reverse slot order (bit-identical sum order).  Correctness first, not tuned.
-__global__ __launch_bounds__(64) void mixer_general_sources(uint32_t n_sources, uint32_t n_frames, float interval,
-                                                            BufStatic* __restrict__ st, BufDyn* __restrict__ dyn,
-                                                            float* __restrict__ slabs, uint32_t* __restrict__ skip,
-                                                            uint32_t* __restrict__ stopped_hdr, uint32_t stopped_cap,
-                                                            FaderRec* __restrict__ faders, float* __restrict__ fader_scratch, int skip_wave_shapes) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_sources) return;
-    BufDyn d = dyn[i];
-    BufStatic s = st[i];
-    if (skip_wave_shapes && buffered_wave_eligible(s)) return;   // mixer_general_sources_wave renders these
-    if (d.common.flags & MIXDYN_STOPPED) { skip[i] = 1; return; }
-    bool fin = (d.common.flags & MIXDYN_STOP_REQUESTED) != 0;                                                   // mixer.rs:102
-    if (!s.fader) {   // Fader::is_finished is always false (fader.rs:76-79)
-        if (s.kind == KIND_FRAMES) fin = fin || d.common.t >= (double)(s.clip_len - 1u) / (double)s.clip_rate;      // frames.rs:204-206
-        if (s.kind == KIND_STREAM) fin = fin || (d.stream_stopping && d.common.phase == (float)d.stream_len);       // stream.rs:88-90
-    }
-    if (fin) {
-        d.common.flags |= MIXDYN_STOPPED;
-        const uint32_t k = atomicAdd(&stopped_hdr[0], 1u);
-        if (k < stopped_cap) stopped_hdr[1 + k] = d.common.id;
-        skip[i] = 1;
-        dyn[i] = d;
-        return;
-    }
-    skip[i] = 0;
-    const uint32_t C = s.channels ? s.channels : 1u;
-    float* my = slabs + (size_t)i * 2 * n_frames;
-    for (uint32_t done = 0; done < n_frames; done += 1024u) {                                                   // mixer.rs:109-117
-        const uint32_t len = (n_frames - done) < 1024u ? (n_frames - done) : 1024u;
-        if (s.fader) fader_sample(s, d, faders[s.fader - 1u], fader_scratch + (size_t)(s.fader - 1u) * FADER_BUF * 2u, interval, my + (size_t)done * C, len);
-        else inner_sample(s, d, interval, my + (size_t)done * C, len);
-    }
-    dyn[i] = d;
-    if (s.fader) st[i] = s;   // a completed fade swapped the signals
-}
-
-// The common general shape -- filters over a mono FramesSignal (MonoToStereo<Gain<FramesSignal>>, ...) -- one wave per
-// source: scanner lanes replay the exact f32 running sums (leaf cursor, Gain progress) and drop a checkpoint every
-// 16 frames, then 64 lanes expand 16 frames each (inner_sample_wave, buffered_kernels.h).  Same per-source sequence
-// as mixer_general_sources (mixer.rs:100-117), same slab, bit-identical samples.
+// ---- general path: any leaf (FramesSignal mono/stereo, Sine, Constant, Cycle, Stream) inside any chain of
+// FixedGain / Gain / Speed filters, optionally inside a Fader.  One wave per source replays Mixer::sample's per-source
+// work (mixer.rs:100-117) through the filter chain into the source's own slab (inner_sample_wave / fader_sample_wave,
+// buffered_kernels.h); mixer_general_reduce then adds the slabs in reverse slot order (bit-identical sum order).
+// One wave per general-path source: every shape the ABI accepts (mono or stereo leaf under any filter chain, Fader).
 __global__ __launch_bounds__(64) void mixer_general_sources_wave(uint32_t n_sources, uint32_t n_frames, float interval,
-                                                                 const BufStatic* __restrict__ st, BufDyn* __restrict__ dyn,
+                                                                 BufStatic* __restrict__ st, BufDyn* __restrict__ dyn,
                                                                  float* __restrict__ slabs, uint32_t* __restrict__ skip,
-                                                                 uint32_t* __restrict__ stopped_hdr, uint32_t stopped_cap) {
+                                                                 uint32_t* __restrict__ stopped_hdr, uint32_t stopped_cap,
+                                                                 FaderRec* __restrict__ faders, float* __restrict__ fader_scratch) {
     __shared__ float ck[8][64];
     const uint32_t i = blockIdx.x;
     const int lane = threadIdx.x;
     if (i >= n_sources) return;
-    const BufStatic s = st[i];
-    if (!buffered_wave_eligible(s)) return;
+    BufStatic s = st[i];
     BufDyn d = dyn[i];
     if (d.common.flags & MIXDYN_STOPPED) { if (lane == 0) skip[i] = 1; return; }
-    const bool fin = (d.common.flags & MIXDYN_STOP_REQUESTED) != 0                                                  // mixer.rs:102
-                     || (s.kind == KIND_FRAMES && d.common.t >= (double)(s.clip_len - 1u) / (double)s.clip_rate);   // frames.rs:204-206 (a Cycle never finishes)
+    bool fin = (d.common.flags & MIXDYN_STOP_REQUESTED) != 0;                                                       // mixer.rs:102
+    if (!s.fader) {   // Fader::is_finished is always false (fader.rs:76-79); a Cycle, a Sine, a Constant never finish
+        if (s.kind == KIND_FRAMES) fin = fin || d.common.t >= (double)(s.clip_len - 1u) / (double)s.clip_rate;      // frames.rs:204-206
+        if (s.kind == KIND_STREAM) fin = fin || (d.stream_stopping && d.common.phase == (float)d.stream_len);       // stream.rs:88-90
+    }
     if (fin) {
         if (lane == 0) {
             d.common.flags |= MIXDYN_STOPPED;
@@ -345,18 +309,25 @@ __global__ __launch_bounds__(64) void mixer_general_sources_wave(uint32_t n_sour
         return;
     }
     if (lane == 0) skip[i] = 0;
+    const uint32_t C = s.channels == 2u ? 2u : 1u;
     float* my = slabs + (size_t)i * 2 * n_frames;
     for (uint32_t done = 0; done < n_frames; done += 1024u) {                                                       // mixer.rs:109-117
         const uint32_t len = (n_frames - done) < 1024u ? (n_frames - done) : 1024u;
-        inner_sample_wave(s, d, interval, my + done, len, ck, lane);
+        bool faded = false;
+        if (s.fader) faded = fader_sample_wave(s, d, faders[s.fader - 1u], fader_scratch + (size_t)(s.fader - 1u) * FADER_BUF * 2u, interval, my + (size_t)done * C, len, ck, lane);
+        if (!faded) inner_sample_wave(s, d, interval, my + (size_t)done * C, len, ck, lane);
     }
-    if (lane == 0) {   // what inner_sample_wave advances (a whole-struct store keeps the untouched fields alive in scratch)
-        dyn[i].common.t = d.common.t;
+    if (lane == 0) {   // what the samplers advance (a whole-struct store keeps the untouched fields alive in scratch)
+        dyn[i].common.t = d.common.t; dyn[i].common.phase = d.common.phase;
+        dyn[i].stream_len = d.stream_len; dyn[i].stream_stopping = d.stream_stopping;
 #pragma unroll
-        for (int w = 0; w < MAX_WRAP; ++w) { dyn[i].sm_prev[w] = d.sm_prev[w]; dyn[i].sm_next[w] = d.sm_next[w]; dyn[i].sm_progress[w] = d.sm_progress[w]; }
+        for (int w = 0; w < MAX_WRAP; ++w) {
+            dyn[i].shared[w] = d.shared[w];   // (a completed fade brings the new signal's targets with it)
+            dyn[i].sm_prev[w] = d.sm_prev[w]; dyn[i].sm_next[w] = d.sm_next[w]; dyn[i].sm_progress[w] = d.sm_progress[w];
+        }
+        if (s.fader) st[i] = s;   // a completed fade swapped the signals
     }
 }
-
 __global__ void mixer_general_reduce(const float* __restrict__ slabs, const uint32_t* __restrict__ skip, const BufStatic* __restrict__ st,
                                      uint32_t n_sources, uint32_t n_frames, float* __restrict__ out, int postfx) {
     const uint32_t o = blockIdx.x * blockDim.x + threadIdx.x;

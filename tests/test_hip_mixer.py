@@ -200,7 +200,7 @@ def test_mixer_general_many_sources(mode):
             og = oc.Gain(oc.MonoToStereo(oc.FixedGain(oc.FramesSignal(oc.Frames(rate, clip), t0), -3.0)))
             ctl.append((gh, og, "gain"))
             control.play(sig); cm.play(og)
-    # shapes outside the wave kernel (thread-per-source): Constant leaf, stereo clip, Cycle
+    # shapes that were rendered one thread per source until round 3: Constant leaf, stereo clip, Cycle
     gh, sig = oa.Gain.new(oa.MonoToStereo(oa.Constant(0.125))); og = oc.Gain(oc.MonoToStereo(oc.Constant(0.125)))
     ctl.append((gh, og, "gain")); control.play(sig); cm.play(og)
     stereo = np.stack([synth.noise_clip(22, 0, 9000), synth.noise_clip(22, 1, 9000)], axis=1)

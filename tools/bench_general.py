@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """Timing of the paths beside the headline one: buffered spatial sources, the Mixer's general path, Seek-set Cycle
-sources (one wave per source since round 2).  Prints ms per 1024-frame callback through the host-output entry point
+sources (one wave per source since round 2; every shape since round 3).  Prints ms per 1024-frame callback through the host-output entry point
 (stream sync + 8 KiB D2H included) for a few set sizes."""
 import os
 import sys
@@ -61,6 +61,54 @@ def main():
             control.play_buffered(g, oa.SpatialOptions(sc["position"][i], sc["velocity"][i], 0.1), 100.0, 48000, 0.1)
         print(f"buffered spatial sources (Gain<Cycle>): {n_src:5d} -> {time_calls(scene):8.3f} ms / 1024-frame callback")
         scene.close()
+
+    # the shapes that were rendered one thread per source until round 3: stereo clips, Sine / Constant / Stream leaves, Fader
+    stereo = oa.Frames.from_slice(48000, np.stack([synth.noise_clip(4, 0, 480000), synth.noise_clip(4, 1, 480000)], axis=1))
+    for n_src in (1, 64, 1024):
+        control, mixer = oa.Mixer(max_sources=1024, max_frames=1024)
+        for i in range(n_src):
+            gc, g = oa.Gain.new(oa.FramesSignal(stereo, 0.0))
+            control.play(g)
+        print(f"mixer general path (Gain<FramesSignal<[f32;2]>>): {n_src:5d} -> {time_calls(mixer):8.3f} ms / 1024-frame callback")
+        mixer.close()
+    for n_src in (1, 64, 1024):
+        control, mixer = oa.Mixer(max_sources=1024, max_frames=1024)
+        for i in range(n_src):
+            gc, g = oa.Gain.new(oa.MonoToStereo(oa.Sine(0.1 * i, 110.0 + i)))
+            control.play(g)
+        print(f"mixer general path (Gain<MonoToStereo<Sine>>): {n_src:5d} -> {time_calls(mixer):8.3f} ms / 1024-frame callback")
+        mixer.close()
+    for n_src in (1, 64, 1024):
+        control, scene = oa.SpatialScene(max_sources=8192, max_frames=1024)
+        sc = synth.make_scene(7, n_src)
+        scene.reserve_buffered(n_src)
+        for i in range(n_src):
+            gc, g = oa.Gain.new(oa.Sine(0.1 * i, 110.0 + i))
+            control.play_buffered(g, oa.SpatialOptions(sc["position"][i], sc["velocity"][i], 0.1), 100.0, 48000, 0.1)
+        print(f"buffered spatial sources (Gain<Sine>): {n_src:5d} -> {time_calls(scene):8.3f} ms / 1024-frame callback")
+        scene.close()
+    for n_src in (1, 64):
+        control, mixer = oa.Mixer(max_sources=1024, max_frames=1024)
+        streams = []
+        for i in range(n_src):
+            sc_, st_ = oa.Stream.new(48000, 48000 * 2)
+            sc_.write(synth.noise_clip(8, i, 48000 * 2 - 8))
+            streams.append(sc_)
+            control.play(oa.MonoToStereo(st_))
+        print(f"mixer general path (MonoToStereo<Stream>, ring in pinned host memory): {n_src:5d} -> {time_calls(mixer, reps=10):8.3f} ms / 1024-frame callback")
+        mixer.close()
+    for n_src in (1, 64, 256):                                   # (a mixer holds at most 256 Faders)
+        control, mixer = oa.Mixer(max_sources=1024, max_frames=1024)
+        faders = []
+        for i in range(n_src):
+            fc, f = oa.Fader.new(oa.MonoToStereo(oa.FramesSignal(clip, 0.0)))
+            control.play(f)
+            faders.append(fc)
+        idle = time_calls(mixer)
+        for fc in faders:
+            fc.fade_to(oa.MonoToStereo(oa.FramesSignal(clip, 1.0)), 30.0)     # a fade that outlasts the measurement
+        print(f"mixer general path (Fader<MonoToStereo<FramesSignal>>): {n_src:5d} -> {idle:8.3f} ms idle, {time_calls(mixer):8.3f} ms while fading / 1024-frame callback")
+        mixer.close()
 
 
 if __name__ == "__main__":
