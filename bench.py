@@ -361,6 +361,8 @@ def main():
                          "peer-to-peer reduce (rank-ordered sum on rank 0; works with several ranks on one GPU)")
     ap.add_argument("--share-devices", action="store_true", help="smoke-testing on a box with fewer GPUs than ranks: rank r uses device r %% count")
     ap.add_argument("--reset-every", type=int, default=320, help="callbacks between host-side motion resets of all sources")
+    ap.add_argument("--event-stride", type=int, default=1,
+                    help="bracket spatial_mix with hipEvents on every n-th timed callback (default: every one)")
     ap.add_argument("--precondition-ms", type=float, default=200.0,
                     help="GPU clock pre-conditioning before the warm-up steps: this many ms of untimed callbacks of the workload "
                          "itself, after which every source is put back to its starting state, so that a short warm-up starts from "
@@ -464,14 +466,21 @@ def main():
         step_no = 0
     for _ in range(args.warmup):
         one_step()
-    scene.set_profiling(2)     # two hipEvents per callback, around spatial_mix (the roofline kernel), inside the timed region
+    # hipEvents around spatial_mix (the roofline kernel) inside the timed region, on every callback.  (A pair of events puts
+    # ~12 us of gaps around the kernel it brackets -- kernel trace of round 3: 7.5 + 5.9 us against 0.9 us between
+    # un-bracketed kernels -- but bracketing only every 4th callback did not pay: back to back the kernel itself runs
+    # 1.5 % slower, step 0.2594-0.2614 vs 0.2613-0.2624 ms, mix 0.2339-0.2356 vs 0.2311-0.2319, same box; --event-stride 4)
+    stride = max(1, args.event_stride)
+    n_samples = (args.steps + stride - 1) // stride
+    scene.set_profiling(1 + stride if stride >= 2 else 2)
     sync_all()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         one_step()
     sync_all()
     elapsed = time.perf_counter() - t0
-    hist = scene.kernel_ms_history(min(args.steps, 512))
+    hist = scene.kernel_ms_history(min(n_samples, 512))
+    assert len(hist) == min(n_samples, 512), (len(hist), n_samples)
     # the other stages of a callback (walk, reduce): a few untimed callbacks with events around every stage
     # (four per callback cost 3-6 us of command-processor time, tools/event_overhead.py; not inside `value`)
     scene.set_profiling(1)
@@ -581,7 +590,9 @@ def main():
                 "frac_callback": b_alg / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBPS,
                 "prepass_ms": float(stages[:, 0].mean()),
                 ("reduce_incl_collective_ms" if sharded else "reduce_ms"): float(stages[:, 2].mean()),
-                "stage_timing": "prepass/reduce: 8 untimed callbacks after the timed region; avg_kernel_ms: every timed callback",
+                "stage_timing": f"prepass/reduce: 8 untimed callbacks after the timed region; avg_kernel_ms: hipEvents around spatial_mix on every "
+                                f"{stride}-th timed callback ({len(hist)} samples)",
+                "kernel_samples": int(len(hist)), "event_stride": int(stride),
             },
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -252,7 +252,9 @@ int oddio_hip_scene_seek_all(oddio_hip_scene* scene, float seconds);
 /* Per-kernel timing of the most recent *_sample* call, measured with hipEvents on the scene's
  * stream (milliseconds): [0] prepass, [1] mix, [2] reduce+postfx.  Blocks until that call's work
  * has finished.  Enabled by oddio_hip_scene_set_profiling(scene, 1); with (scene, 2) only the mix kernel is
- * bracketed (two events per callback instead of four; [0] and [2] read 0). */
+ * bracketed (two events per callback instead of four; [0] and [2] read 0); with (scene, 1 + k), k >= 2, only the mix
+ * kernel of every k-th call is (an event pair costs the stream ~10 us of gaps around the kernel it brackets: a
+ * throughput measurement samples the kernel instead of bracketing every launch). */
 int oddio_hip_scene_set_profiling(oddio_hip_scene* scene, int enable);
 int oddio_hip_scene_last_kernel_ms(oddio_hip_scene* scene, float ms[3]);
 /* The same for up to `max_calls` most recent profiled calls (oldest first; ms is [n][3]); the

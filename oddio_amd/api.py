@@ -438,8 +438,9 @@ class _SceneSignal(Signal):
         _lib.check(_lib.lib().oddio_hip_scene_set_exact_updates(self._h, int(bool(wait_for_staging))))
 
     def set_profiling(self, on):
-        """False/0 off, True/1 events around every stage, 2 events around the mix kernel only."""
-        _lib.check(_lib.lib().oddio_hip_scene_set_profiling(self._h, 2 if on == 2 else int(bool(on))))
+        """False/0 off, True/1 events around every stage, 2 events around the mix kernel only, 1 + k (k >= 2): around the
+        mix kernel of every k-th call."""
+        _lib.check(_lib.lib().oddio_hip_scene_set_profiling(self._h, int(on) if int(on) >= 2 else int(bool(on))))
 
     def last_kernel_ms(self):
         ms = (C.c_float * 3)()
