@@ -270,15 +270,9 @@ __device__ __forceinline__ double f64_rem_euclid(double a, double b) {   // core
 #ifndef ODDIO_MIX_DEPTH
 #define ODDIO_MIX_DEPTH 1
 #endif
-#ifndef ODDIO_MIX_PREFETCH
-#define ODDIO_MIX_PREFETCH 1
-#endif
 #ifndef ODDIO_WIN_POLICY
 #define ODDIO_WIN_POLICY " nt"    // cache policy of the window loads: streaming -- every sample is read once per callback (same box, spatial_mix:
                                  // default policy 0.2343 / 0.2284 ms, nt 0.2253 / 0.2265, sc1 0.2337 / 0.2334; profiles/r03_ab_window_policy.txt)
-#endif
-#ifndef ODDIO_STORE_VARIANT
-#define ODDIO_STORE_VARIANT 0
 #endif
 
 constexpr int MIX_WG_WAVES = ODDIO_MIX_WG_WAVES;       // waves per workgroup
@@ -905,16 +899,8 @@ __device__ __forceinline__ void rows_transpose(const float (&acc)[16], float4 (&
 #undef ODDIO_PICK
 }
 __device__ __forceinline__ void rows_store(const float4 (&o)[4], unsigned char* p) {
-#if ODDIO_STORE_VARIANT == 2      // experiment: no row stores at all (the kernel's compute floor; wrong results)
-    asm volatile("" :: "v"(o[0].x), "v"(o[1].y), "v"(o[2].z), "v"(o[3].w), "v"(p));
-#elif ODDIO_STORE_VARIANT == 1    // streaming (non-temporal) stores
-    typedef float f32x4 __attribute__((ext_vector_type(4)));
 #pragma unroll
-    for (int k = 0; k < 4; ++k) { f32x4 t = {o[k].x, o[k].y, o[k].z, o[k].w}; __builtin_nontemporal_store(t, reinterpret_cast<f32x4*>(p + k * 64)); }
-#else
-#pragma unroll
-    for (int k = 0; k < 4; ++k) *reinterpret_cast<float4*>(p + k * 64) = o[k];
-#endif
+    for (int k = 0; k < 4; ++k) *reinterpret_cast<float4*>(p + k * 64) = o[k];   // (non-temporal stores measured no different)
 }
 
 // grid = (n_workgroups, tiles of this pass); block = 64 * MIX_WG_WAVES.  Wave w walks groups [g_lo, g_hi) of
@@ -973,7 +959,7 @@ __global__ __launch_bounds__(64 * MIX_WG_WAVES, MIX_WAVES_PER_SIMD) void spatial
     const uint32_t row_off0 = (((uint32_t)eB * contrib_ncb + ((frame0 >> 4) & ~3u)) * MIX_GROUP) * 64u + 16u * (uint32_t)(lane & 3);   // == ((e * ncb/4 + quad) * 16) * 256 + 16 * i
 
     // The records of a group -- lanes 0-15: {descriptor words, info} of source `lane`; lane (j, e, c): the stream's
-    // {ds, g0, dg, wrel} and frac0 -- are fetched one group ahead (ODDIO_MIX_PREFETCH): the loads are issued during the
+    // {ds, g0, dg, wrel} and frac0 -- are fetched one group ahead: the loads are issued during the
     // first source of the group before and have landed long before the group boundary, and that group's last source
     // starts the first window of this one, so a boundary costs the cursor scan and nothing else.
 #define ODDIO_LOAD_GROUP(GG, V, Q, F)                                                                                     \
@@ -994,7 +980,7 @@ __global__ __launch_bounds__(64 * MIX_WG_WAVES, MIX_WAVES_PER_SIMD) void spatial
     uint4 pv = make_uint4(0u, 0u, 0u, 0u);
     float4 pq = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     float pf = 0.0f;
-    if (ODDIO_MIX_PREFETCH && g_hi > g_lo) ODDIO_LOAD_GROUP(g_hi - 1u, pv, pq, pf)
+    if (g_hi > g_lo) ODDIO_LOAD_GROUP(g_hi - 1u, pv, pq, pf)
     int buf = 0;
     bool pre_issued = false;     // the last source of the previous group already started this group's first window
     for (uint32_t g = g_hi; g-- > g_lo;) {
@@ -1004,9 +990,8 @@ __global__ __launch_bounds__(64 * MIX_WG_WAVES, MIX_WAVES_PER_SIMD) void spatial
         uint4 vdesc;
         float4 q;
         float frac0;
-        if (ODDIO_MIX_PREFETCH) { vdesc = pv; q = pq; frac0 = pf; }
-        else ODDIO_LOAD_GROUP(g, vdesc, q, frac0)
-        bool need_prefetch = ODDIO_MIX_PREFETCH && g > g_lo;
+        vdesc = pv; q = pq; frac0 = pf;
+        bool need_prefetch = g > g_lo;
         int laneA = lane;
         asm volatile("" : "+v"(laneA));
         const int cA = laneA & 1;
@@ -1079,7 +1064,7 @@ __global__ __launch_bounds__(64 * MIX_WG_WAVES, MIX_WAVES_PER_SIMD) void spatial
             nxt_info = (uint32_t)__builtin_amdgcn_readlane((int)vdesc.w, nxt);                                            \
             ODDIO_ISSUE_WINDOW(nxt, buf ^ 1)                                                                              \
             ODDIO_LANE_DATA(nxt, nx0, nt)                                                                                 \
-        } else if ((PRE) && ODDIO_MIX_PREFETCH && g > g_lo && fetched_before) {                                           \
+        } else if ((PRE) && g > g_lo && fetched_before) {                                           \
             /* last staged source of the group: the other window buffer is free for the next group's first window */     \
             const unsigned nm_ = (unsigned)__ballot((int)(pv.w & 7u) == PATH_LDS);                                        \
             if (nm_) { ODDIO_ISSUE_WINDOW_OF(pv, 31 - __builtin_clz(nm_), buf ^ 1) pre_issued = true; }                   \
@@ -1285,25 +1270,9 @@ constexpr int ORD_Q = 8;                      // quad steps (4 rows each) per re
     "v_add_f32_dpp %0, " V ", %0 quad_perm:[2,2,2,2] row_mask:0xf bank_mask:0xf\n\t" \
     "v_add_f32_dpp %0, " V ", %0 quad_perm:[1,1,1,1] row_mask:0xf bank_mask:0xf\n\t" \
     "v_add_f32_dpp %0, " V ", %0 quad_perm:[0,0,0,0] row_mask:0xf bank_mask:0xf\n\t"
-#ifndef ODDIO_ORD_VARIANT
-#define ODDIO_ORD_VARIANT 0
-#endif
 __device__ __forceinline__ void chain_add8(float& s, const float (&v)[8]) {
-#if ODDIO_ORD_VARIANT == 2
-#pragma unroll
-    for (int q = 0; q < 8; ++q) {
-        asm("v_add_f32_dpp %0, %1, %0 quad_perm:[3,3,3,3] row_mask:0xf bank_mask:0xf" : "+v"(s) : "v"(v[q]));
-        asm("v_add_f32_dpp %0, %1, %0 quad_perm:[2,2,2,2] row_mask:0xf bank_mask:0xf" : "+v"(s) : "v"(v[q]));
-        asm("v_add_f32_dpp %0, %1, %0 quad_perm:[1,1,1,1] row_mask:0xf bank_mask:0xf" : "+v"(s) : "v"(v[q]));
-        asm("v_add_f32_dpp %0, %1, %0 quad_perm:[0,0,0,0] row_mask:0xf bank_mask:0xf" : "+v"(s) : "v"(v[q]));
-    }
-#elif ODDIO_ORD_VARIANT == 1
-    asm volatile(ODDIO_DPP4("%1") ODDIO_DPP4("%2") ODDIO_DPP4("%3") ODDIO_DPP4("%4") ODDIO_DPP4("%5") ODDIO_DPP4("%6") ODDIO_DPP4("%7") ODDIO_DPP4("%8")
-        : "+v"(s) : "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "v"(v[4]), "v"(v[5]), "v"(v[6]), "v"(v[7]));
-#else
     asm(ODDIO_DPP4("%1") ODDIO_DPP4("%2") ODDIO_DPP4("%3") ODDIO_DPP4("%4") ODDIO_DPP4("%5") ODDIO_DPP4("%6") ODDIO_DPP4("%7") ODDIO_DPP4("%8")
         : "+v"(s) : "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "v"(v[4]), "v"(v[5]), "v"(v[6]), "v"(v[7]));
-#endif
 }
 #undef ODDIO_DPP4
 
