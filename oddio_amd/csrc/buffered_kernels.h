@@ -371,6 +371,7 @@ __device__ __forceinline__ bool fader_sample_wave(BufStatic& st, BufDyn& dyn, Fa
             F.next_dyn.sm_prev[w] = ndyn.sm_prev[w]; F.next_dyn.sm_next[w] = ndyn.sm_next[w]; F.next_dyn.sm_progress[w] = ndyn.sm_progress[w];
         }
     }
+    wg_sync();   // a second call in the same callback (the ring write wraps) reads the record lane 0 has just written
     return true;
 }
 

@@ -85,9 +85,12 @@ def test_fader_errors():
     mixer.close()
 
 
-def test_fader_as_buffered_spatial_source():
+@pytest.mark.parametrize("max_distance", [120.0, 9.0])
+def test_fader_as_buffered_spatial_source(max_distance):
     # play_buffered(Fader<FixedGain<FramesSignal>>) with fades while the source moves; a Gain-wrapped
-    # target, a Cycle target, a queued command that is replaced; plus a plain seekable neighbour
+    # target, a Cycle target, a queued command that is replaced; plus a plain seekable neighbour.
+    # max_distance 9 m: a ring of 6 060 samples, so the ring write wraps (two Fader::sample calls in one callback,
+    # ring.rs:33-38) while fades are running
     import oddio_amd as oa
     control, scene = oa.SpatialScene(max_sources=16, max_frames=2048)
     scene.set_mode(oa.MODE_ORDERED)
@@ -107,14 +110,15 @@ def test_fader_as_buffered_spatial_source():
     fc, f_h = oa.Fader.new(chain(oa, 0, db=-2.0))
     f_o = oc.Fader(chain(oc, 0, db=-2.0))
     pos, vel = np.float32([6.0, 1.0, -3.0]), np.float32([-9.0, 0.0, 2.0])
-    h_h = control.play_buffered(f_h, oa.SpatialOptions(pos, vel, 0.1), 120.0, 48000, 0.1)
-    h_o = ref.play_buffered(f_o, oc.SpatialOptions(pos, vel, 0.1), 120.0, 48000, 0.1)
+    h_h = control.play_buffered(f_h, oa.SpatialOptions(pos, vel, 0.1), max_distance, 48000, 0.1)
+    h_o = ref.play_buffered(f_o, oc.SpatialOptions(pos, vel, 0.1), max_distance, 48000, 0.1)
     control.play(chain(oa, 4), oa.SpatialOptions([2.0, 2.0, 2.0], [1.0, 0.0, 0.0]))
     ref.play(chain(oc, 4), oc.SpatialOptions([2.0, 2.0, 2.0], [1.0, 0.0, 0.0]))
     plan = {1: dict(i=1, rate=44100, dur=0.05),
             2: dict(i=2, gain=True, dur=0.4),            # waits, then is replaced by ...
             3: dict(i=3, cycle=True, db=3.0, dur=0.03),   # ... this one
-            8: dict(i=1, start=0.2, dur=0.08)}
+            8: dict(i=1, start=0.2, dur=0.08),
+            10: dict(i=2, rate=22050, dur=0.2)}            # still fading when the small ring wraps again
     for cb in range(13):
         if cb in plan:
             a = dict(plan[cb]); dur = a.pop("dur")
