@@ -361,6 +361,9 @@ def main():
                          "peer-to-peer reduce (rank-ordered sum on rank 0; works with several ranks on one GPU)")
     ap.add_argument("--share-devices", action="store_true", help="smoke-testing on a box with fewer GPUs than ranks: rank r uses device r %% count")
     ap.add_argument("--reset-every", type=int, default=320, help="callbacks between host-side motion resets of all sources")
+    ap.add_argument("--precondition-hold", type=int, default=32,
+                    help="reset every source to its start every n pre-conditioning callbacks, so that they run BASELINE's workload too "
+                         "(0: let the sources drift until the reset before the warm-up; measured 0-3 %% slower in the timed region, by box)")
     ap.add_argument("--event-stride", type=int, default=1,
                     help="bracket spatial_mix with hipEvents on every n-th timed callback (default: every one)")
     ap.add_argument("--precondition-ms", type=float, default=200.0,
@@ -452,8 +455,16 @@ def main():
         # the mix kernel is latency-bound enough to feel that (tools/ramp_probe.py).  Untimed callbacks of the workload
         # itself, then every source is put back where BASELINE's workload starts: clip cursors rewound, Motion reset.
         # (a fixed number of callbacks, ~0.3 ms each: the ranks of a sharded scene must all make the same calls)
+        hold = args.precondition_hold
         for k in range(int(args.precondition_ms / 0.3)):
             one_step()
+            if hold > 0 and k % hold == hold - 1:
+                # keep the pre-conditioning callbacks on BASELINE's workload too (left alone the sources fly apart and the
+                # windows shrink): every source back to its start, in stream order
+                control.set_motion_batch(g["ids"], g["spec"]["position"], g["spec"]["velocity"], True)
+                scene.seek_all(-float((step_no % span) * N_FRAMES) / RATE)
+                scene.sample_device(interval, out.data_ptr(), 0)
+                step_no = 0
             if k % 32 == 31:
                 scene.synchronize()
         # the reset is host work (a batch set_motion of every source): ~25 ms of callbacks are queued first, so that the
@@ -584,6 +595,7 @@ def main():
             "host_output_ms_per_step": host_ms,
             "ordered_mode_ms_per_step": ordered_ms,      # bit-exact (reference sum order) mode, same scene
             "precondition_ms": args.precondition_ms,
+            "precondition_hold": args.precondition_hold,
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
                 "traffic": traffic, "traffic_source": traffic_source,
