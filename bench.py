@@ -527,16 +527,17 @@ def main():
     if world == 1:
         import oddio_amd as oa
         scene.set_mode(oa.MODE_ORDERED)
-        for k in range(5):
+        n_warm, n_timed = 3, 8                 # (the first launches after the mode switch run slower: the sum's first 1.06 ms, then 0.79-0.84)
+        for k in range(n_warm + n_timed):
             if step_no % span == 0:
                 scene.seek_all(rewind_seconds)
-            if k == 1:
+            if k == n_warm:
                 scene.synchronize()
                 to0 = time.perf_counter()
             scene.sample_device(interval, out.data_ptr(), N_FRAMES)
             step_no += 1
         scene.synchronize()
-        ordered_ms = (time.perf_counter() - to0) / 4 * 1e3
+        ordered_ms = (time.perf_counter() - to0) / n_timed * 1e3
         scene.set_mode(oa.MODE_FAST)
 
     ranks_seen = 1
