@@ -47,12 +47,15 @@ enum { /* oddio_hip_scene_set_postfx */
 };
 
 enum { /* oddio_hip_scene_set_mode */
-    ODDIO_HIP_MODE_FAST = 0,    /* sources spread over the whole chip; deterministic tree sum */
+    ODDIO_HIP_MODE_FAST = 0,    /* sources spread over the whole chip; deterministic tree sum.  When a callback is
+                                   rendered by more than one wavefront (more than 16 sources) each running sum takes
+                                   `s * gain` with a fused multiply-add (one rounding where src/spatial.rs:460 has
+                                   two): within 1e-5 of the reference, not its bits -- use ORDERED for those */
     ODDIO_HIP_MODE_ORDERED = 1, /* the contributions are added in the reference's reverse-index order:
                                    bit-comparable with the sequential f32 sum of src/spatial.rs:204,460.
                                    Scenes: up to 1024 sources one wavefront walks the set; above that every
                                    source's contribution is rendered on the whole chip and a second kernel
-                                   adds the rows in order (about 10x the FAST callback; set_mode allocates
+                                   adds the rows in order (about 5.5x the FAST callback; set_mode allocates
                                    8 KiB per source slot for it, on the calling thread).  Mixers: one
                                    wavefront. */
 };

@@ -10,7 +10,7 @@ import sys
 path = sys.argv[1]
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 20
 after = int(sys.argv[3]) if len(sys.argv) > 3 else 16
-rows = [r for r in csv.DictReader(open(path)) if r["Kernel_Name"].startswith("void oddio_hip::spatial_mix<true, false>")]
+rows = [r for r in csv.DictReader(open(path)) if r["Kernel_Name"].startswith(("void oddio_hip::spatial_mix<true, false>", "void oddio_hip::spatial_mix<true, false, true>"))]
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 timed = rows[len(rows) - after - steps: len(rows) - after]
 print("launch,start_ns,duration_us,gap_before_us")
