@@ -48,9 +48,10 @@ enum { /* oddio_hip_scene_set_postfx */
 
 enum { /* oddio_hip_scene_set_mode */
     ODDIO_HIP_MODE_FAST = 0,    /* sources spread over the whole chip; deterministic tree sum.  When a callback is
-                                   rendered by more than one wavefront (more than 16 sources) each running sum takes
-                                   `s * gain` with a fused multiply-add (one rounding where src/spatial.rs:460 has
-                                   two): within 1e-5 of the reference, not its bits -- use ORDERED for those */
+                                   rendered by more than one wavefront (more than 16 sources) the lerp, the gain
+                                   ramp and the running sums use fused multiply-adds (one rounding where
+                                   src/frame.rs:39-41 and src/spatial.rs:459-460 have two): within 1e-5 of the
+                                   reference, not its bits -- use ORDERED for those */
     ODDIO_HIP_MODE_ORDERED = 1, /* the contributions are added in the reference's reverse-index order:
                                    bit-comparable with the sequential f32 sum of src/spatial.rs:204,460.
                                    Scenes: up to 1024 sources one wavefront walks the set; above that every

@@ -731,7 +731,8 @@ __device__ __forceinline__ void window_repack_padded(unsigned char* win_bytes, i
 // gives the sums of each inlined variant fresh registers and copies all 16 back at every join.
 // FUSED (FAST mode when a callback is rendered by more than one wave, i.e. when the sum is a tree anyway): acc = fma(v, g, acc),
 // one rounding where spatial.rs:460's `o += s * gain` has two -- one VALU op less per sample (0.233 -> 0.227 ms per launch
-// at the headline size, same box) and closer to the exact sum.  ORDERED mode, the contribution rows and single-wave
+// at the headline size, same box) and closer to the exact sum; the lerp and the gain ramp of those kernels are fused the same
+// way (mix_source_lds).  ORDERED mode, the contribution rows and single-wave
 // callbacks keep the reference's two roundings: the product, then the sum.
 template <bool FULL, bool FUSED>
 __device__ __forceinline__ void acc_add(float& acc, float v, float g, bool on) {
@@ -759,9 +760,9 @@ __device__ __forceinline__ void mix_source_lds(const unsigned char* win_bytes, i
         for (int i = 0; i < 16; ++i) {
             const int w1 = w0 + i + 1;
             const float bb = win[w1 + (w1 >> 4)];
-            float v = a + frac0 * (bb - a);
+            float v = FUSED ? __builtin_fmaf(frac0, bb - a, a) : a + frac0 * (bb - a);
             if (HAS_FG) v = v * fixed_gain;
-            acc_add<FULL, FUSED>(acc[i], v, g0 + fi[i] * dg, frame0 + (uint32_t)i < n_frames);
+            acc_add<FULL, FUSED>(acc[i], v, FUSED ? __builtin_fmaf(fi[i], dg, g0) : g0 + fi[i] * dg, frame0 + (uint32_t)i < n_frames);
             a = bb;
         }
         return;
@@ -792,9 +793,9 @@ __device__ __forceinline__ void mix_source_lds(const unsigned char* win_bytes, i
         // keeps hipcc from hoisting 16 gain values out of the loop (16 VGPRs -> scratch); placed before the lerp so that
         // the instruction after it does not read dg (hipcc pads an asm statement whose output is read next with s_nop)
         asm volatile("" : "+v"(dg));
-        float v = a[i] + fr[i] * (bb[i] - a[i]);              // frame.rs:39-41 lerp, unfused
+        float v = FUSED ? __builtin_fmaf(fr[i], bb[i] - a[i], a[i]) : a[i] + fr[i] * (bb[i] - a[i]);   // frame.rs:39-41 lerp (unfused in the exact kernels)
         if (HAS_FG) v = v * fixed_gain;                       // gain.rs:32-37
-        acc_add<FULL, FUSED>(acc[i], v, g0 + fi[i] * dg, frame0 + (uint32_t)i < n_frames);   // spatial.rs:459-460
+        acc_add<FULL, FUSED>(acc[i], v, FUSED ? __builtin_fmaf(fi[i], dg, g0) : g0 + fi[i] * dg, frame0 + (uint32_t)i < n_frames);   // spatial.rs:459-460
         __builtin_amdgcn_sched_barrier(0);
     }
 #undef ODDIO_ISSUE
