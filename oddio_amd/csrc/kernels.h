@@ -907,9 +907,13 @@ __device__ __forceinline__ void rows_transpose(const float (&acc)[16], float4 (&
 #undef ODDIO_PICK4
 #undef ODDIO_PICK
 }
-__device__ __forceinline__ void rows_store(const float4 (&o)[4], unsigned char* p) {
+// rows of sources J (o) and J + 1 (o1) for the four column blocks of the quad: column block k is the k-th 1-KiB block
+__device__ __forceinline__ void rows_store(const float4 (&o)[4], const float4 (&o1)[4], unsigned char* p) {
 #pragma unroll
-    for (int k = 0; k < 4; ++k) *reinterpret_cast<float4*>(p + k * 64) = o[k];   // (non-temporal stores measured no different)
+    for (int k = 0; k < 4; ++k) {
+        *reinterpret_cast<float4*>(p + k * (MIX_GROUP * 64)) = o[k];
+        *reinterpret_cast<float4*>(p + k * (MIX_GROUP * 64) + 64) = o1[k];
+    }
 }
 
 // grid = (n_workgroups, tiles of this pass); block = 64 * MIX_WG_WAVES.  Wave w walks groups [g_lo, g_hi) of
@@ -942,6 +946,7 @@ __global__ __launch_bounds__(64 * MIX_WG_WAVES, MIX_WAVES_PER_SIMD) void spatial
     const TileRec* __restrict__ trecs = recs + (size_t)blockIdx.y * rec_stride;
     const uint32_t n_frames = P.n_frames;
     float acc[16], fi[16];
+    float4 held_[4] = {};        // STORE: the rows of the odd source of a pair (rows_store)
     // phase-B role: ear e, chunk c (of the tile), block b -> 16 consecutive frames
     const int eB = lane >> 5, cB = (lane >> 4) & 1, bB = lane & 15;
     const uint32_t frame0 = tile * TILE_FRAMES + 16u * (uint32_t)(lane & 31);   // this lane's first output frame
@@ -965,7 +970,7 @@ __global__ __launch_bounds__(64 * MIX_WG_WAVES, MIX_WAVES_PER_SIMD) void spatial
     unsigned char* const blkB0 = smem + LDS_STREAM + (eB * 2 + cB) * (STREAM_WORDS * 4);
     constexpr int BLK_SRC = 4 * STREAM_WORDS * 4;            // bytes of stream blocks per source
     // STORE: this lane's byte offset inside a group's rows for source 0 (store_rows)
-    const uint32_t row_off0 = (((uint32_t)eB * contrib_ncb + ((frame0 >> 4) & ~3u)) * MIX_GROUP) * 64u + 16u * (uint32_t)(lane & 3);   // == ((e * ncb/4 + quad) * 16) * 256 + 16 * i
+    const uint32_t row_off0 = ((uint32_t)eB * contrib_ncb + ((frame0 >> 4) & ~3u)) * (MIX_GROUP * 64u) + 16u * (uint32_t)(lane & 3);   // 1-KiB block of (ear, first column block of the quad) + piece
 
     // The records of a group -- lanes 0-15: {descriptor words, info} of source `lane`; lane (j, e, c): the stream's
     // {ds, g0, dg, wrel} and frac0 -- are fetched one group ahead: the loads are issued during the
@@ -1100,10 +1105,13 @@ __global__ __launch_bounds__(64 * MIX_WG_WAVES, MIX_WAVES_PER_SIMD) void spatial
         // so that nothing waits for them, changes nothing: the kernel moves 3.3 GB in 0.65 ms, it is HBM bound.)
 #define ODDIO_EMIT(J)                                                                                                     \
     if (STORE) {                                                                                                          \
-        if (g * MIX_GROUP + (uint32_t)(J) < n_sources) {                                                                  \
+        /* rows leave in pairs: source J + 1 (odd) waits in registers for source J, and the two 64-byte rows of each */  \
+        /* column block are written back to back -- whole 128-byte lines */                                              \
+        if ((J) & 1) rows_transpose(acc, held_, lane);                                                                    \
+        else {                                                                                                            \
             float4 o_[4];                                                                                                 \
             rows_transpose(acc, o_, lane);                                                                                \
-            rows_store(o_, reinterpret_cast<unsigned char*>(contrib) + (size_t)g * 2u * contrib_ncb * (MIX_GROUP * 64u) + (row_off0 + 256u * (uint32_t)(J))); \
+            rows_store(o_, held_, reinterpret_cast<unsigned char*>(contrib) + (size_t)g * 2u * contrib_ncb * (MIX_GROUP * 64u) + (row_off0 + 64u * (uint32_t)(J))); \
         }                                                                                                                 \
         _Pragma("unroll") for (int k = 0; k < 16; ++k) acc[k] = 0.0f;                                                     \
     }
@@ -1305,11 +1313,11 @@ __global__ __launch_bounds__(64 * (1 + ORD_LOADERS)) void ordered_sum(const floa
     if (loader) {
         const uint32_t group_stride = 2u * contrib_ncb * 1024u;      // bytes from a group's chunk to the next group's
         // group 0: the 4-KiB chunk of this column block's quad, this column block's 64-byte rows 256 bytes apart
-        const unsigned char* chunk0 = reinterpret_cast<const unsigned char*>(contrib) + ((size_t)e * (contrib_ncb / 4u) + (cb >> 2)) * 4096u + (cb & 3u) * 64u;
+        const unsigned char* chunk0 = reinterpret_cast<const unsigned char*>(contrib) + ((size_t)e * contrib_ncb + cb) * 1024u;
         const uint32_t lds0 = (uint32_t)(uintptr_t)&ring[0][0][0];
         // the instruction offset (i * 1024) advances both the LDS and the memory address: the scalar offset adds the rest of i * group_stride
         const uint32_t so = group_stride - 1024u;
-        const int voff = (lane >> 2) * 256 + (lane & 3) * 16;      // lane = (row of the group, 16-byte piece)
+        const int voff = lane * 16;                                  // lane = (row of the group, 16-byte piece): a group's 16 rows are 1 KiB in a row
         constexpr int IN_FLIGHT = 6;                                 // this loader's tiles in flight after each wait (one more right after an issue)
         static_assert(8 * (IN_FLIGHT + 1) <= 63, "the tiles in flight fit the 6-bit VMEM counter");
         static_assert((IN_FLIGHT + 2) * ORD_LOADERS <= ORD_RING, "ring slots for everything in flight");
