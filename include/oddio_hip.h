@@ -57,7 +57,9 @@ enum { /* oddio_hip_scene_set_mode */
                                    Scenes: up to 1024 sources one wavefront walks the set; above that every
                                    source's contribution is rendered on the whole chip and a second kernel
                                    adds the rows in order (about 5.5x the FAST callback; set_mode allocates
-                                   8 KiB per source slot for it, on the calling thread).  Mixers: one
+                                   2 x 8 KiB per source slot for it, on the calling thread: back-to-back
+                                   oddio_hip_scene_sample_device calls on the scene's own stream overlap the
+                                   render of one callback with the sum of the one before).  Mixers: one
                                    wavefront. */
 };
 
