@@ -10,8 +10,9 @@ import sys
 
 summary, sources, out = sys.argv[1], int(sys.argv[2]), sys.argv[3]
 d = json.load(open(summary))
-# the accumulate instantiation (FAST mode), not spatial_mix<.., STORE> of the few ORDERED-mode callbacks: most dispatches
-k = max((k for k in d if k.startswith("spatial_mix")), key=lambda k: d[k].get("_dispatches") or 0)
+# the accumulate instantiations (FAST mode: spatial_mix<FULL, false, ..>), not spatial_mix<.., true, ..> = the row render of the
+# ORDERED-mode callbacks; of those the one with most dispatches
+k = max((k for k in d if k.startswith("spatial_mix<true, false") or k.startswith("spatial_mix<false, false")), key=lambda k: d[k].get("_dispatches") or 0)
 c = d[k]
 res = {
     "kernel": k, "sources": sources, "dispatches": c.get("_dispatches"),
