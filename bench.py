@@ -602,6 +602,9 @@ def main():
             "config": {
                 "workload": shape + f"Doppler + propagation delay, 48 kHz stereo, {N_FRAMES}-frame callbacks",
                 "sources_per_gpu": S, "frames_per_callback": N_FRAMES, "sample_rate": RATE, "clip_len": L,
+                "sum_mode": "FAST: deterministic tree sum over waves and workgroups, fused multiply-adds in the lerp / gain ramp / accumulate "
+                            "(within 1e-5 of the reference up to 4096 sources; `parity` has the figures at this size); the bit-exact ORDERED mode is "
+                            "timed in ordered_mode_ms_per_step / ordered_mode_latency_ms",
                 "parallelism": ("single-gpu" if world == 1 else ((f"source-sharded scene + stereo-buffer reduce ({args.reduce})") if sharded else "scene-parallel")),
                 "ranks_seen": ranks_seen,
             },
