@@ -156,10 +156,16 @@ impl HipSpatialScene {
         check(unsafe { oddio_hip_scene_set_postfx((self.0).0, postfx) });
         self
     }
-    /// The reference's sequential f32 sum, bit for bit (ODDIO_HIP_MODE_ORDERED): about 10x the cost of the default
+    /// The reference's sequential f32 sum, bit for bit (ODDIO_HIP_MODE_ORDERED): about 5.5x the cost of the default
     /// deterministic tree sum; allocates the per-source contribution rows on the calling thread.
     pub fn bit_exact(self) -> Self {
         check(unsafe { oddio_hip_scene_set_mode((self.0).0, 1) });
+        self
+    }
+    /// The tree sum with the reference's roundings in every contribution (ODDIO_HIP_MODE_FAST_UNFUSED): the default
+    /// mode fuses the lerp, the gain ramp and the accumulate of large scenes (within 1e-5 of the reference either way).
+    pub fn unfused(self) -> Self {
+        check(unsafe { oddio_hip_scene_set_mode((self.0).0, 2) });
         self
     }
     /// One logical scene split by source index over `world` GPUs (BASELINE configs[4]): every rank

@@ -61,6 +61,10 @@ enum { /* oddio_hip_scene_set_mode */
                                    oddio_hip_scene_sample_device calls on the scene's own stream overlap the
                                    render of one callback with the sum of the one before).  Mixers: one
                                    wavefront. */
+    ODDIO_HIP_MODE_FAST_UNFUSED = 2, /* scenes: FAST's tree sum with the reference's arithmetic in every contribution
+                                   (a + t*(b-a), prev_gain + i*d_gain, o += s*gain: each operation rounded by itself,
+                                   src/frame.rs:39-41, src/spatial.rs:459-460) -- what FAST was before round 3; ~3-6 %
+                                   slower per callback at 262 144 sources.  Mixers treat it as FAST. */
 };
 
 typedef struct oddio_hip_frames oddio_hip_frames; /* == Arc<Frames<f32>>, src/frames.rs:19-22 */

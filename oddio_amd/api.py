@@ -27,7 +27,7 @@ import numpy as np
 from . import _lib
 
 POSTFX_NONE, POSTFX_REINHARD, POSTFX_TANH = 0, 1, 2
-MODE_FAST, MODE_ORDERED = 0, 1
+MODE_FAST, MODE_ORDERED, MODE_FAST_UNFUSED = 0, 1, 2
 
 
 def _fp(a):
