@@ -501,6 +501,23 @@ def main():
     for _ in range(8):
         one_step()
     stages = scene.kernel_ms_history(8)
+    # the same kernel with the reference's arithmetic in every contribution (MODE_FAST_UNFUSED: no fused multiply-adds), untimed
+    import oddio_amd as _oa
+    # (on the workload of the timed region: every source put back where it started, the same warm-up, the same number of callbacks)
+    scene.set_mode(_oa.MODE_FAST_UNFUSED)
+    for _ in range(96):                    # (the reset is host work: keep the GPU loaded meanwhile, as before the timed region)
+        one_step()
+    control.set_motion_batch(g["ids"], g["spec"]["position"], g["spec"]["velocity"], True)
+    scene.seek_all(-float((step_no % span) * N_FRAMES) / RATE)
+    scene.sample_device(interval, out.data_ptr(), 0)
+    step_no = 0
+    for _ in range(args.warmup):
+        one_step()
+    scene.set_profiling(2)
+    for _ in range(args.steps):
+        one_step()
+    unfused_ms = float(scene.kernel_ms_history(min(args.steps, 512))[:, 1].mean())
+    scene.set_mode(_oa.MODE_FAST)
     scene.set_profiling(False)
     assert len(scene) == len(g["ids"]), "sources finished inside the timed region"
     assert bool(torch.isfinite(out).all()) and float(out.abs().max()) > 0.0
@@ -625,6 +642,8 @@ def main():
                 "stage_timing": f"prepass/reduce: 8 untimed callbacks after the timed region; avg_kernel_ms: hipEvents around spatial_mix on every "
                                 f"{stride}-th timed callback ({len(hist)} samples)",
                 "kernel_samples": int(len(hist)), "event_stride": int(stride),
+                "unfused_kernel_ms": unfused_ms,              # spatial_mix in MODE_FAST_UNFUSED, the timed region repeated after it (untimed)
+                "unfused_frac": b_alg / (unfused_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
             },
         }
         if world == 1 and not args.no_cpu_baseline:
