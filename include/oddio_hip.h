@@ -166,6 +166,34 @@ int oddio_hip_scene_play_buffered(oddio_hip_scene* scene, int leaf_kind, oddio_h
 int oddio_hip_source_set_gain(oddio_hip_scene* scene, uint32_t source_id, int filter_index, float amplitude_ratio);
 int oddio_hip_source_set_gain_db(oddio_hip_scene* scene, uint32_t source_id, int filter_index, float db);
 int oddio_hip_source_set_speed(oddio_hip_scene* scene, uint32_t source_id, int filter_index, float factor);
+/* GainControl::amplitude_ratio / gain (src/gain.rs:133-150: gain = 20 * log10(amplitude_ratio)) and
+ * SpeedControl::speed (src/speed.rs:47-49): the value the control last stored, or the one the filter
+ * was built with -- what the reference's relaxed load returns on the thread that stores. */
+int oddio_hip_source_get_amplitude_ratio(oddio_hip_scene* scene, uint32_t source_id, int filter_index, float* amplitude_ratio);
+int oddio_hip_source_get_gain_db(oddio_hip_scene* scene, uint32_t source_id, int filter_index, float* db);
+int oddio_hip_source_get_speed(oddio_hip_scene* scene, uint32_t source_id, int filter_index, float* factor);
+/* n x SpatialSceneControl::play_buffered(filters(FramesSignal::new(frames[i], start_seconds[i])), ..)
+ * (src/spatial.rs:314-340) under one lock, the rings from one stretch of device memory: how a scene
+ * with 10^5..10^6 Gain / Speed sources is populated.  The chain's filter kinds are shared;
+ * filter_params holds n_filters values per source ([n][n_filters], meaning as oddio_hip_filter.param). */
+int oddio_hip_scene_play_buffered_batch(oddio_hip_scene* scene, size_t n, oddio_hip_frames* const* frames,
+                                        const double* start_seconds, const int* filter_kinds, int n_filters,
+                                        const float* filter_params, const float* positions,
+                                        const float* velocities, const float* radii, float max_distance,
+                                        uint32_t rate, float buffer_duration, uint32_t* ids);
+/* n GainControl::set_amplitude_ratio / SpeedControl::set_speed stores (src/gain.rs:158-160,
+ * src/speed.rs:52-54) to filter `filter_index` of n buffered sources, under one lock. */
+int oddio_hip_scene_set_control_batch(oddio_hip_scene* scene, size_t n, const uint32_t* source_ids,
+                                      int filter_index, const float* values);
+/* Which kernels render the buffered set (results are identical): 1 (default) = the batched path for
+ * FramesSignal leaves under FixedGain / Gain / Speed chains (ring write 16 sources per wavefront, ring
+ * reads in the Seek set's mix kernel) with the general kernel for every other shape; 0 = the general
+ * one-wavefront-per-source kernel for everything (tests; env ODDIO_HIP_BUFFERED_FAST=0 at the first
+ * play_buffered does the same). */
+int oddio_hip_scene_set_buffered_fast(oddio_hip_scene* scene, int enable);
+/* (tests) the number of buffered sources the last callback of up to 1024 frames left to the general
+ * kernel (0 when every source took the batched path); waits for the scene's stream. */
+int oddio_hip_debug_buffered_slow(oddio_hip_scene* scene, uint32_t* n_slow);
 /* `scene.recv_buffered.len()` after the last sample call */
 int oddio_hip_scene_len_buffered(oddio_hip_scene* scene, size_t* len);
 
@@ -364,6 +392,10 @@ int oddio_hip_mixer_play_stream(oddio_hip_mixer* mixer, oddio_hip_stream* stream
 int oddio_hip_mixer_set_gain(oddio_hip_mixer* mixer, uint32_t source_id, int filter_index, float amplitude_ratio);
 int oddio_hip_mixer_set_gain_db(oddio_hip_mixer* mixer, uint32_t source_id, int filter_index, float db);
 int oddio_hip_mixer_set_speed(oddio_hip_mixer* mixer, uint32_t source_id, int filter_index, float factor);
+/* GainControl::amplitude_ratio / gain (src/gain.rs:133-150), SpeedControl::speed (src/speed.rs:47-49) */
+int oddio_hip_mixer_get_amplitude_ratio(oddio_hip_mixer* mixer, uint32_t source_id, int filter_index, float* amplitude_ratio);
+int oddio_hip_mixer_get_gain_db(oddio_hip_mixer* mixer, uint32_t source_id, int filter_index, float* db);
+int oddio_hip_mixer_get_speed(oddio_hip_mixer* mixer, uint32_t source_id, int filter_index, float* factor);
 /* Mixed::stop / Mixed::is_stopped (src/mixer.rs:34-43) */
 int oddio_hip_mixer_stop(oddio_hip_mixer* mixer, uint32_t source_id);
 int oddio_hip_mixer_is_stopped(oddio_hip_mixer* mixer, uint32_t source_id, int* stopped);

@@ -112,6 +112,16 @@ def lib():
         "oddio_hip_source_set_gain_db": (i32, [vp, u32, i32, f32]),
         "oddio_hip_source_set_speed": (i32, [vp, u32, i32, f32]),
         "oddio_hip_scene_len_buffered": (i32, [vp, C.POINTER(sz)]),
+        "oddio_hip_source_get_amplitude_ratio": (i32, [vp, u32, i32, fp]),
+        "oddio_hip_source_get_gain_db": (i32, [vp, u32, i32, fp]),
+        "oddio_hip_source_get_speed": (i32, [vp, u32, i32, fp]),
+        "oddio_hip_mixer_get_amplitude_ratio": (i32, [vp, u32, i32, fp]),
+        "oddio_hip_mixer_get_gain_db": (i32, [vp, u32, i32, fp]),
+        "oddio_hip_mixer_get_speed": (i32, [vp, u32, i32, fp]),
+        "oddio_hip_scene_play_buffered_batch": (i32, [vp, sz, vpp, C.POINTER(f64), C.POINTER(i32), i32, fp, fp, fp, fp, f32, u32, f32, u32p]),
+        "oddio_hip_scene_set_control_batch": (i32, [vp, sz, u32p, i32, fp]),
+        "oddio_hip_scene_set_buffered_fast": (i32, [vp, i32]),
+        "oddio_hip_debug_buffered_slow": (i32, [vp, u32p]),
         "oddio_hip_source_is_finished": (i32, [vp, u32, C.POINTER(i32)]),
         "oddio_hip_source_release": (i32, [vp, u32]),
         "oddio_hip_source_playback_position": (i32, [vp, u32, C.POINTER(f64)]),

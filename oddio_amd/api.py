@@ -192,7 +192,24 @@ class GainControl:
         self.set_amplitude_ratio(np.float32(_powf10(db)))
 
     def amplitude_ratio(self):
+        """GainControl::amplitude_ratio (src/gain.rs:147-150); through the C ABI once the signal has been played."""
+        if self._target is not None:
+            owner, sid, index = self._target
+            fn = _lib.lib().oddio_hip_mixer_get_amplitude_ratio if isinstance(owner, _MixerSignal) else _lib.lib().oddio_hip_source_get_amplitude_ratio
+            v = C.c_float()
+            _lib.check(fn(owner._h, sid, index, C.byref(v)))
+            return float(v.value)
         return float(self._ratio)
+
+    def gain(self):
+        """GainControl::gain (src/gain.rs:133-135): 20 * log10(amplitude_ratio), in decibels."""
+        if self._target is not None:
+            owner, sid, index = self._target
+            fn = _lib.lib().oddio_hip_mixer_get_gain_db if isinstance(owner, _MixerSignal) else _lib.lib().oddio_hip_source_get_gain_db
+            v = C.c_float()
+            _lib.check(fn(owner._h, sid, index, C.byref(v)))
+            return float(v.value)
+        return float(np.float32(20.0) * np.log10(self._ratio, dtype=np.float32))
 
 
 class SpeedControl:
@@ -214,6 +231,13 @@ class SpeedControl:
             _lib.check(fn(owner._h, sid, index, np.float32(factor)))
 
     def speed(self):
+        """SpeedControl::speed (src/speed.rs:47-49); through the C ABI once the signal has been played."""
+        if self._target is not None:
+            owner, sid, index = self._target
+            fn = _lib.lib().oddio_hip_mixer_get_speed if isinstance(owner, _MixerSignal) else _lib.lib().oddio_hip_source_get_speed
+            v = C.c_float()
+            _lib.check(fn(owner._h, sid, index, C.byref(v)))
+            return float(v.value)
         return float(self._speed)
 
 
@@ -423,6 +447,16 @@ class _SceneSignal(Signal):
         """Capacity of the buffered set (default 256); call before the first play_buffered."""
         _lib.check(_lib.lib().oddio_hip_scene_reserve_buffered(self._h, int(max_buffered)))
 
+    def debug_buffered_slow(self) -> int:
+        """(tests) buffered sources the last callback left to the general kernel."""
+        n = C.c_uint32()
+        _lib.check(_lib.lib().oddio_hip_debug_buffered_slow(self._h, C.byref(n)))
+        return n.value
+
+    def set_buffered_fast(self, enable: bool):
+        """Which kernels render the buffered set (identical results): the batched path (default) or the general kernel for everything."""
+        _lib.check(_lib.lib().oddio_hip_scene_set_buffered_fast(self._h, int(bool(enable))))
+
     def set_postfx(self, kind):
         _lib.check(_lib.lib().oddio_hip_scene_set_postfx(self._h, int(kind)))
 
@@ -562,6 +596,36 @@ class SpatialSceneControl:
             s._h, n, arr, st.ctypes.data_as(C.POINTER(C.c_double)), _fp(fg) if fg is not None else None,
             _fp(pos), _fp(vel), _fp(rad), ids.ctypes.data_as(C.POINTER(C.c_uint32))))
         return [Spatial(s, int(i)) for i in ids]
+
+    def play_buffered_frames_batch(self, frames_list, start_seconds, filter_kinds, filter_params, positions, velocities, radii,
+                                   max_distance: float, rate: int, buffer_duration: float):
+        """Bulk `play_buffered(filters(FramesSignal::new(frames[i], start[i])), ..)` (src/spatial.rs:314-340) for large scenes:
+        `filter_kinds` (innermost first: FILTER_FIXED_GAIN / FILTER_GAIN / FILTER_SPEED) is shared, `filter_params` is [n][len(kinds)].
+        Returns the handle ids (np.uint32); controls are addressed with set_control_batch(ids, filter_index, values)."""
+        n = len(frames_list)
+        s = self._scene
+        s._keep.extend(frames_list)
+        arr = (C.c_void_p * n)(*[f._h.value for f in frames_list])
+        st = np.ascontiguousarray(np.asarray(start_seconds, dtype=np.float64).reshape(n))
+        kinds = np.ascontiguousarray(np.asarray(filter_kinds, dtype=np.int32).reshape(-1))
+        nf = len(kinds)
+        par = np.ascontiguousarray(np.asarray(filter_params, dtype=np.float32).reshape(n, nf)) if nf else np.zeros((n, 1), np.float32)
+        pos = np.ascontiguousarray(np.asarray(positions, dtype=np.float32).reshape(n, 3))
+        vel = np.ascontiguousarray(np.asarray(velocities, dtype=np.float32).reshape(n, 3))
+        rad = np.ascontiguousarray(np.asarray(radii, dtype=np.float32).reshape(n))
+        ids = np.zeros(n, dtype=np.uint32)
+        _lib.check(_lib.lib().oddio_hip_scene_play_buffered_batch(
+            s._h, n, arr, st.ctypes.data_as(C.POINTER(C.c_double)), kinds.ctypes.data_as(C.POINTER(C.c_int32)), nf, _fp(par),
+            _fp(pos), _fp(vel), _fp(rad), np.float32(max_distance), int(rate), np.float32(buffer_duration),
+            ids.ctypes.data_as(C.POINTER(C.c_uint32))))
+        return ids
+
+    def set_control_batch(self, ids, filter_index: int, values):
+        """n GainControl::set_amplitude_ratio / SpeedControl::set_speed stores under one lock."""
+        ids = np.ascontiguousarray(np.asarray(ids, dtype=np.uint32))
+        vals = np.ascontiguousarray(np.asarray(values, dtype=np.float32).reshape(len(ids)))
+        _lib.check(_lib.lib().oddio_hip_scene_set_control_batch(self._scene._h, len(ids), ids.ctypes.data_as(C.POINTER(C.c_uint32)),
+                                                                 int(filter_index), _fp(vals)))
 
     def set_motion_batch(self, handles, positions, velocities, discontinuity: bool):
         if isinstance(handles, np.ndarray):

@@ -32,7 +32,7 @@ struct alignas(16) BufStatic {
     float wrap_param[MAX_WRAP];   // FixedGain: linear gain
     uint32_t channels;      // 1 (mono) or 2 (interleaved stereo clip; Mixer general path only)
     uint32_t fader;         // Mixer general path: 1 + index of this source's FaderRec (0: not a Fader)
-    uint32_t pad;
+    uint32_t flags;         // BUF_FAST_OK (buffered_fast.h): set at play_buffered for the shapes buffered_write renders
 };
 static_assert(sizeof(BufStatic) == 96, "BufStatic layout");
 
@@ -375,6 +375,94 @@ __device__ __forceinline__ bool fader_sample_wave(BufStatic& st, BufDyn& dyn, Fa
     return true;
 }
 
+// The rendering of one buffered source after its walk, one wave: Ring::write through the filter chain (ring.rs:18-41),
+// then Ring::sample per ear and 256-frame chunk (ring.rs:51-79, spatial.rs:409-431) into the source's slab row `my`
+// ([frame][ear], `s * gain`).  Every lane holds the same `s` / `d`; per ear: prev_offset, dt, g0, d_gain (spatial.rs:412-421).
+// Also keeps the mirror behind the ring's end (buffered_fast.h: the first RING_MIRROR samples repeated) up to date.
+constexpr uint32_t RING_MIRROR = 640;            // >= WIN_CAP + 4: a tile's window of spatial_mix<.., RING>, started anywhere before the ring's end
+__device__ __forceinline__ void buffered_render_wave(const SceneParams& P, BufStatic& s, BufDyn& d, float po0, float dt0, float g00, float dg0,
+                                                     float po1, float dt1, float g01, float dg1, float* __restrict__ my,
+                                                     FaderRec* __restrict__ faders, float* __restrict__ fader_scratch, float (*ck)[64], int lane) {
+    const float elapsed = P.elapsed;
+    const uint32_t n = P.n_frames;
+    float* ring = s.ring;
+    const uint32_t len = s.ring_len;
+    const float prev_offset[2] = {po0, po1}, dts[2] = {dt0, dt1}, g0s[2] = {g00, g01}, dgs[2] = {dg0, dg1};
+    {   // Ring::write (ring.rs:18-41): extend the delay queue with new data
+        const float end = fmodf(d.ring_write + elapsed * (float)s.rate, (float)len);
+        const size_t start_idx = f32_as_usize(ceilf(d.ring_write));
+        const size_t end_idx = f32_as_usize(ceilf(end));
+        const float interval = 1.0f / (float)s.rate;
+        // one or (when the write wraps) two stretches of the ring; one call site, so that the sampler is inlined once
+        const int n_seg = end_idx > start_idx ? 1 : 2;
+        for (int sg = 0; sg < n_seg; ++sg) {
+            float* o = sg == 0 ? ring + start_idx : ring;
+            const uint32_t cnt = n_seg == 1 ? (uint32_t)(end_idx - start_idx) : (sg == 0 ? (uint32_t)(len - start_idx) : (uint32_t)end_idx);
+            bool faded = false;
+            if (s.fader) faded = fader_sample_wave(s, d, faders[s.fader - 1u], fader_scratch + (size_t)(s.fader - 1u) * FADER_BUF, interval, o, cnt, ck, lane);
+            if (!faded) inner_sample_wave(s, d, interval, o, cnt, ck, lane);
+        }
+        d.ring_write = end;
+        if (n_seg == 2 || start_idx < RING_MIRROR) {   // the write touched the ring's first samples: repeat them behind its end
+            wg_sync();
+            for (uint32_t q = (uint32_t)lane; q < RING_MIRROR && q < len; q += 64u) ring[len + q] = ring[q];
+        }
+    }
+    wg_sync();   // the ring samples written above are read back by other lanes below
+
+    // Ring::sample (ring.rs:51-79) per ear and 256-frame chunk (spatial.rs:424): 4 chunks x 2 ears per pass
+    auto ring_step = [&](float& offset, float ds_, float& a, float& b, float& fract) {
+        size_t x = (size_t)offset;
+        fract = offset - (float)x;
+        if (x < (size_t)len - 1) { a = ring[x]; b = ring[x + 1]; }
+        else if (x < (size_t)len) { a = ring[x]; b = ring[0]; }
+        else {
+            x = x % len;
+            offset = (float)x + fract;
+            if (x < (size_t)len - 1) { a = ring[x]; b = ring[x + 1]; }
+            else { a = ring[x]; b = ring[0]; }
+        }
+        offset = offset + ds_;
+    };
+    for (uint32_t pass0 = 0; pass0 < n; pass0 += 1024u) {
+        if (lane < 8) {
+            const int e = lane >> 2;
+            const uint32_t done = pass0 + 256u * (uint32_t)(lane & 3);
+            if (done < n) {
+                const uint32_t clen = (n - done) < 256u ? (n - done) : 256u;
+                const float t = prev_offset[e] + (float)done * dts[e];                 // idx == done at the chunk's start (spatial.rs:424)
+                float offset = f32_rem_euclid(d.ring_write + t * (float)s.rate, (float)len);
+                const float ds_ = dts[e] * (float)s.rate;
+                for (uint32_t b = 0; b * 16u < clen; ++b) {
+                    ck[lane][b] = offset;
+                    const uint32_t cnt = (clen - 16u * b) < 16u ? (clen - 16u * b) : 16u;
+                    for (uint32_t k = 0; k < cnt; ++k) { float a, bb, fr; ring_step(offset, ds_, a, bb, fr); }
+                }
+            }
+        }
+        wg_sync();
+        for (int e = 0; e < 2; ++e) {
+            const int cq = lane >> 4, b = lane & 15;
+            const uint32_t done = pass0 + 256u * (uint32_t)cq;
+            const uint32_t f0 = done + 16u * (uint32_t)b;
+            if (f0 < n) {
+                const uint32_t clen = (n - done) < 256u ? (n - done) : 256u;
+                const uint32_t cnt = (clen - 16u * (uint32_t)b) < 16u ? (clen - 16u * (uint32_t)b) : 16u;
+                float offset = ck[e * 4 + cq][b];
+                const float ds_ = dts[e] * (float)s.rate;
+                for (uint32_t k = 0; k < cnt; ++k) {
+                    float a, bb, fr;
+                    ring_step(offset, ds_, a, bb, fr);
+                    const float v = a + fr * (bb - a);
+                    const float gain = g0s[e] + (float)(f0 + k) * dgs[e];              // spatial.rs:426
+                    my[2 * (f0 + k) + e] = v * gain;
+                }
+            }
+        }
+        wg_sync();
+    }
+}
+
 // One wave per buffered slot, every shape the ABI accepts (leaf FramesSignal / Cycle / Stream / Sine / Constant under any
 // FixedGain / Gain / Speed chain, optionally inside a Fader).
 __global__ __launch_bounds__(64) void buffered_sources_wave(SceneParams P, const uint32_t* __restrict__ d_len_b, BufStatic* __restrict__ st,
@@ -437,89 +525,19 @@ __global__ __launch_bounds__(64) void buffered_sources_wave(SceneParams P, const
         return;
     }
     if (lane == 0) skip[i] = 0;
-    float* ring = s.ring;
-    const uint32_t len = s.ring_len;
-    {   // Ring::write (ring.rs:18-41): extend the delay queue with new data
-        const float end = fmodf(d.ring_write + elapsed * (float)s.rate, (float)len);
-        const size_t start_idx = f32_as_usize(ceilf(d.ring_write));
-        const size_t end_idx = f32_as_usize(ceilf(end));
-        const float interval = 1.0f / (float)s.rate;
-        // one or (when the write wraps) two stretches of the ring; one call site, so that the sampler is inlined once
-        const int n_seg = end_idx > start_idx ? 1 : 2;
-        for (int sg = 0; sg < n_seg; ++sg) {
-            float* o = sg == 0 ? ring + start_idx : ring;
-            const uint32_t cnt = n_seg == 1 ? (uint32_t)(end_idx - start_idx) : (sg == 0 ? (uint32_t)(len - start_idx) : (uint32_t)end_idx);
-            bool faded = false;
-            if (s.fader) faded = fader_sample_wave(s, d, faders[s.fader - 1u], fader_scratch + (size_t)(s.fader - 1u) * FADER_BUF, interval, o, cnt, ck, lane);
-            if (!faded) inner_sample_wave(s, d, interval, o, cnt, ck, lane);
-        }
-        if (s.fader && lane == 0) st[i] = s;   // a completed fade swapped the signals
-        d.ring_write = end;
-    }
-    wg_sync();   // the ring samples written above are read back by other lanes below
-    float* my = contrib + (size_t)i * 2 * n;
-    float prev_offset[2], dts[2], g0s[2], dgs[2];
+    float po[2], dtv[2], g0v[2], dgv[2];
     for (int e = 0; e < 2; ++e) {   // spatial.rs:409-423
         float off0, g0, off1, g1;
         ear_state(p0, e, s.radius, off0, g0);
         ear_state(p1, e, s.radius, off1, g1);
-        prev_offset[e] = fmaxf(off0 - elapsed, -s.max_delay);
+        po[e] = fmaxf(off0 - elapsed, -s.max_delay);
         const float next_offset = fmaxf(off1, -s.max_delay);
-        dts[e] = (next_offset - prev_offset[e]) / nf;
-        dgs[e] = (g1 - g0) / nf;
-        g0s[e] = g0;
+        dtv[e] = (next_offset - po[e]) / nf;
+        dgv[e] = (g1 - g0) / nf;
+        g0v[e] = g0;
     }
-    // Ring::sample (ring.rs:51-79) per ear and 256-frame chunk (spatial.rs:424): 4 chunks x 2 ears per pass
-    auto ring_step = [&](float& offset, float ds_, float& a, float& b, float& fract) {
-        size_t x = (size_t)offset;
-        fract = offset - (float)x;
-        if (x < (size_t)len - 1) { a = ring[x]; b = ring[x + 1]; }
-        else if (x < (size_t)len) { a = ring[x]; b = ring[0]; }
-        else {
-            x = x % len;
-            offset = (float)x + fract;
-            if (x < (size_t)len - 1) { a = ring[x]; b = ring[x + 1]; }
-            else { a = ring[x]; b = ring[0]; }
-        }
-        offset = offset + ds_;
-    };
-    for (uint32_t pass0 = 0; pass0 < n; pass0 += 1024u) {
-        if (lane < 8) {
-            const int e = lane >> 2;
-            const uint32_t done = pass0 + 256u * (uint32_t)(lane & 3);
-            if (done < n) {
-                const uint32_t clen = (n - done) < 256u ? (n - done) : 256u;
-                const float t = prev_offset[e] + (float)done * dts[e];                 // idx == done at the chunk's start (spatial.rs:424)
-                float offset = f32_rem_euclid(d.ring_write + t * (float)s.rate, (float)len);
-                const float ds_ = dts[e] * (float)s.rate;
-                for (uint32_t b = 0; b * 16u < clen; ++b) {
-                    ck[lane][b] = offset;
-                    const uint32_t cnt = (clen - 16u * b) < 16u ? (clen - 16u * b) : 16u;
-                    for (uint32_t k = 0; k < cnt; ++k) { float a, bb, fr; ring_step(offset, ds_, a, bb, fr); }
-                }
-            }
-        }
-        wg_sync();
-        for (int e = 0; e < 2; ++e) {
-            const int cq = lane >> 4, b = lane & 15;
-            const uint32_t done = pass0 + 256u * (uint32_t)cq;
-            const uint32_t f0 = done + 16u * (uint32_t)b;
-            if (f0 < n) {
-                const uint32_t clen = (n - done) < 256u ? (n - done) : 256u;
-                const uint32_t cnt = (clen - 16u * (uint32_t)b) < 16u ? (clen - 16u * (uint32_t)b) : 16u;
-                float offset = ck[e * 4 + cq][b];
-                const float ds_ = dts[e] * (float)s.rate;
-                for (uint32_t k = 0; k < cnt; ++k) {
-                    float a, bb, fr;
-                    ring_step(offset, ds_, a, bb, fr);
-                    const float v = a + fr * (bb - a);
-                    const float gain = g0s[e] + (float)(f0 + k) * dgs[e];              // spatial.rs:426
-                    my[2 * (f0 + k) + e] = v * gain;
-                }
-            }
-        }
-        wg_sync();
-    }
+    buffered_render_wave(P, s, d, po[0], dtv[0], g0v[0], dgv[0], po[1], dtv[1], g0v[1], dgv[1], contrib + (size_t)i * 2 * n, faders, fader_scratch, ck, lane);
+    if (s.fader && lane == 0) st[i] = s;   // a completed fade swapped the signals
     if (lane == 0) dyn[i] = d;
 }
 

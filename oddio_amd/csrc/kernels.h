@@ -312,6 +312,9 @@ constexpr int LDS_STREAM = LDS_WIN1 + WIN_BYTES;
 constexpr int STREAM_WORDS = 20;
 constexpr int LDS_TOTAL = LDS_STREAM + 64 * STREAM_WORDS * 4;
 constexpr int SFLAG_NEG = 1, SFLAG_FAST_L = 2, SFLAG_FAST_R = 4, SFLAG_PAD = 8, SFLAG_FG = 16;
+// RING records (the ring reads of the buffered set, buffered_fast.h): a cursor of the tile may reach the ring's end
+// (ring.rs:66-74's rewrite); shares the bit of SFLAG_FG, which a ring record never carries
+constexpr int SFLAG_WRAP = 16;
 static_assert(WIN_BYTES % 16 == 0 && LDS_TOTAL % 16 == 0, "per-wave LDS slices and window buffers stay 16-byte aligned");
 static_assert(LDS_TOTAL <= 10240, "16 waves per CU need <= 10 KB of LDS each");
 static_assert(LDS_STREAM >= 16 * 64 * 4, "accumulator parking / cross-wave reduction use 4 KB at offset 0 and must not reach the stream blocks");
@@ -745,12 +748,33 @@ __device__ __forceinline__ void acc_add(float& acc, float v, float g, bool on) {
         else if (on) acc = acc + p;
     }
 }
-template <bool FULL, bool HAS_FG, bool NONNEG, bool PAD, bool FUSED>
+template <bool FULL, bool HAS_FG, bool NONNEG, bool PAD, bool FUSED, bool WRAP = false>
 __device__ __forceinline__ void mix_source_lds(const unsigned char* win_bytes, int wrel4, float x, int b, int fast, float frac0, float (&acc)[16],
                                                const float (&fi)[16], uint32_t frame0, uint32_t n_frames, float fixed_gain, float g0, float dg,
-                                               float ds, int win_samples, uint32_t* err) {
+                                               float ds, int win_samples, uint32_t* err, int ring_len = 0) {
     if (!FULL && frame0 >= n_frames) return;   // this lane's 16 frames lie past the end of `out`
     const float* win = reinterpret_cast<const float*>(win_bytes);
+    if (WRAP) {
+        // Ring::sample (ring.rs:59-78) for a lane whose cursor may pass the ring's end: `x >= len` rewrites the cursor to
+        // (x % len) + fract before the step.  The staged window is linear across the ring's end (the ring carries a mirror
+        // of its first samples behind its last one), so the LDS position of index x - len is that of x: only the cursor
+        // value changes.  Not pipelined: a few percent of the sources of a callback take this variant.
+        int wrel = wrel4 >> 2;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            int tr = (int)x;
+            const float fr = x - (float)tr;                                    // ring.rs:61 (from the cursor before the rewrite)
+            if (tr >= ring_len) { tr -= ring_len; x = (float)tr + fr; wrel += ring_len; }   // :66-68 (len <= x < 2 len)
+            const int w = wrel + tr;
+            float a = 0.0f, bb = 0.0f;
+            if (ODDIO_BOUNDS_CHECK(err, w >= 0 && w + 1 < win_samples, BOUNDS_WINDOW_INDEX, w, win_samples)) { a = win[w]; bb = win[w + 1]; }
+            x = x + ds;                                                        // :77
+            asm volatile("" : "+v"(dg));
+            const float v = FUSED ? __builtin_fmaf(fr, bb - a, a) : a + fr * (bb - a);
+            acc_add<FULL, FUSED>(acc[i], v, FUSED ? __builtin_fmaf(fi[i], dg, g0) : g0 + fi[i] * dg, frame0 + (uint32_t)i < n_frames);
+        }
+        return;
+    }
     if (PAD && fast) {
         // frames.rs:180-187 (|ds - 1| <= EPSILON): constant fract, consecutive pairs
         const int w0 = (wrel4 >> 2) + 16 * b;
@@ -886,6 +910,15 @@ __device__ __noinline__ void mix_source_rare(float* acc_lds, int lane, uint32_t 
     }
 }
 
+// RING: a buffered source that the general kernel rendered (buffered_sources_wave: every shape the fast path does not
+// take) left `s * gain` for both ears in its slab row [frame][ear]; it is added at the source's place in the walk.
+__device__ __noinline__ void mix_source_slab(float* acc_lds, int lane, uint32_t frame0, uint32_t n_frames, const float* __restrict__ row) {
+    const int eB = lane >> 5;
+#pragma unroll 1
+    for (int i = 0; i < 16; ++i)
+        if (frame0 + (uint32_t)i < n_frames) acc_lds[i * 64 + lane] = acc_lds[i * 64 + lane] + row[2 * (frame0 + (uint32_t)i) + eB];
+}
+
 // v_mov_b32_dpp quad_perm:[K,K,K,K]: every lane reads lane K of its group of four
 template <int K> __device__ __forceinline__ float quad_bcast(float v) {
     return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), K * 0x55, 0xf, 0xf, true));
@@ -926,7 +959,12 @@ __device__ __forceinline__ void rows_store(const float4 (&o)[4], const float4 (&
 // the quad][16 frames], i.e. a lane's 16 accumulators are one 64-byte row, the four rows a quad of lanes holds for one
 // source are 256 contiguous bytes (two whole 128-byte lines per source, written back to back) and everything a wave
 // writes while it walks a group lies within 2 * ncb KiB -- and ordered_sum then adds the rows in the reference's order.  `partials` / `init` are unused there.  contrib_ncb = column blocks per ear.
-template <bool FULL, bool STORE = false, bool FUSED = false>
+// RING: the records describe Ring::sample reads of the buffered set (buffered_fast.h): frac0 is the cursor's absolute
+// position in the ring, desc[2] the ring length (the window's byte count is 16 * nvec: a ring carries a mirror of its
+// first samples behind its end, so a window never needs clipping), SFLAG_WRAP marks sources whose cursors may pass the
+// ring's end, and an out-of-line source adds the slab row the general kernel rendered (P.cycle_rows = the slabs,
+// [slot][frame][ear]).  The non-RING instantiations compile to what they were before the flag existed.
+template <bool FULL, bool STORE = false, bool FUSED = false, bool RING = false>
 __global__ __launch_bounds__(64 * MIX_WG_WAVES, MIX_WAVES_PER_SIMD) void spatial_mix(SceneParams P, const SrcStatic* __restrict__ st,
                                                                                      const EarParams* __restrict__ ear,
                                                                                      const TileRec* __restrict__ recs, uint32_t rec_stride, uint32_t tile0,
@@ -1018,7 +1056,8 @@ __global__ __launch_bounds__(64 * MIX_WG_WAVES, MIX_WAVES_PER_SIMD) void spatial
         uint32_t cur_info = 0;
 #define ODDIO_ISSUE_WINDOW_OF(VD, JN, BUF)                                                                                \
     window_dma(lds_slice + (uint32_t)((BUF) ? LDS_WIN1 : LDS_WIN0), (uint32_t)__builtin_amdgcn_readlane((int)(VD).x, (JN)),  \
-               (uint32_t)__builtin_amdgcn_readlane((int)(VD).y, (JN)), (uint32_t)__builtin_amdgcn_readlane((int)(VD).z, (JN)), \
+               (uint32_t)__builtin_amdgcn_readlane((int)(VD).y, (JN)),                                                      \
+               RING ? 16u * (((uint32_t)__builtin_amdgcn_readlane((int)(VD).w, (JN)) >> 8) & 255u) : (uint32_t)__builtin_amdgcn_readlane((int)(VD).z, (JN)), \
                (uint32_t)__builtin_amdgcn_readlane((int)(VD).w, (JN)), lane16);
 #define ODDIO_ISSUE_WINDOW(JN, BUF) ODDIO_ISSUE_WINDOW_OF(vdesc, JN, BUF)
         if (cur >= 0) {   // the first window is on its way while the cursors are scanned
@@ -1031,14 +1070,37 @@ __global__ __launch_bounds__(64 * MIX_WG_WAVES, MIX_WAVES_PER_SIMD) void spatial
             float* blk = reinterpret_cast<float*>(smem + LDS_STREAM + laneA * (STREAM_WORDS * 4));
             const float ds = q.x;
             float x = frac0;
+            if (RING && __ballot(laneA < MIX_GROUP && (((vdesc.w >> 3) & SFLAG_WRAP) != 0u))) {
+                // a source of the group may pass its ring's end: Ring::sample's rewrite (ring.rs:66-68) is part of the
+                // running sum.  Blocks of 16 steps that no stream can wrap in run the plain adds.
+                const int rlen = __shfl((int)vdesc.z, laneA >> 2);
+                const float lenf = (float)rlen;                     // exact: fast-path rings are shorter than 2^24 samples
 #pragma unroll 1
-            for (int b = 0; b < 15; ++b) {
-                blk[b] = x;
+                for (int b = 0; b < 15; ++b) {
+                    blk[b] = x;
+                    if (__any(x + 17.0f * ds >= lenf)) {
+#pragma unroll 1
+                        for (int i = 0; i < 16; ++i) {
+                            const int tr = (int)x;
+                            if (tr >= rlen) x = (float)(tr - rlen) + (x - (float)tr);
+                            x = x + ds;
+                        }
+                    } else {
 #pragma unroll
-                for (int i = 0; i < 16; ++i) x = x + ds;
+                        for (int i = 0; i < 16; ++i) x = x + ds;
+                    }
+                }
+            } else {
+#pragma unroll 1
+                for (int b = 0; b < 15; ++b) {
+                    blk[b] = x;
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) x = x + ds;
+                }
             }
             blk[15] = x;
-            const uint32_t wr = (__float_as_uint(q.w) >> (16 * cA)) & 0xffffu;
+            uint32_t wr = (__float_as_uint(q.w) >> (16 * cA)) & 0xffffu;
+            if (RING) wr -= (uint32_t)(int)frac0;   // the stream's window position belongs to index trunc(frac0), not to index 0
             *reinterpret_cast<float4*>(blk + 16) = make_float4(__uint_as_float(4u * wr), q.y, q.z, q.x);
         }
         wave_sync();
@@ -1057,7 +1119,8 @@ __global__ __launch_bounds__(64 * MIX_WG_WAVES, MIX_WAVES_PER_SIMD) void spatial
         // one staged source (== cur): wait for its window, start the next one's, mix
         // VAR: 0 the common source (no FixedGain, non-negative cursor), 1 padded layout (resample ratio within PAD_EPS
         // of 1), 2 FixedGain and/or a cursor that starts negative; -1: decided here (wave-uniform branches)
-#define ODDIO_VARIANT(INFO) ((((INFO) >> 3) & SFLAG_PAD) ? 1 : ((((INFO) >> 3) & (SFLAG_FG | SFLAG_NEG)) ? 2 : 0))
+#define ODDIO_VARIANT(INFO) (RING ? ((((INFO) >> 3) & SFLAG_WRAP) ? 3 : ((((INFO) >> 3) & SFLAG_PAD) ? 1 : 0)) \
+                                  : ((((INFO) >> 3) & SFLAG_PAD) ? 1 : ((((INFO) >> 3) & (SFLAG_FG | SFLAG_NEG)) ? 2 : 0)))
 #define ODDIO_STAGED_SOURCE(VAR, PRE)                                                                                        \
     {                                                                                                                     \
         const int flags_j = (int)((cur_info >> 3) & 31u);                                                                 \
@@ -1084,8 +1147,15 @@ __global__ __launch_bounds__(64 * MIX_WG_WAVES, MIX_WAVES_PER_SIMD) void spatial
             if (nm_) { ODDIO_ISSUE_WINDOW_OF(pv, 31 - __builtin_clz(nm_), buf ^ 1) pre_issued = true; }                   \
         }                                                                                                                 \
         const int wrel4 = __float_as_int(ct.x);                                                                           \
-        if (var_j == 1) {                                                                                                 \
-            const float fg = (flags_j & SFLAG_FG) ? st[g * MIX_GROUP + (uint32_t)cur].fixed_gain : 1.0f;   /* v * 1.0 == v */ \
+        if (RING && var_j == 3) {                                                                                         \
+            /* a lane whose checkpoint lies behind its stream's start has already been rewritten: its window position is */ \
+            /* one ring length further on */                                                                              \
+            const int rlen_ = __builtin_amdgcn_readlane((int)vdesc.z, cur);                                               \
+            const float start_ = reinterpret_cast<const float*>(blkB0 + cur * BLK_SRC)[0];   /* checkpoint 0 */           \
+            const int wr4_ = wrel4 + (((int)cx0 < (int)start_) ? 4 * rlen_ : 0);                                          \
+            mix_source_lds<FULL, false, true, false, FUSED, true>(win_bytes, wr4_, cx0, bB, 0, 0.0f, acc, fi, frame0, n_frames, 1.0f, ct.y, ct.z, ct.w, 4 * (int)((cur_info >> 8) & 255u), P.bounds_err, rlen_); \
+        } else if (var_j == 1) {                                                                                          \
+            const float fg = (!RING && (flags_j & SFLAG_FG)) ? st[g * MIX_GROUP + (uint32_t)cur].fixed_gain : 1.0f;   /* v * 1.0 == v */ \
             const float frac0_ = reinterpret_cast<const float*>(blkB0 + cur * BLK_SRC)[0];   /* checkpoint 0 */           \
             const int fast_e = eB ? (flags_j & SFLAG_FAST_R) : (flags_j & SFLAG_FAST_L);                                  \
             window_repack_padded(win_bytes, (int)((cur_info >> 8) & 255u), lane, P.bounds_err);                                         \
@@ -1093,7 +1163,7 @@ __global__ __launch_bounds__(64 * MIX_WG_WAVES, MIX_WAVES_PER_SIMD) void spatial
         } else if (var_j == 0) {                                                                                          \
             mix_source_lds<FULL, false, true, false, FUSED>(win_bytes, wrel4, cx0, bB, 0, 0.0f, acc, fi, frame0, n_frames, 1.0f, ct.y, ct.z, ct.w, 4 * (int)((cur_info >> 8) & 255u), P.bounds_err); \
         } else {                                                                                                          \
-            const float fg = (flags_j & SFLAG_FG) ? st[g * MIX_GROUP + (uint32_t)cur].fixed_gain : 1.0f;                  \
+            const float fg = (!RING && (flags_j & SFLAG_FG)) ? st[g * MIX_GROUP + (uint32_t)cur].fixed_gain : 1.0f;       \
             mix_source_lds<FULL, true, false, false, FUSED>(win_bytes, wrel4, cx0, bB, 0, 0.0f, acc, fi, frame0, n_frames, fg, ct.y, ct.z, ct.w, 4 * (int)((cur_info >> 8) & 255u), P.bounds_err); \
         }                                                                                                                 \
         buf ^= 1;                                                                                                         \
@@ -1125,7 +1195,8 @@ __global__ __launch_bounds__(64 * MIX_WG_WAVES, MIX_WAVES_PER_SIMD) void spatial
         wave_sync();                                                                                                      \
         _Pragma("unroll") for (int k = 0; k < 16; ++k) park[k * 64 + lane] = acc[k];                                      \
         wave_sync();                                                                                                      \
-        mix_source_rare(park, lane, frame0, n_frames, cB_abs, path_j, st, ear, g * MIX_GROUP + (uint32_t)(J), P.cycle_rows, P.cycle_plane); \
+        if (RING) mix_source_slab(park, lane, frame0, n_frames, P.cycle_rows + (size_t)(g * MIX_GROUP + (uint32_t)(J)) * P.cycle_plane);    \
+        else mix_source_rare(park, lane, frame0, n_frames, cB_abs, path_j, st, ear, g * MIX_GROUP + (uint32_t)(J), P.cycle_rows, P.cycle_plane); \
         wave_sync();                                                                                                      \
         _Pragma("unroll") for (int k = 0; k < 16; ++k) acc[k] = park[k * 64 + lane];                                      \
         wave_sync();                                                                                                      \
@@ -1149,6 +1220,10 @@ __global__ __launch_bounds__(64 * MIX_WG_WAVES, MIX_WAVES_PER_SIMD) void spatial
                 while (cur > rj && ODDIO_VARIANT(cur_info) == 1) ODDIO_STAGED_SOURCE(1, rm == 0)
 #pragma unroll 1
                 while (cur > rj && ODDIO_VARIANT(cur_info) == 2) ODDIO_STAGED_SOURCE(2, rm == 0)
+                if (RING) {
+#pragma unroll 1
+                    while (cur > rj && ODDIO_VARIANT(cur_info) == 3) ODDIO_STAGED_SOURCE(3, rm == 0)
+                }
             }
         } else {
 #pragma unroll 1

@@ -25,6 +25,7 @@
 #include "kernels.h"
 #include "mixer_kernels.h"
 #include "buffered_kernels.h"
+#include "buffered_fast.h"
 #include "set_kernels.h"
 
 using namespace oddio_hip;

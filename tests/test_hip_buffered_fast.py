@@ -1,0 +1,265 @@
+"""The batched path of the buffered set (oddio_amd/csrc/buffered_fast.h: buffered_walk + buffered_write +
+spatial_mix<.., RING>) against the CPU oracle, through the C ABI.  GPU only.
+
+What it must reproduce: SpatialSceneControl::play_buffered (src/spatial.rs:314-340), the buffered half of
+SpatialScene::sample (:395-433), Ring (src/ring.rs:4-80) incl. the write that wraps and the read cursor's rewrite at
+the ring's end, Gain + Smoothed (src/gain.rs:58-127, src/smooth.rs), Speed (src/speed.rs:26-40), FixedGain
+(src/gain.rs:9-51) over FramesSignal (src/frames.rs:176-201, both branches).  ORDERED mode: bit-exact.  FAST mode: the
+north-star tolerance, 1e-5 of max|ref|, written below."""
+import numpy as np
+import pytest
+
+from oddio_amd import synth
+from oracle import oracle_c as oc
+
+pytestmark = pytest.mark.gpu
+
+INTERVAL = np.float32(1.0) / np.float32(48000)
+FAST_TOL = 1e-5      # relative to max|ref| (BASELINE.json north_star)
+
+
+def opts(mod, p, v, r=0.1):
+    return mod.SpatialOptions(np.asarray(p, np.float32), np.asarray(v, np.float32), r)
+
+
+def init_gain(g, ratio):
+    """Gain::set_amplitude_ratio before the signal is played (src/gain.rs:90-93): no ramp"""
+    if hasattr(g, "init_amplitude_ratio"):
+        g.init_amplitude_ratio(ratio)       # the oracle's Gain
+    else:
+        g.set_amplitude_ratio(ratio)        # oddio_amd: a control that is not bound yet sets the filter's initial value
+
+
+def build_chain(mod, shape, clip, clip_rate, start, speed, gain, db):
+    """-> (signal, gain control or None, speed control or None) for one of the chain shapes"""
+    leaf = mod.FramesSignal(mod.Frames.from_slice(clip_rate, clip) if mod is not oc else mod.Frames(clip_rate, clip), start)
+    gc = sc = None
+    if shape == "plain":
+        sig = leaf
+    elif shape == "gain":
+        if mod is oc:
+            sig = oc.Gain(leaf); gc = sig
+        else:
+            gc, sig = mod.Gain.new(leaf)
+        init_gain(gc, gain)
+    elif shape == "gain_speed":          # Gain<Speed<FramesSignal>>: the bench's shape
+        if mod is oc:
+            sp = oc.Speed(leaf); sc = sp
+            sig = oc.Gain(sp); gc = sig
+        else:
+            sc, sp = mod.Speed.new(leaf)
+            gc, sig = mod.Gain.new(sp)
+        sc.set_speed(speed); init_gain(gc, gain)
+    elif shape == "speed_gain_fixed":    # Speed<Gain<FixedGain<FramesSignal>>>
+        fg = mod.FixedGain(leaf, db)
+        if mod is oc:
+            g = oc.Gain(fg); gc = g
+            sig = oc.Speed(g); sc = sig
+        else:
+            gc, g = mod.Gain.new(fg)
+            sc, sig = mod.Speed.new(g)
+        sc.set_speed(speed); init_gain(gc, gain)
+    elif shape == "two_gains":           # Gain<Gain<FramesSignal>>: two ramps at once
+        if mod is oc:
+            g1 = oc.Gain(leaf)
+            sig = oc.Gain(g1); gc = sig
+            init_gain(g1, gain * 0.5)
+        else:
+            c1, g1 = mod.Gain.new(leaf)
+            gc, sig = mod.Gain.new(g1)
+            init_gain(c1, gain * 0.5)
+        sc = None
+    else:
+        raise ValueError(shape)
+    return sig, gc, sc
+
+
+SHAPES = ("plain", "gain", "gain_speed", "speed_gain_fixed", "two_gains")
+
+
+def populate(n_src, seed, *, max_distance, buffer_duration, cube, vmax, clip_len=40000, rates=(48000, 44100, 48000, 32000), shapes=SHAPES,
+             mode=None, max_frames=1024, speed_span=0.1):
+    import oddio_amd as oa
+    control, scene = oa.SpatialScene(max_sources=max(64, n_src), max_frames=max_frames)
+    scene.reserve_buffered(max(256, n_src))
+    if mode is not None:
+        scene.set_mode(mode)
+    ref = oc.SpatialScene()
+    sc = synth.make_scene(seed, n_src, cube=cube, vmax=vmax)
+    rng = np.random.default_rng(seed)
+    ctl = []
+    for i in range(n_src):
+        shape = shapes[i % len(shapes)]
+        clip_rate = rates[(i // len(shapes)) % len(rates)]
+        clip = synth.noise_clip(seed, i, clip_len)
+        start = float(rng.uniform(-0.01, 0.05))
+        speed = np.float32(1.0 + rng.uniform(-speed_span, speed_span))
+        gain = np.float32(rng.uniform(0.3, 1.5))
+        db = float(rng.uniform(-9.0, 3.0))
+        sh, gh, sph = build_chain(oa, shape, clip, clip_rate, start, speed, gain, db)
+        so, go, spo = build_chain(oc, shape, clip, clip_rate, start, speed, gain, db)
+        control.play_buffered(sh, opts(oa, sc["position"][i], sc["velocity"][i]), max_distance, 48000, buffer_duration)
+        ref.play_buffered(so, opts(oc, sc["position"][i], sc["velocity"][i]), max_distance, 48000, buffer_duration)
+        ctl.append(((gh, go), (sph, spo)))
+    return oa, control, scene, ref, ctl, rng
+
+
+def test_every_fast_shape_bit_exact_over_ring_wraps():
+    """Rings of ~3 900 samples: the write wraps every fourth callback, the read cursors pass the ring's end as often; gain
+    and speed stores land mid-ramp; ORDERED mode (one wave walks the set): bit-exact."""
+    import oddio_amd as oa
+    oa_, control, scene, ref, ctl, rng = populate(60, 5, max_distance=20.0, buffer_duration=0.02, cube=12.0, vmax=15.0, mode=oa.MODE_ORDERED)
+    for cb in range(26):
+        if cb in (2, 3, 7, 12, 13, 20):
+            for k, ((gh, go), (sph, spo)) in enumerate(ctl):
+                if gh is not None and (k + cb) % 2 == 0:
+                    g = np.float32(rng.uniform(0.0, 2.0))
+                    gh.set_amplitude_ratio(g); go.set_amplitude_ratio(g)
+                if sph is not None and (k + cb) % 3 == 0:
+                    sp = np.float32(rng.uniform(0.85, 1.15))
+                    sph.set_speed(sp); spo.set_speed(sp)
+        a, b = ref.sample_n(INTERVAL, 1024), scene.sample_n(INTERVAL, 1024)
+        assert scene.debug_buffered_slow() == 0, f"callback {cb}: every source should take the batched path"
+        np.testing.assert_array_equal(b, a, err_msg=f"callback {cb}")
+    assert np.abs(a).max() > 0
+    scene.close()
+
+
+def test_ragged_callbacks_and_unit_speed_fast_branch():
+    """Callback sizes that are not 1024 (the ring write is then not 64 x 16 frames; chunks of fewer than 256 frames), and
+    sources whose resample ratio is exactly 1 (frames.rs:180-187's constant-fract branch in the leaf, padded windows)."""
+    import oddio_amd as oa
+    oa_, control, scene, ref, ctl, rng = populate(40, 9, max_distance=40.0, buffer_duration=0.05, cube=15.0, vmax=1.0, rates=(48000,),
+                                                  shapes=("plain", "gain", "gain_speed"), mode=oa.MODE_ORDERED, speed_span=0.0)
+    for cb, n in enumerate((1024, 700, 256, 1, 1000, 513, 1024, 64, 1024)):
+        if cb == 3:
+            for (gh, go), _ in ctl:
+                if gh is not None:
+                    gh.set_amplitude_ratio(0.5); go.set_amplitude_ratio(0.5)
+        a, b = ref.sample_n(INTERVAL, n), scene.sample_n(INTERVAL, n)
+        assert scene.debug_buffered_slow() == 0
+        np.testing.assert_array_equal(b, a, err_msg=f"callback {cb} ({n} frames)")
+    scene.close()
+
+
+def test_fast_equals_general_kernel_and_other_shapes_ride_along():
+    """Sine / Constant / Cycle leaves and a Fader keep the general kernel (their slab rows are added at their place in
+    the walk); the same scene rendered with the batched path switched off gives the same bits."""
+    import oddio_amd as oa
+    outs = []
+    for fast in (True, False):
+        oa_, control, scene, ref, ctl, rng = populate(24, 13, max_distance=30.0, buffer_duration=0.03, cube=10.0, vmax=8.0, mode=oa.MODE_ORDERED)
+        scene.set_buffered_fast(fast)
+        extra = [
+            (lambda m: (m.Gain(m.Constant(0.5)) if m is oc else m.Gain.new(m.Constant(0.5))[1]), [1.0, 2.0, 2.0]),
+            (lambda m: (m.Speed(m.Cycle(m.Frames(32000, synth.noise_clip(31, 0, 1234)))) if m is oc
+                        else m.Speed.new(m.Cycle(m.Frames.from_slice(32000, synth.noise_clip(31, 0, 1234))))[1]), [6.0, 1.0, 2.0]),
+        ]
+        for mk, p in extra:
+            control.play_buffered(mk(oa), opts(oa, p, [0.5, 0.0, -1.0]), 30.0, 48000, 0.03)
+            ref.play_buffered(mk(oc), opts(oc, p, [0.5, 0.0, -1.0]), 30.0, 48000, 0.03)
+        res = []
+        for cb in range(9):
+            a, b = ref.sample_n(INTERVAL, 1024), scene.sample_n(INTERVAL, 1024)
+            if fast:
+                assert scene.debug_buffered_slow() == len(extra)
+            np.testing.assert_array_equal(b, a, err_msg=f"fast={fast} callback {cb}")
+            res.append(b)
+        outs.append(np.stack(res))
+        scene.close()
+    np.testing.assert_array_equal(outs[0], outs[1])
+
+
+def test_removal_motion_and_rotation_with_a_seek_set_beside():
+    import oddio_amd as oa
+    control, scene = oa.SpatialScene(max_sources=128, max_frames=1024)
+    scene.set_mode(oa.MODE_ORDERED)
+    ref = oc.SpatialScene()
+    hb, rb = [], []
+    for i in range(20):   # buffered: short clips that finish and are removed after their delay
+        clip = synth.noise_clip(11, i, 3000 + 2500 * i)
+        p, v = [3.0 + 2 * (i % 7), -1.0, 2.0 + 0.3 * i], [1.0, 0.5 * (i % 5), -2.0]
+        gh, g_h = oa.Gain.new(oa.FramesSignal(oa.Frames.from_slice(48000, clip), 0.0))
+        g_o = oc.Gain(oc.FramesSignal(oc.Frames(48000, clip), 0.0))
+        hb.append(control.play_buffered(g_h, opts(oa, p, v), 120.0, 48000, 0.1))
+        rb.append(ref.play_buffered(g_o, opts(oc, p, v), 120.0, 48000, 0.1))
+    hs, rs = [], []
+    for i in range(9):
+        clip = synth.noise_clip(12, i, 26000)
+        p, v = [-4.0 - i, 2.0, 1.0 + i], [5.0, -3.0, 0.5 * i]
+        hs.append(control.play(oa.FramesSignal(oa.Frames.from_slice(48000, clip), 0.05), opts(oa, p, v)))
+        rs.append(ref.play(oc.FramesSignal(oc.Frames(48000, clip), 0.05), opts(oc, p, v)))
+    for cb in range(60):
+        if cb in (2, 9):
+            for h, r in ((hb[1], rb[1]), (hb[7], rb[7]), (hs[3], rs[3])):
+                h.set_motion(np.float32([2.0, 2.0, 2.0]), np.float32([0.0, 1.0, 0.0]), cb == 2)
+                r.set_motion(np.float32([2.0, 2.0, 2.0]), np.float32([0.0, 1.0, 0.0]), cb == 2)
+        if cb == 4:
+            q = np.float32([np.cos(0.4), 0.0, np.sin(0.4), 0.0])
+            control.set_listener_rotation(q)
+            ref.set_listener_rotation(q)
+        a, b = ref.sample_n(INTERVAL, 1024), scene.sample_n(INTERVAL, 1024)
+        np.testing.assert_array_equal(b, a, err_msg=f"callback {cb}")
+        assert (scene.len_buffered(), len(scene)) == (ref.len_buffered(), len(ref))
+        assert [h.is_finished() for h in hb + hs] == [r.is_finished() for r in rb + rs]
+        if scene.len_buffered() == 0 and cb > 30:
+            break
+    assert scene.len_buffered() == 0
+    scene.close()
+
+
+def test_fast_mode_tolerance_and_getters():
+    import oddio_amd as oa
+    oa_, control, scene, ref, ctl, rng = populate(400, 21, max_distance=60.0, buffer_duration=0.05, cube=25.0, vmax=20.0)
+    (gh, go), (sph, spo) = ctl[2]          # a gain_speed source
+    gh.set_gain(-6.0); go.set_gain(-6.0)
+    assert abs(gh.gain() - (-6.0)) < 1e-4 and abs(gh.amplitude_ratio() - 10.0 ** (-6.0 / 20.0)) < 1e-6
+    sph.set_speed(1.05); spo.set_speed(1.05)
+    assert abs(sph.speed() - 1.05) < 1e-7
+    for cb in range(6):
+        a, b = ref.sample_n(INTERVAL, 1024), scene.sample_n(INTERVAL, 1024)
+        assert scene.debug_buffered_slow() == 0
+        assert np.abs(b - a).max() <= FAST_TOL * np.abs(a).max(), f"callback {cb}"
+    scene.close()
+
+
+def test_ordered_rows_path_above_the_serial_threshold():
+    """More than 1024 buffered sources in ORDERED mode: spatial_mix<.., STORE, .., RING> writes contribution rows and
+    ordered_sum adds them in the reference's reverse walk order; a Seek set beside it is seeded with the result."""
+    import oddio_amd as oa
+    n_buf, n_seek = 2300, 1300
+    control, scene = oa.SpatialScene(max_sources=4096, max_frames=1024)
+    scene.reserve_buffered(n_buf)
+    scene.set_mode(oa.MODE_ORDERED)
+    ref = oc.SpatialScene()
+    sc = synth.make_scene(77, n_buf + n_seek, cube=8.0, vmax=6.0)
+    frames_h, clips = [], []
+    bank = [synth.noise_clip(78, k, 24000) for k in range(64)]
+    bank_h = [oa.Frames.from_slice(48000, c) for c in bank]
+    kinds = [oa.FILTER_SPEED, oa.FILTER_GAIN]
+    rng = np.random.default_rng(3)
+    params = np.stack([1.0 + rng.uniform(-0.1, 0.1, n_buf), rng.uniform(0.2, 1.2, n_buf)], axis=1).astype(np.float32)
+    starts = rng.uniform(0.0, 0.05, n_buf)
+    ids = control.play_buffered_frames_batch([bank_h[i % 64] for i in range(n_buf)], starts, kinds, params, sc["position"][:n_buf], sc["velocity"][:n_buf],
+                                             sc["radius"][:n_buf], 25.0, 48000, 0.03)
+    gains_o = []
+    for i in range(n_buf):
+        sp = oc.Speed(oc.FramesSignal(oc.Frames(48000, bank[i % 64]), float(starts[i])))
+        sp.set_speed(params[i, 0])
+        g = oc.Gain(sp)
+        g.init_amplitude_ratio(params[i, 1])
+        gains_o.append(g)
+        ref.play_buffered(g, oc.SpatialOptions(sc["position"][i], sc["velocity"][i], 0.1), 25.0, 48000, 0.03)
+    for i in range(n_buf, n_buf + n_seek):
+        control.play(oa.FramesSignal(bank_h[i % 64], 0.04), oa.SpatialOptions(sc["position"][i], sc["velocity"][i], 0.1))
+        ref.play(oc.FramesSignal(oc.Frames(48000, bank[i % 64]), 0.04), oc.SpatialOptions(sc["position"][i], sc["velocity"][i], 0.1))
+    for cb, n in enumerate((1024, 1024, 600, 1024, 1024)):
+        if cb == 2:
+            new = rng.uniform(0.0, 1.5, n_buf).astype(np.float32)
+            control.set_control_batch(ids[::3], 1, new[::3])
+            for i in range(0, n_buf, 3):
+                gains_o[i].set_amplitude_ratio(new[i])
+        a, b = ref.sample_n(INTERVAL, n), scene.sample_n(INTERVAL, n)
+        assert scene.debug_buffered_slow() == 0
+        np.testing.assert_array_equal(b, a, err_msg=f"callback {cb}")
+    scene.close()
