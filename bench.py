@@ -320,6 +320,248 @@ def cpu_baseline(seed: int, budget_s: float = 20.0, parity_device: int | None = 
 
 
 # ---------------------------------------------------------------------------------------------------
+# --workload buffered: the path Gain / Speed sources take into a scene (play_buffered, src/spatial.rs:314-340,395-433)
+# ---------------------------------------------------------------------------------------------------
+BUF_MAX_DISTANCE = 100.0     # metres: ring = ceil((100 / 343 + 0.1) * 48000) + 1 = 18 795 samples per source
+BUF_DURATION = 0.1
+
+
+def buffered_algorithmic_bytes(speeds: np.ndarray, n_frames: int) -> dict:
+    """Per callback: every source's leaf samples (N * speed), its ring extended by N samples, the ring window both ears read
+    (N + 32), its parameters, and the stereo buffer:  B = sum_s [4 N speed_s + 4 N + 4 (N + 32) + P] + 8 N."""
+    s = float(len(speeds))
+    leaf = 4.0 * n_frames * float(np.sum(speeds.astype(np.float64)))
+    ring_w = 4.0 * n_frames * s
+    ring_r = 4.0 * (n_frames + 32) * s
+    par = PARAM_BYTES * s
+    return {"leaf_read": leaf, "ring_write": ring_w, "ring_read": ring_r, "parameters": par, "output": 8.0 * n_frames,
+            "write_kernel": leaf + ring_w + par / 2, "read_kernel": ring_r + par / 2 + 8.0 * n_frames,
+            "total": leaf + ring_w + ring_r + par + 8.0 * n_frames}
+
+
+def buffered_cpu_and_parity(device: int, seed: int, budget_s: float) -> tuple[dict, dict]:
+    """The oracle (C restatement of the reference) on the same kind of scene: throughput of one thread, and parity of the HIP
+    path against it -- 4 096 Gain<Speed<FramesSignal>> sources, 6 callbacks with a gain store to every source before the third."""
+    import oddio_amd as oa
+    from oddio_amd import synth
+    from oracle import oracle_c as oc
+    n_src, clip_len, n_cb = 4096, 16384, 6
+    sc = synth.make_scene(seed, n_src)
+    st = synth.SplitMixStreams(seed ^ 0xB0F, n_src)
+    speeds = st.uniform(0.9, 1.1)
+    gains = st.uniform(0.5, 1.0)
+    bank = np.stack([synth.sine_clip(float(sc["freq_hz"][k]), clip_len) for k in range(256)])
+    interval = np.float32(1.0) / np.float32(RATE)
+
+    def oracle_scene():
+        ref = oc.SpatialScene()
+        ctl = []
+        frames = [oc.Frames(RATE, bank[k]) for k in range(256)]
+        for i in range(n_src):
+            sp = oc.Speed(oc.FramesSignal(frames[i % 256], 0.02))
+            sp.set_speed(speeds[i])
+            g = oc.Gain(sp)
+            ref.play_buffered(g, oc.SpatialOptions(sc["position"][i], sc["velocity"][i], 0.1), BUF_MAX_DISTANCE, RATE, BUF_DURATION)
+            ctl.append(g)
+        return ref, ctl
+
+    ref, ctl = oracle_scene()
+    outs_ref, t_cb = [], []
+    for cb in range(n_cb):
+        if cb == 2:
+            for i, g in enumerate(ctl):
+                g.set_amplitude_ratio(gains[i])
+        t0 = time.perf_counter()
+        outs_ref.append(ref.sample_n(interval, N_FRAMES))
+        t_cb.append(time.perf_counter() - t0)
+    # more callbacks for the timing if the budget allows (the first ones include page faults of the rings)
+    t_extra, n_extra = 0.0, 0
+    while t_extra + sum(t_cb) < budget_s and n_extra < 3:
+        t0 = time.perf_counter()
+        ref.sample_n(interval, N_FRAMES)
+        t_extra += time.perf_counter() - t0
+        n_extra += 1
+    per_cb = (sum(t_cb[1:]) + t_extra) / (n_cb - 1 + n_extra)
+    del ref, ctl
+    res = {}
+    for mode, name in ((oa.MODE_ORDERED, "ordered"), (oa.MODE_FAST, "fast")):
+        control, scene = oa.SpatialScene(device=device, max_sources=n_src, max_frames=N_FRAMES)
+        scene.reserve_buffered(n_src)
+        scene.set_mode(mode)
+        frames = [oa.Frames.from_slice(RATE, bank[k]) for k in range(256)]
+        ids = control.play_buffered_frames_batch([frames[i % 256] for i in range(n_src)], np.full(n_src, 0.02), [oa.FILTER_SPEED, oa.FILTER_GAIN],
+                                                 np.stack([speeds, np.ones(n_src, np.float32)], axis=1), sc["position"], sc["velocity"], sc["radius"],
+                                                 BUF_MAX_DISTANCE, RATE, BUF_DURATION)
+        outs = []
+        for cb in range(n_cb):
+            if cb == 2:
+                control.set_control_batch(ids, 1, gains)
+            outs.append(scene.sample_n(interval, N_FRAMES))
+        res[name] = outs
+        assert scene.debug_buffered_slow() == 0
+        scene.close()
+    scale = max(float(np.abs(o).max()) for o in outs_ref)
+    rel = max(float(np.abs(a.astype(np.float64) - b.astype(np.float64)).max()) for a, b in zip(res["fast"], outs_ref)) / scale
+    parity = {"sources": n_src, "callbacks": n_cb, "shape": "Gain<Speed<FramesSignal>>, a gain store to every source before the third callback",
+              "ordered_bit_exact": bool(all(np.array_equal(a, b) for a, b in zip(res["ordered"], outs_ref))),
+              "fast_rel_err_vs_reference": rel, "tolerance": 1e-5, "max_abs_reference": scale}
+    cpu = {"value": n_src * N_FRAMES / per_cb, "unit": "source-frames/s", "cores": 1, "kind": "port",
+           "sample": f"{n_src} buffered Gain<Speed<FramesSignal>> sources (same generator, 256 shared clips), {n_cb - 1 + n_extra} callbacks of {N_FRAMES} frames, "
+                     f"C restatement of the reference (oracle/oddio_oracle.c, -O2 -ffp-contract=off, not rustc output), one thread = the reference's one audio thread",
+           "cpu_model": _cpu_model(), "seconds_per_callback": per_cb}
+    return cpu, parity
+
+
+def bench_buffered(args, device: int) -> None:
+    """One SpatialScene whose sources are all played with play_buffered as Gain<Speed<FramesSignal>>: own clip each, speeds in
+    [0.9, 1.1], a new gain target for every source before every 4th callback (so that every Gain is always ramping)."""
+    import torch
+
+    import oddio_amd as oa
+    from oddio_amd import synth
+    S, L = args.sources, args.clip_len
+    dev = torch.device("cuda", device)
+    sc = synth.make_scene(args.seed, S)
+    st = synth.SplitMixStreams(args.seed ^ 0xB0F, S)
+    speeds = st.uniform(0.9, 1.1)
+    n_clips = S if args.clips <= 0 else min(args.clips, S)
+    clips = torch.empty((n_clips, L), dtype=torch.float32, device=dev)
+    control, scene = oa.SpatialScene(device=device, max_sources=S, max_frames=N_FRAMES)   # (max_sources also bounds the buffered set and sizes the control queue)
+    scene.reserve_buffered(S)
+    base = clips.data_ptr()
+    frames = [oa.Frames.from_device_ptr(RATE, base + 4 * L * i, L, device=device, copy=False) for i in range(n_clips)]
+    if n_clips < S:
+        pick = ((np.arange(S, dtype=np.uint64) * np.uint64(0x9E3779B97F4A7C15)) >> np.uint64(20)) % np.uint64(n_clips)
+        flist = [frames[int(k)] for k in pick]
+    else:
+        flist = frames
+    start_seconds = 0.5
+    t_play = time.perf_counter()
+    ids = control.play_buffered_frames_batch(flist, np.full(S, start_seconds), [oa.FILTER_SPEED, oa.FILTER_GAIN],
+                                             np.stack([speeds, np.ones(S, np.float32)], axis=1), sc["position"], sc["velocity"], sc["radius"],
+                                             BUF_MAX_DISTANCE, RATE, BUF_DURATION)
+    t_play = time.perf_counter() - t_play
+    freq = torch.from_numpy(sc["freq_hz"][:n_clips]).to(dev).double()
+    n = torch.arange(L, device=dev, dtype=torch.float64)
+    chunk = max(1, (1 << 28) // L)
+    for s0 in range(0, n_clips, chunk):
+        s1 = min(n_clips, s0 + chunk)
+        clips[s0:s1] = torch.sin((2.0 * np.pi / RATE) * freq[s0:s1, None] * n[None, :]).float()
+    d_ids = torch.from_numpy(ids.astype(np.int64)).to(dev).to(torch.int32)        # uint32 values < 2^31: same bits
+    d_pos = torch.from_numpy(sc["position"]).to(dev).contiguous()
+    d_vel = torch.from_numpy(sc["velocity"]).to(dev).contiguous()
+    gain_sets = [(0.5 + 0.5 * torch.rand(S, device=dev, dtype=torch.float32, generator=torch.Generator(device=dev).manual_seed(args.seed + k))).contiguous()
+                 for k in range(4)]
+    torch.cuda.synchronize(dev)
+    out = torch.zeros((N_FRAMES, 2), dtype=torch.float32, device=dev)
+    interval = np.float32(1.0) / np.float32(RATE)
+    # callbacks a clip lasts at the highest speed; every source's FramesSignal clock is put back before that
+    span = max(4, int((L - int(start_seconds * RATE)) / (N_FRAMES * 1.1)) - 4)
+    step_no = 0
+
+    def one_step():
+        nonlocal step_no
+        if step_no and step_no % span == 0:
+            scene.debug_reset_buffered_clock(start_seconds)
+        if step_no and step_no % args.reset_every == 0:
+            control.set_motion_device(S, d_ids.data_ptr(), d_pos.data_ptr(), d_vel.data_ptr(), True)
+        if step_no % 4 == 0:      # GainControl::set_amplitude_ratio on every source: a 0.1 s ramp (4.7 callbacks) is always running
+            control.set_control_device(S, d_ids.data_ptr(), 1, gain_sets[(step_no // 4) % 4].data_ptr())
+        scene.sample_device(interval, out.data_ptr(), N_FRAMES)
+        step_no += 1
+
+    def sync_all():
+        scene.synchronize()
+        torch.cuda.synchronize()
+
+    if args.precondition_ms > 0:
+        hold = args.precondition_hold
+        for k in range(int(args.precondition_ms / 1.0)):
+            one_step()
+            if hold > 0 and k % hold == hold - 1:
+                control.set_motion_device(S, d_ids.data_ptr(), d_pos.data_ptr(), d_vel.data_ptr(), True)
+            if k % 32 == 31:
+                scene.synchronize()
+        control.set_motion_device(S, d_ids.data_ptr(), d_pos.data_ptr(), d_vel.data_ptr(), True)
+        scene.debug_reset_buffered_clock(start_seconds)
+        step_no = 0
+    for _ in range(args.warmup):
+        one_step()
+    scene.set_profiling(1)
+    sync_all()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        one_step()
+    sync_all()
+    elapsed = time.perf_counter() - t0
+    stages = scene.buffered_ms_history(min(args.steps, 512))
+    assert len(stages) == min(args.steps, 512), (len(stages), args.steps)
+    scene.set_profiling(False)
+    n_slow = scene.debug_buffered_slow()
+    assert scene.len_buffered() == S, "sources finished inside the timed region"
+    assert bool(torch.isfinite(out).all()) and float(out.abs().max()) > 0.0
+    # host-output calls (the reference's boundary hands a host slice), untimed by `value`
+    host_buf = np.zeros((N_FRAMES, 2), dtype=np.float32)
+    for _ in range(2):
+        scene.sample(interval, host_buf); step_no += 1
+    th0 = time.perf_counter()
+    for _ in range(6):
+        scene.sample(interval, host_buf); step_no += 1
+    host_ms = (time.perf_counter() - th0) / 6 * 1e3
+    # the general kernel on the same scene (what every buffered source took before round 4), a few callbacks
+    scene.set_buffered_fast(False)
+    for _ in range(2):
+        one_step()
+    scene.synchronize()
+    tg0 = time.perf_counter()
+    for _ in range(4):
+        one_step()
+    scene.synchronize()
+    general_ms = (time.perf_counter() - tg0) / 4 * 1e3
+    scene.set_buffered_fast(True)
+
+    b = buffered_algorithmic_bytes(speeds, N_FRAMES)
+    walk_ms, write_ms, read_ms = (float(stages[:, k].mean()) for k in range(3))
+    path_ms = walk_ms + write_ms + read_ms
+    ms_per_step = elapsed / args.steps * 1e3
+    value = float(S) * N_FRAMES * args.steps / elapsed
+    gbps = lambda nbytes, ms: nbytes / (ms * 1e-3) / 1e9     # noqa: E731
+    line = {
+        "metric": "mixed source-frames/sec (48 kHz stereo)",
+        "value": value, "unit": "source-frames/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {
+            "workload": f"buffered path (north_star: speed.rs, gain.rs, smooth.rs, ring.rs): SpatialScene, {S} moving Gain<Speed<FramesSignal>> sources played "
+                        f"with play_buffered (own {L}-sample clip each, speeds uniform in [0.9, 1.1], a GainControl store to every source before every 4th callback), "
+                        f"rings of {int(np.ceil((BUF_MAX_DISTANCE / 343.0 + BUF_DURATION) * RATE)) + 1} samples, Doppler + propagation delay, 48 kHz stereo, {N_FRAMES}-frame callbacks",
+            "sources_per_gpu": S, "frames_per_callback": N_FRAMES, "sample_rate": RATE, "clip_len": L,
+            "sum_mode": "FAST: deterministic tree sum over waves and workgroups; ring contents are the reference's bits in every mode",
+            "parallelism": "single-gpu", "play_seconds": t_play, "sources_on_general_kernel": int(n_slow),
+        },
+        "max_realtime_sources": value / RATE,
+        "host_output_ms_per_step": host_ms,
+        "general_kernel_ms_per_step": general_ms,
+        "precondition_ms": args.precondition_ms,
+        "roofline": {
+            "bound": "hbm", "achieved": gbps(b["total"], path_ms), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": gbps(b["total"], path_ms) / HBM_PEAK_GBPS,
+            "traffic": None, "traffic_source": None,
+            "kernel": "buffered_walk + buffered_write + spatial_mix<RING> (+ its reduce): the buffered set's whole path",
+            "avg_kernel_ms": path_ms, "algorithmic_bytes_per_launch": b["total"], "bytes": b,
+            "frac_callback": gbps(b["total"], ms_per_step) / HBM_PEAK_GBPS,
+            "walk_ms": walk_ms,
+            "write_ms": write_ms, "write_frac": gbps(b["write_kernel"], write_ms) / HBM_PEAK_GBPS,
+            "read_ms": read_ms, "read_frac": gbps(b["read_kernel"], read_ms) / HBM_PEAK_GBPS,
+            "stage_timing": f"hipEvents around the three stages of every timed callback ({len(stages)} samples)",
+        },
+    }
+    if not args.no_cpu_baseline:
+        cpu, parity = buffered_cpu_and_parity(device, args.seed, args.cpu_budget)
+        cpu["gpu_over_cpu"] = value / cpu["value"]
+        line["cpu_baseline"], line["parity"] = cpu, parity
+    print(json.dumps(line), flush=True)
+
+
+# ---------------------------------------------------------------------------------------------------
 def _free_port() -> int:
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -372,6 +614,9 @@ def main():
                     help="GPU clock pre-conditioning before the warm-up steps: this many ms of untimed callbacks of the workload "
                          "itself, after which every source is put back to its starting state, so that a short warm-up starts from "
                          "loaded clocks instead of the idle state the host-side set-up leaves behind (DESIGN.md section 5); 0 disables it")
+    ap.add_argument("--workload", choices=["seek", "buffered"], default="seek",
+                    help="'seek' (default): BASELINE's FramesSignal sources played with play(); 'buffered': the same number of "
+                         "Gain<Speed<FramesSignal>> sources played with play_buffered (single GPU)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-worker", default=None, help=argparse.SUPPRESS)
     ap.add_argument("--cpu-budget", type=float, default=20.0)
@@ -407,6 +652,11 @@ def main():
         dist_mod.init_process_group(backend="gloo", rank=rank, world_size=world)
         dist = dist_mod
 
+    if args.workload == "buffered":
+        if world != 1:
+            raise SystemExit("--workload buffered is a single-GPU line")
+        bench_buffered(args, device)
+        return
     S, L = args.sources, args.clip_len
     sharded = args.mode == "sharded" and world > 1
     # clips start 1.0 s in: the propagation delay (<= 0.25 s at set-up) may grow by the drift of the

@@ -185,6 +185,16 @@ int oddio_hip_scene_play_buffered_batch(oddio_hip_scene* scene, size_t n, oddio_
  * src/speed.rs:52-54) to filter `filter_index` of n buffered sources, under one lock. */
 int oddio_hip_scene_set_control_batch(oddio_hip_scene* scene, size_t n, const uint32_t* source_ids,
                                       int filter_index, const float* values);
+/* The same n stores, and n Spatial::set_motion calls (src/spatial.rs:137-149; positions / velocities
+ * [n][3]), with the handle ids and the values in DEVICE memory (readable on the scene's device): one
+ * message on the control queue, applied by a kernel in message order at the next sample call -- for
+ * hosts that compute gains or trajectories on the GPU.  The arrays must stay valid until that sample
+ * call has executed (e.g. oddio_hip_scene_synchronize after it).  Ids of sources that have left the
+ * scene are skipped.  The get_* calls above do not see device-side stores. */
+int oddio_hip_scene_set_control_device(oddio_hip_scene* scene, size_t n, const uint32_t* d_source_ids,
+                                       int filter_index, const float* d_values);
+int oddio_hip_scene_set_motion_device(oddio_hip_scene* scene, size_t n, const uint32_t* d_source_ids,
+                                      const float* d_positions, const float* d_velocities, int discontinuity);
 /* Which kernels render the buffered set (results are identical): 1 (default) = the batched path for
  * FramesSignal leaves under FixedGain / Gain / Speed chains (ring write 16 sources per wavefront, ring
  * reads in the Seek set's mix kernel) with the general kernel for every other shape; 0 = the general
@@ -194,6 +204,10 @@ int oddio_hip_scene_set_buffered_fast(oddio_hip_scene* scene, int enable);
 /* (tests) the number of buffered sources the last callback of up to 1024 frames left to the general
  * kernel (0 when every source took the batched path); waits for the scene's stream. */
 int oddio_hip_debug_buffered_slow(oddio_hip_scene* scene, uint32_t* n_slow);
+/* (bench) FramesSignal::t = seconds for every buffered source with a FramesSignal leaf, in stream
+ * order.  Not part of the reference's interface (a buffered signal is not Seek): bench.py keeps its
+ * sources inside their clips with it, as it does with oddio_hip_scene_seek_all for the Seek set. */
+int oddio_hip_debug_reset_buffered_clock(oddio_hip_scene* scene, double seconds);
 /* `scene.recv_buffered.len()` after the last sample call */
 int oddio_hip_scene_len_buffered(oddio_hip_scene* scene, size_t* len);
 
@@ -300,6 +314,9 @@ int oddio_hip_scene_last_kernel_ms(oddio_hip_scene* scene, float ms[3]);
  * without synchronising inside it. */
 int oddio_hip_scene_kernel_ms_history(oddio_hip_scene* scene, float* ms, size_t max_calls,
                                       size_t* n_calls);
+/* The buffered set's stages of the last profiled calls (set_profiling(1); callbacks of up to 1024 frames):
+ * ms[3 * i + {0, 1, 2}] = walk, ring write through the filter chains (+ the general kernel), ring reads + their sum. */
+int oddio_hip_scene_buffered_ms_history(oddio_hip_scene* scene, float* ms, size_t max_calls, size_t* n_calls);
 
 /* Debug: the runtime's view of the mix kernel's residency (64-thread blocks per CU) and its
  * register / LDS footprint. */

@@ -120,8 +120,11 @@ def lib():
         "oddio_hip_mixer_get_speed": (i32, [vp, u32, i32, fp]),
         "oddio_hip_scene_play_buffered_batch": (i32, [vp, sz, vpp, C.POINTER(f64), C.POINTER(i32), i32, fp, fp, fp, fp, f32, u32, f32, u32p]),
         "oddio_hip_scene_set_control_batch": (i32, [vp, sz, u32p, i32, fp]),
+        "oddio_hip_scene_set_control_device": (i32, [vp, sz, vp, i32, vp]),
+        "oddio_hip_scene_set_motion_device": (i32, [vp, sz, vp, vp, vp, i32]),
         "oddio_hip_scene_set_buffered_fast": (i32, [vp, i32]),
         "oddio_hip_debug_buffered_slow": (i32, [vp, u32p]),
+        "oddio_hip_debug_reset_buffered_clock": (i32, [vp, f64]),
         "oddio_hip_source_is_finished": (i32, [vp, u32, C.POINTER(i32)]),
         "oddio_hip_source_release": (i32, [vp, u32]),
         "oddio_hip_source_playback_position": (i32, [vp, u32, C.POINTER(f64)]),
@@ -145,6 +148,7 @@ def lib():
         "oddio_hip_scene_set_profiling": (i32, [vp, i32]),
         "oddio_hip_scene_last_kernel_ms": (i32, [vp, fp]),
         "oddio_hip_scene_kernel_ms_history": (i32, [vp, fp, sz, C.POINTER(sz)]),
+        "oddio_hip_scene_buffered_ms_history": (i32, [vp, fp, sz, C.POINTER(sz)]),
         "oddio_hip_scene_set_motion_batch": (i32, [vp, sz, u32p, fp, fp, i32]),
         "oddio_hip_debug_mix_occupancy": (i32, [i32, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]),
         "oddio_hip_mixer_create": (i32, [i32, u32, u32, vpp]),

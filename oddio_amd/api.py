@@ -453,6 +453,10 @@ class _SceneSignal(Signal):
         _lib.check(_lib.lib().oddio_hip_debug_buffered_slow(self._h, C.byref(n)))
         return n.value
 
+    def debug_reset_buffered_clock(self, seconds: float):
+        """(bench) FramesSignal::t = seconds for every buffered FramesSignal leaf, in stream order."""
+        _lib.check(_lib.lib().oddio_hip_debug_reset_buffered_clock(self._h, float(seconds)))
+
     def set_buffered_fast(self, enable: bool):
         """Which kernels render the buffered set (identical results): the batched path (default) or the general kernel for everything."""
         _lib.check(_lib.lib().oddio_hip_scene_set_buffered_fast(self._h, int(bool(enable))))
@@ -486,6 +490,13 @@ class _SceneSignal(Signal):
         buf = np.zeros((max_calls, 3), dtype=np.float32)
         n = C.c_size_t()
         _lib.check(_lib.lib().oddio_hip_scene_kernel_ms_history(self._h, _fp(buf), max_calls, C.byref(n)))
+        return buf[:n.value].copy()
+
+    def buffered_ms_history(self, max_calls=512):
+        """[n, 3] milliseconds (walk, ring write, ring reads + sum) of the buffered set's stages in the most recent profiled calls."""
+        buf = np.zeros((max_calls, 3), dtype=np.float32)
+        n = C.c_size_t()
+        _lib.check(_lib.lib().oddio_hip_scene_buffered_ms_history(self._h, _fp(buf), max_calls, C.byref(n)))
         return buf[:n.value].copy()
 
     def __len__(self):
@@ -626,6 +637,15 @@ class SpatialSceneControl:
         vals = np.ascontiguousarray(np.asarray(values, dtype=np.float32).reshape(len(ids)))
         _lib.check(_lib.lib().oddio_hip_scene_set_control_batch(self._scene._h, len(ids), ids.ctypes.data_as(C.POINTER(C.c_uint32)),
                                                                  int(filter_index), _fp(vals)))
+
+    def set_control_device(self, n: int, d_ids_ptr: int, filter_index: int, d_values_ptr: int):
+        """n gain / speed stores with ids (uint32) and values (float32) in device memory; the arrays must outlive the next sample call's execution."""
+        _lib.check(_lib.lib().oddio_hip_scene_set_control_device(self._scene._h, int(n), C.c_void_p(d_ids_ptr), int(filter_index), C.c_void_p(d_values_ptr)))
+
+    def set_motion_device(self, n: int, d_ids_ptr: int, d_positions_ptr: int, d_velocities_ptr: int, discontinuity: bool):
+        """n set_motion calls with ids, positions [n][3], velocities [n][3] in device memory; same lifetime rule."""
+        _lib.check(_lib.lib().oddio_hip_scene_set_motion_device(self._scene._h, int(n), C.c_void_p(d_ids_ptr), C.c_void_p(d_positions_ptr),
+                                                                C.c_void_p(d_velocities_ptr), int(bool(discontinuity))))
 
     def set_motion_batch(self, handles, positions, velocities, discontinuity: bool):
         if isinstance(handles, np.ndarray):

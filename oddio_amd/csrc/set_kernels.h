@@ -181,6 +181,32 @@ __global__ void apply_control_by_id(const ControlById* __restrict__ up, uint32_t
     bdyn[sl & ~SLOT_BUFFERED_BIT].shared[u.index & (MAX_WRAP - 1)] = u.value;
 }
 
+// The same two updates with ids and values in DEVICE memory (oddio_hip_scene_set_control_device / _set_motion_device):
+// an engine that computes gains or positions on the GPU hands them over without a trip through the host; one message
+// per batch on the control queue, applied in message order.
+__global__ void apply_control_dev(const uint32_t* __restrict__ ids, const float* __restrict__ values, uint32_t n, uint32_t index,
+                                  const uint32_t* __restrict__ slot_of_id, BufDyn* __restrict__ bdyn) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t sl = slot_of_id[ids[i]];
+    if (sl == SLOT_INVALID || !(sl & SLOT_BUFFERED_BIT)) return;
+    bdyn[sl & ~SLOT_BUFFERED_BIT].shared[index] = values[i];
+}
+__global__ void apply_motion_dev(const uint32_t* __restrict__ ids, const float* __restrict__ pos, const float* __restrict__ vel, uint32_t n,
+                                 uint32_t discontinuity, const uint32_t* __restrict__ slot_of_id, SrcPending* __restrict__ pend,
+                                 SrcPending* __restrict__ pend_b) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t sl = slot_of_id[ids[i]];
+    if (sl == SLOT_INVALID) return;
+    SrcPending p;
+    p.pos[0] = pos[3 * i]; p.pos[1] = pos[3 * i + 1]; p.pos[2] = pos[3 * i + 2];
+    p.vel[0] = vel[3 * i]; p.vel[1] = vel[3 * i + 1]; p.vel[2] = vel[3 * i + 2];
+    p.flags = PEND_FRESH | (discontinuity ? PEND_DISCONTINUITY : 0u);
+    p.pad = 0;
+    if (sl & SLOT_BUFFERED_BIT) pend_b[sl & ~SLOT_BUFFERED_BIT] = p; else pend[sl] = p;
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // Sharded scene, deterministic reduce (SURVEY.md 8e's alternative to the RCCL all-reduce): every peer writes its
 // partial stereo buffer into a slab in rank 0's memory (opened through hipIpc: xGMI peer-to-peer writes, or plain
@@ -252,6 +278,13 @@ __global__ void seek_all_live(SrcDyn* __restrict__ dyn, const SrcStatic* __restr
     if (st[i].kind == KIND_FRAMES || st[i].kind == KIND_DOWNMIX) dyn[i].t = dyn[i].t + (double)seconds;   // frames.rs:211-213
     else if (st[i].kind == KIND_SINE) dyn[i].phase = fmodf(dyn[i].phase + seconds * st[i].freq_or_value, ODDIO_TAU);
     else if (st[i].kind == KIND_CYCLE) dyn[i].t = f64_rem_euclid(dyn[i].t + (double)seconds * (double)st[i].clip_rate, (double)st[i].clip_len);
+}
+
+// (bench) FramesSignal::t = seconds for the FramesSignal leaves of the buffered set
+__global__ void reset_buffered_clock(BufDyn* __restrict__ dyn, const BufStatic* __restrict__ st, const uint32_t* __restrict__ d_len, double seconds) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= d_len[0]) return;
+    if (st[i].kind == KIND_FRAMES) dyn[i].common.t = seconds;
 }
 
 }  // namespace oddio_hip
