@@ -32,7 +32,11 @@ static_assert(RING_MIRROR >= WIN_CAP + 4 && RING_MIRROR % 4 == 0, "a mix window 
 constexpr uint32_t BUF_FAST_OK = 1u;             // BufStatic::flags: the shape is one buffered_write renders
 constexpr uint32_t RING_FAST_MIN = 2048, RING_FAST_MAX = 1u << 24;   // ring lengths the fast path takes ((float)len exact; one wrap per chunk at most)
 constexpr uint32_t BW_FRAMES = 1024;             // frames per Ring::write the fast path takes (64 lanes x 16)
-constexpr int BW_GROUP = 16;                     // sources per scan
+#ifndef ODDIO_BW_GROUP_LOG2
+#define ODDIO_BW_GROUP_LOG2 4
+#endif
+constexpr int BW_GROUP_LOG2 = ODDIO_BW_GROUP_LOG2;
+constexpr int BW_GROUP = 1 << BW_GROUP_LOG2;    // sources per scan
 constexpr int BW_SLOTS = 3;                      // running sums per source: leaf cursor, two ramping Gains
 constexpr int BW_STREAMS = BW_SLOTS * BW_GROUP;
 constexpr int BW_CK_STRIDE = BW_STREAMS + 1;     // odd: lane b's reads (row b) and the scanners' writes (one row) are both conflict-free
@@ -69,6 +73,11 @@ struct alignas(16) WriteRec {
     uint32_t pad[6];
 };
 static_assert(sizeof(WriteRec) == 128, "WriteRec layout");
+// (buffered_write reads the record as 32-bit words through v_readlane: word indices below)
+static_assert(offsetof(WriteRec, info) == 12 && offsetof(WriteRec, ring) == 16 && offsetof(WriteRec, ring_len) == 24 && offsetof(WriteRec, start_idx) == 28 &&
+              offsetof(WriteRec, frac0) == 32 && offsetof(WriteRec, ds) == 40 && offsetof(WriteRec, wrel) == 44 && offsetof(WriteRec, cnt) == 48 &&
+              offsetof(WriteRec, ops) == 52 && offsetof(WriteRec, c) == 56 && offsetof(WriteRec, rprev) == 72 && offsetof(WriteRec, rnext) == 80 &&
+              offsetof(WriteRec, rp0) == 88 && offsetof(WriteRec, rstep) == 96, "WriteRec word indices");
 
 // the per-ear scalars of spatial.rs:409-423 for a source the general kernel renders after buffered_walk
 struct alignas(16) BufEar { float prev_offset, dt, g0, dg; };
@@ -165,18 +174,19 @@ __device__ __forceinline__ bool ring_tile_rec(TileRec& r, const SceneParams& P, 
 // buffered_walk: one thread per slot of the buffered set
 // ---------------------------------------------------------------------------------------------------------------
 // d_len_b: the device-resident set length; len_snap: what this walk saw (read by the later kernels of the callback).
-// slow_hdr: [0] = number of sources left to the general kernel this callback, [1..] their slots.
+// slow_hdr: [par] = number of sources left to the general kernel this callback (par = callback parity; this walk zeroes the
+// other one for the next callback: no memset on the stream), [2..] their slots.
 __global__ __launch_bounds__(128) void buffered_walk(SceneParams P, const BufStatic* __restrict__ st, BufDyn* __restrict__ dyn, SrcPending* __restrict__ pend,
                                                      int check_pending, const uint32_t* __restrict__ d_len_b, uint32_t* __restrict__ len_snap,
                                                      WriteRec* __restrict__ wrecs, TileRec* __restrict__ trecs, uint32_t rec_stride,
-                                                     BufEarPair* __restrict__ bear, uint32_t* __restrict__ slow_hdr,
+                                                     BufEarPair* __restrict__ bear, uint32_t* __restrict__ slow_hdr, uint32_t par,
                                                      uint32_t* __restrict__ stopped_hdr, uint32_t stopped_cap) {
     __shared__ uint32_t stage[2][64 * 37];
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     const int lane = threadIdx.x & 63;
     uint32_t* lds = stage[threadIdx.x >> 6];
     const uint32_t len = d_len_b[0];
-    if (i == 0) *len_snap = len;
+    if (i == 0) { *len_snap = len; slow_hdr[par ^ 1u] = 0u; }
     const uint32_t first = i - (uint32_t)lane;
     if (first >= len) return;
     const uint32_t n_valid = (len - first) < 64u ? (len - first) : 64u;
@@ -381,8 +391,8 @@ __global__ __launch_bounds__(128) void buffered_walk(SceneParams P, const BufSta
             } else {
                 wr = WriteRec{};
                 wr.info = BW_SLOW;
-                const uint32_t k = atomicAdd(&slow_hdr[0], 1u);
-                slow_hdr[1 + k] = i;
+                const uint32_t k = atomicAdd(&slow_hdr[par], 1u);
+                slow_hdr[2 + k] = i;
 #pragma unroll
                 for (int t = 0; t < REC_TILES; ++t) { tr[t] = TileRec{}; if ((uint32_t)t < n_tiles) tr[t].info = PATH_ROW; }
             }
@@ -458,7 +468,7 @@ __global__ __launch_bounds__(64) void buffered_write(const WriteRec* __restrict_
     if (g_hi > n_groups) g_hi = n_groups;
     const uint32_t lds_base = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uintptr_t)smem);
     float* ck = reinterpret_cast<float*>(smem + BW_LDS_CK);
-    const int slot = lane >> 4, jA = lane & 15;
+    const int slot = lane >> BW_GROUP_LOG2, jA = lane & (BW_GROUP - 1);
     int buf = 0;
     for (uint32_t g = g_lo; g < g_hi; ++g) {
         // ------------------------------ phase A: the running sums of the group ------------------------------
@@ -488,14 +498,26 @@ __global__ __launch_bounds__(64) void buffered_write(const WriteRec* __restrict_
         }
         const unsigned long long fast_mask = __ballot(slot == 0 && (infoA & 7u) == BW_FAST);   // bit j: source j of the group is rendered here
         if (fast_mask == 0ull) continue;
+        // lanes 0-15 keep the record of source `lane` in registers for the whole group: phase B takes a source's (wave-uniform)
+        // words from there with v_readlane -- fetched from memory at the point of use, every source paid a scalar-load latency
+        uint32_t recw[28];
+        {
+            const uint4* rp = reinterpret_cast<const uint4*>(wrecs + g * BW_GROUP + (uint32_t)(lane & (BW_GROUP - 1)));
+#pragma unroll
+            for (int q = 0; q < 7; ++q) {
+                uint4 v = make_uint4(0u, 0u, 0u, 0u);
+                if (lane < BW_GROUP && g * BW_GROUP + (uint32_t)lane < n_sources) v = rp[q];
+                recw[4 * q] = v.x; recw[4 * q + 1] = v.y; recw[4 * q + 2] = v.z; recw[4 * q + 3] = v.w;
+            }
+        }
+#define ODDIO_RW(K, J) ((uint32_t)__builtin_amdgcn_readlane((int)recw[(K)], (J)))
+#define ODDIO_RF(K, J) __int_as_float(__builtin_amdgcn_readlane((int)recw[(K)], (J)))
         // the first window is on its way while the sums are scanned
         int cur = __builtin_ctzll(fast_mask);
 #define ODDIO_BW_ISSUE(J, BUF)                                                                                            \
     {                                                                                                                     \
-        const WriteRec* r_ = wrecs + (g * BW_GROUP + (uint32_t)(J));                                                      \
-        const uint32_t i_ = (uint32_t)__builtin_amdgcn_readfirstlane((int)r_->info);                                      \
-        leaf_window_dma(lds_base + (uint32_t)((BUF) ? BW_LDS_WIN1 : BW_LDS_WIN0), (uint32_t)__builtin_amdgcn_readfirstlane((int)r_->desc[0]), \
-                        (uint32_t)__builtin_amdgcn_readfirstlane((int)r_->desc[1]), (uint32_t)__builtin_amdgcn_readfirstlane((int)r_->desc[2]), \
+        const uint32_t i_ = ODDIO_RW(3, (J));                                                                             \
+        leaf_window_dma(lds_base + (uint32_t)((BUF) ? BW_LDS_WIN1 : BW_LDS_WIN0), ODDIO_RW(0, (J)), ODDIO_RW(1, (J)), ODDIO_RW(2, (J)),  \
                         (int)((i_ >> 8) & 0xfffu), (int)((i_ >> 20) & 0xffu), lane16);                                    \
     }
         ODDIO_BW_ISSUE(cur, buf)
@@ -531,27 +553,30 @@ __global__ __launch_bounds__(64) void buffered_write(const WriteRec* __restrict_
         }
         // ------------------------------ phase B: one source at a time ------------------------------
         unsigned long long todo = fast_mask;
+        int light = 0;            // VMEM instructions issued after the window that is waited for next, when their number is known (4-6); else 0
         while (todo) {
             const int j = cur;
             todo &= todo - 1ull;
             const uint32_t src = g * BW_GROUP + (uint32_t)j;
-            const WriteRec* r = wrecs + src;
-            const uint32_t info = (uint32_t)__builtin_amdgcn_readfirstlane((int)r->info);
+            const uint32_t info = ODDIO_RW(3, j);
             unsigned char* win_bytes = smem + (buf ? BW_LDS_WIN1 : BW_LDS_WIN0);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this source's window has landed
+            // this source's window has landed.  (vmcnt counts loads and stores in issue order: everything issued after the window
+            // -- the ring stores of the source before, `light` of them -- may stay in flight; waiting for those stores too, a
+            // full write latency per source, made the kernel 2x slower)
+            if (light == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else if (light == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+            else if (light == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             if (todo) { cur = __builtin_ctzll(todo); ODDIO_BW_ISSUE(cur, buf ^ 1) }
-            float* const ring = reinterpret_cast<float*>(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)((uint64_t)r->ring >> 32)) << 32) |
-                                                         (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint64_t)r->ring));
-            const uint32_t rlen = (uint32_t)__builtin_amdgcn_readfirstlane((int)r->ring_len);
-            const uint32_t start_idx = (uint32_t)__builtin_amdgcn_readfirstlane((int)r->start_idx);
-            const float ds = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(r->ds)));
-            const float fr0 = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(r->frac0[0])));
-            const float fr1 = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(r->frac0[1])));
-            const uint32_t wrelw = (uint32_t)__builtin_amdgcn_readfirstlane((int)r->wrel);
+            float* const ring = reinterpret_cast<float*>(((uint64_t)ODDIO_RW(5, j) << 32) | (uint64_t)ODDIO_RW(4, j));
+            const uint32_t rlen = ODDIO_RW(6, j);
+            const uint32_t start_idx = ODDIO_RW(7, j);
+            const float fr0 = ODDIO_RF(8, j), fr1 = ODDIO_RF(9, j), ds = ODDIO_RF(10, j);
+            const uint32_t wrelw = ODDIO_RW(11, j);
             const int wrel0 = (int)(wrelw & 0xffffu), wrel1 = (int)(wrelw >> 16);
-            const uint32_t cntw = (uint32_t)__builtin_amdgcn_readfirstlane((int)r->cnt);
+            const uint32_t cntw = ODDIO_RW(12, j);
             const uint32_t cnt1 = cntw & 0xffffu, cnt = cntw >> 16;
-            const uint32_t ops = (uint32_t)__builtin_amdgcn_readfirstlane((int)r->ops);
+            const uint32_t ops = ODDIO_RW(13, j);
             const int nvec = (int)((info >> 8) & 0xfffu);
             const bool pad = (info & BWF_PAD) != 0u, leaf_fast = (info & BWF_LEAF_FAST) != 0u, seg2 = (info & BWF_SEG2) != 0u;
             if (pad) leaf_repack_padded(win_bytes, nvec, lane);
@@ -623,16 +648,16 @@ __global__ __launch_bounds__(64) void buffered_write(const WriteRec* __restrict_
                 if (w >= n_wrap) break;
                 const uint32_t kind = (ops >> (4 + 2 * w)) & 3u;
                 if (kind == 0u) {
-                    const float cw = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(r->c[w])));
+                    const float cw = ODDIO_RF(14 + w, j);
                     if (cw != 1.0f) {
 #pragma unroll
                         for (int k = 0; k < 16; ++k) out[k] = out[k] * cw;
                     }
                 } else {
                     const int ri = (int)kind - 1;
-                    const float prev = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(r->rprev[ri])));
-                    const float next = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(r->rnext[ri])));
-                    const float step = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(r->rstep[ri])));
+                    const float prev = ri ? ODDIO_RF(19, j) : ODDIO_RF(18, j);
+                    const float next = ri ? ODDIO_RF(21, j) : ODDIO_RF(20, j);
+                    const float step = ri ? ODDIO_RF(25, j) : ODDIO_RF(24, j);
                     float p = ckl[BW_GROUP * (int)kind + j];
                     float pfin = p;
 #pragma unroll
@@ -647,42 +672,58 @@ __global__ __launch_bounds__(64) void buffered_write(const WriteRec* __restrict_
                 }
             }
             // ---- Ring::write's stores (ring.rs:33-38) ----
+            // A lane holds 16 consecutive frames; stored from there, every instruction would touch 64 lines with 16 bytes each
+            // (8 partial writes per 128-byte line: the kernel was bound by the L2's request rate, 104 M requests per launch).
+            // The frames go through the window buffer just consumed instead (frame f at byte 4 f + 16 (f >> 6): the 16-byte
+            // pad per 64 frames keeps the 64-byte lane rows off each other's banks) and leave as whole kilobytes.
+            {
+                float4* stg = reinterpret_cast<float4*>(win_bytes + 64 * lane + 16 * (lane >> 2));
+#pragma unroll
+                for (int q = 0; q < 4; ++q) stg[q] = make_float4(out[4 * q], out[4 * q + 1], out[4 * q + 2], out[4 * q + 3]);
+            }
+            wave_sync();
             if (!(info & BWF_SPECIAL)) {
-                float* dst = ring + start_idx + f0;
+                float* dst = ring + start_idx + 4u * (uint32_t)lane;
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    f4u v4 = {out[4 * q], out[4 * q + 1], out[4 * q + 2], out[4 * q + 3]};
-                    *reinterpret_cast<f4u*>(dst + 4 * q) = v4;
+                    const float4 v = *reinterpret_cast<const float4*>(win_bytes + 1024 * q + 16 * lane + 16 * (4 * q + (lane >> 4)));
+                    f4u v4 = {v.x, v.y, v.z, v.w};
+                    *reinterpret_cast<f4u*>(dst + 256 * q) = v4;
                 }
             } else {
 #pragma unroll 1
                 for (int k = 0; k < 16; ++k) {
-                    const uint32_t f = f0 + (uint32_t)k;
+                    const uint32_t f = 64u * (uint32_t)k + (uint32_t)lane;
+                    const float v = *reinterpret_cast<const float*>(win_bytes + 272 * k + 4 * lane);
                     if (f < cnt) {
                         const uint32_t idx = f < cnt1 ? start_idx + f : f - cnt1;
-                        ring[idx] = out[k];
-                        if (idx < RING_MIRROR) ring[rlen + idx] = out[k];     // the mirror behind the ring's end
+                        ring[idx] = v;
+                        if (idx < RING_MIRROR) ring[rlen + idx] = v;     // the mirror behind the ring's end
                     }
                 }
             }
+            // stores of this source: 4 vector stores + one per ramping Gain (its progress), issued after the next window's DMA
+            light = (info & BWF_SPECIAL) ? 0 : 4 + (int)(((ops >> 4) & 3u) != 0u) + (int)(((ops >> 6) & 3u) != 0u) + (int)(((ops >> 8) & 3u) != 0u) + (int)(((ops >> 10) & 3u) != 0u);
             wave_sync();      // every lane is done with this window buffer before it is refilled two sources on
             buf ^= 1;
         }
 #undef ODDIO_BW_ISSUE
+#undef ODDIO_RW
+#undef ODDIO_RF
     }
 }
 
 // The general kernel's rendering of the sources buffered_walk left on the slow list (every shape the ABI accepts), after
 // the walk: Ring::write through inner_sample_wave / fader_sample_wave, the per-ear Ring::sample reads into the source's
 // slab row, and the mirror behind the ring's end.  grid = any; workgroup w takes list entries w, w + gridDim.x, ...
-__global__ __launch_bounds__(64) void buffered_sources_slow(SceneParams P, const uint32_t* __restrict__ slow_hdr, BufStatic* __restrict__ st,
+__global__ __launch_bounds__(64) void buffered_sources_slow(SceneParams P, const uint32_t* __restrict__ slow_hdr, uint32_t par, BufStatic* __restrict__ st,
                                                             BufDyn* __restrict__ dyn, const BufEarPair* __restrict__ bear,
                                                             float* __restrict__ contrib, FaderRec* __restrict__ faders, float* __restrict__ fader_scratch) {
     __shared__ float ck[8][64];
     const int lane = threadIdx.x;
-    const uint32_t n_slow = slow_hdr[0];
+    const uint32_t n_slow = slow_hdr[par];
     for (uint32_t q = blockIdx.x; q < n_slow; q += gridDim.x) {
-        const uint32_t i = slow_hdr[1 + q];
+        const uint32_t i = slow_hdr[2 + q];
         BufStatic s = st[i];
         BufDyn d = dyn[i];
         const BufEarPair be = bear[i];

@@ -20,7 +20,7 @@ for path in glob.glob(os.path.join(root, "**", "*counter_collection.csv"), recur
                 pass
 out = {}
 for k, counters in acc.items():
-    if not any(t in k for t in ("spatial_", "reduce_", "mixer_", "ordered_")):
+    if not any(t in k for t in ("spatial_", "reduce_", "mixer_", "ordered_", "buffered_")):
         continue
     out[k] = {c: sum(v) / len(v) for c, v in sorted(counters.items())}
     out[k]["_dispatches"] = max(len(v) for v in counters.values())
