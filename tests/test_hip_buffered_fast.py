@@ -263,3 +263,67 @@ def test_ordered_rows_path_above_the_serial_threshold():
         assert scene.debug_buffered_slow() == 0
         np.testing.assert_array_equal(b, a, err_msg=f"callback {cb}")
     scene.close()
+
+
+def test_65536_buffered_sources_ordered_bit_exact_fast_vs_f64():
+    """BASELINE configs[3]'s per-GPU size with every source played through play_buffered as Gain<Speed<FramesSignal>>.
+    ORDERED (contribution rows + ordered_sum): bit-exact.  FAST (tree sum over the whole chip): at this source count the
+    reference's own sequential f32 sum is further than 1e-5 from the exact sum, so FAST is held to the exact
+    (f64-accumulated) sum of the reference's contributions, and to the reference within the two sums' own distances."""
+    import oddio_amd as oa
+    n_src, n_cb = 65536, 3
+    fast_vs_exact_tol = 2e-6
+    sc = synth.make_scene(91, n_src, cube=10.0, vmax=10.0)
+    rng = np.random.default_rng(91)
+    speeds = (1.0 + rng.uniform(-0.1, 0.1, n_src)).astype(np.float32)
+    gains0 = rng.uniform(0.3, 1.0, n_src).astype(np.float32)
+    gains1 = rng.uniform(0.0, 1.2, n_src).astype(np.float32)
+    starts = rng.uniform(0.0, 0.05, n_src)
+    bank = [synth.noise_clip(92, k, 12000) for k in range(256)]
+
+    def oracle_run(acc64):
+        ref = oc.SpatialScene()
+        frames = [oc.Frames(48000, c) for c in bank]
+        ctl = []
+        for i in range(n_src):
+            sp = oc.Speed(oc.FramesSignal(frames[i % 256], float(starts[i])))
+            sp.set_speed(speeds[i])
+            g = oc.Gain(sp)
+            g.init_amplitude_ratio(gains0[i])
+            ref.play_buffered(g, oc.SpatialOptions(sc["position"][i], sc["velocity"][i], 0.1), 30.0, 48000, 0.03)
+            ctl.append(g)
+        outs = []
+        for cb in range(n_cb):
+            if cb == 1:
+                for i in range(0, n_src, 3):
+                    ctl[i].set_amplitude_ratio(gains1[i])
+            outs.append(ref.sample_f64acc(INTERVAL, 1024) if acc64 else ref.sample_n(INTERVAL, 1024))
+        return outs
+
+    ref32, ref64 = oracle_run(False), oracle_run(True)
+    got = {}
+    for mode in (oa.MODE_ORDERED, oa.MODE_FAST):
+        control, scene = oa.SpatialScene(max_sources=n_src, max_frames=1024)
+        scene.reserve_buffered(n_src)
+        scene.set_mode(mode)
+        bank_h = [oa.Frames.from_slice(48000, c) for c in bank]
+        ids = control.play_buffered_frames_batch([bank_h[i % 256] for i in range(n_src)], starts, [oa.FILTER_SPEED, oa.FILTER_GAIN],
+                                                 np.stack([speeds, gains0], axis=1), sc["position"], sc["velocity"], sc["radius"], 30.0, 48000, 0.03)
+        outs = []
+        for cb in range(n_cb):
+            if cb == 1:
+                control.set_control_batch(ids[::3], 1, gains1[::3])
+            outs.append(scene.sample_n(INTERVAL, 1024))
+            assert scene.debug_buffered_slow() == 0
+        got[mode] = outs
+        scene.close()
+    for cb in range(n_cb):
+        np.testing.assert_array_equal(got[oa.MODE_ORDERED][cb], ref32[cb], err_msg=f"ORDERED callback {cb}")
+        scale = float(np.abs(ref32[cb]).max())
+        g64 = got[oa.MODE_FAST][cb].astype(np.float64)
+        e_exact = float(np.abs(g64 - ref64[cb]).max())
+        e_ref = float(np.abs(g64 - ref32[cb].astype(np.float64)).max())
+        e_refexact = float(np.abs(ref32[cb].astype(np.float64) - ref64[cb]).max())
+        assert scale > 0
+        assert e_exact <= fast_vs_exact_tol * scale, (cb, e_exact / scale)
+        assert e_ref <= max(FAST_TOL * scale, e_exact + e_refexact), (cb, e_ref / scale, e_refexact / scale)
