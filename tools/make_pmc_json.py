@@ -24,5 +24,13 @@ res = {
     "correction": "read side x2 (gfx950 FETCH_SIZE counts 64 B per 128 B request on wide coalesced loads)",
     "counters": {n: v for n, v in c.items() if not n.startswith("_")},
 }
+# ORDERED mode: the row render (spatial_mix<.., true, ..>) + ordered_sum of one callback
+rows = [k for k in d if k.startswith("spatial_mix<true, true") or k.startswith("spatial_mix<false, true")]
+sums = [k for k in d if k.startswith("ordered_sum")]
+if rows and sums and "FETCH_SIZE" in d[rows[0]] and "FETCH_SIZE" in d[sums[0]]:
+    r_, s_ = d[rows[0]], d[sums[0]]
+    res["ordered_hbm_bytes_per_callback"] = (2.0 * r_["FETCH_SIZE"] + r_.get("WRITE_SIZE", 0.0) + 2.0 * s_["FETCH_SIZE"] + s_.get("WRITE_SIZE", 0.0)) * 1024.0
+    res["ordered_kernels"] = {rows[0]: {"FETCH_SIZE_KiB": r_["FETCH_SIZE"], "WRITE_SIZE_KiB": r_.get("WRITE_SIZE")},
+                              sums[0]: {"FETCH_SIZE_KiB": s_["FETCH_SIZE"], "WRITE_SIZE_KiB": s_.get("WRITE_SIZE")}}
 json.dump(res, open(out, "w"), indent=1)
 print(json.dumps({"hbm_bytes_per_launch": res["hbm_bytes_per_launch"]}))
