@@ -1000,8 +1000,20 @@ __global__ __launch_bounds__(64 * MIX_WG_WAVES, MIX_WAVES_PER_SIMD) void spatial
     }
     const uint32_t cB_abs = tile * TILE_CHUNKS + (uint32_t)cB;
 
-    const uint32_t g_lo = wave * groups_per_wave;
-    uint32_t g_hi = g_lo + groups_per_wave;
+    // Small scenes (fewer groups than resident waves): 2^split waves share a group, each rendering 16 >> split of its
+    // sources -- the callback's latency is a wave's walk, and a quarter of a group is a quarter of the time.  `groups_per_wave`
+    // carries split in its top byte (then one group per 2^split waves).
+    const uint32_t split_log2 = groups_per_wave >> 24;
+    uint32_t g_lo = wave * (groups_per_wave & 0xffffffu);
+    uint32_t g_hi = g_lo + (groups_per_wave & 0xffffffu);
+    unsigned part_mask = 0xffffu;
+    if (split_log2) {
+        g_lo = wave >> split_log2;
+        g_hi = g_lo + 1u;
+        const uint32_t per = (uint32_t)MIX_GROUP >> split_log2;
+        part_mask = ((1u << per) - 1u) << ((wave & ((1u << split_log2) - 1u)) * per);
+    }
+    part_mask = (unsigned)__builtin_amdgcn_readfirstlane((int)part_mask);   // (wave-uniform; the compiler cannot see that: `wave` comes from threadIdx)
     if (g_hi > n_groups) g_hi = n_groups;
 
     // this lane's stream block in phase B belongs to stream 4j + 2e + c: byte offset of source 0's, then 4 blocks per source
@@ -1049,8 +1061,8 @@ __global__ __launch_bounds__(64 * MIX_WG_WAVES, MIX_WAVES_PER_SIMD) void spatial
         const int cA = laneA & 1;
         // bit j of lds_mask: source j of the group takes the staged-window path; rare_mask: an out-of-line path
         const int pj = (int)(vdesc.w & 7u);
-        const unsigned lds_mask = (unsigned)__ballot(pj == PATH_LDS);
-        const unsigned rare_mask = (unsigned)__ballot(pj != PATH_LDS && pj != PATH_SKIP);
+        const unsigned lds_mask = (unsigned)__ballot(pj == PATH_LDS) & part_mask;
+        const unsigned rare_mask = (unsigned)__ballot(pj != PATH_LDS && pj != PATH_SKIP) & part_mask;
         // `cur`: the next staged source of the walk; its window is in flight to / sits in WIN[buf]
         int cur = lds_mask ? 31 - __builtin_clz(lds_mask) : -1;
         uint32_t cur_info = 0;

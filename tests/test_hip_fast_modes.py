@@ -1,7 +1,8 @@
-"""The two tree-sum modes.  With 17-32 sources a callback is rendered by two waves (one per group of 16 slots, each adding
-its sources in descending slot order from zero) whose sums are then added: what MODE_FAST_UNFUSED must produce can be
-written down from single-source oracle renders -- every contribution with the reference's roundings -- and compared bit
-for bit.  MODE_FAST fuses the lerp, the gain ramp and the accumulate in such multi-wave callbacks: it has to stay within
+"""The two tree-sum modes.  With 17-32 sources a callback is rendered by eight waves -- a small scene's groups of 16 slots are
+shared by four waves each (spatial_mix's `split`), every wave adding its four sources in descending slot order from zero --
+whose sums are added in a fixed order: the two waves of a workgroup, then the workgroups in ascending order.  What
+MODE_FAST_UNFUSED must produce can therefore be written down from single-source oracle renders -- every contribution with
+the reference's roundings -- and compared bit for bit.  MODE_FAST fuses the lerp, the gain ramp and the accumulate in such multi-wave callbacks: it has to stay within
 the north_star's 1e-5 of the reference (here: far inside it), not equal."""
 import numpy as np
 import pytest
@@ -47,12 +48,13 @@ def test_unfused_tree_sum_is_the_sum_of_exact_contributions(n_src):
     fused = _render(oa.MODE_FAST, clips, sc, n_cb)
     for cb in range(n_cb):
         waves = []
-        for lo, hi in ((0, 16), (16, n_src)):                   # a wave per group of 16 slots, descending slot order, from zero
+        for lo in range(0, 32, 4):                              # wave w: slots [4 w, 4 w + 4), descending slot order, from zero
             acc = np.zeros((N, 2), dtype=np.float32)
-            for i in range(hi - 1, lo - 1, -1):
+            for i in range(min(lo + 4, n_src) - 1, lo - 1, -1):
                 acc = acc + contrib[i][cb]
             waves.append(acc)
-        want = waves[0] + waves[1]
+        wgs = [waves[2 * k] + waves[2 * k + 1] for k in range(4)]   # the two waves of a workgroup, through LDS
+        want = ((wgs[0] + wgs[1]) + wgs[2]) + wgs[3]              # reduce_partials: workgroups in ascending order
         np.testing.assert_array_equal(unfused[cb], want, err_msg=f"callback {cb}")
         reference = ref.sample_n(INTERVAL, N)
         scale = np.abs(reference).max()
