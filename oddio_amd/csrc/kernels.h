@@ -293,6 +293,13 @@ constexpr int WIN_PIECES = (WIN_CAP * 4 + 1023) / 1024;   // 1 KiB DMA pieces co
 #define ODDIO_PAD_EPS 0.004f
 #endif
 constexpr float PAD_EPS = ODDIO_PAD_EPS;           // |ds - 1| below this: lanes' runs sit 16 samples apart -> padded layout
+// Windows larger than the LDS stage (resample ratios above ~1.11: a 96 or 192 kHz clip in a 48 kHz scene, strong Doppler) are
+// staged in `npass` sub-windows of WIN_CAP samples, MULTI_STRIDE apart; a lane renders its 16 frames in the pass whose
+// sub-window holds its whole run (16 * ds + 2 samples <= the overlap WIN_CAP - MULTI_STRIDE).  TileRec::info bits 24-26: npass.
+constexpr int MULTI_STRIDE = 532;
+constexpr float MULTI_DS_MAX = 4.5f;
+constexpr int MULTI_PASS_MAX = 7;
+static_assert(MULTI_STRIDE % 4 == 0 && WIN_CAP - MULTI_STRIDE >= 16 * 4.5f + 3, "a lane's run fits the overlap of two sub-windows");
 
 enum : int { PATH_SKIP = 0, PATH_LDS = 1, PATH_GENERIC = 2, PATH_SINE = 3, PATH_CONST = 4, PATH_ROW = 5 };
 
@@ -577,21 +584,31 @@ __device__ __forceinline__ TileRec make_tile_rec(const SceneParams& P, const Src
             else fl &= ~SFLAG_PAD;
         }
     }
-    int path;
+    int path, npass = 1;
     if (generic) path = PATH_GENERIC;
     else if (lo > hi) path = PATH_SKIP;              // no frames in this tile
-    else path = (count <= WIN_CAP) ? PATH_LDS : PATH_GENERIC;
+    else if (count <= WIN_CAP) path = PATH_LDS;
+    else {
+        // larger than the stage: sub-windows, if both ears step forward slowly enough for a lane's run to fit their overlap
+        // (the constant-fract branch exists for the padded single window only)
+        npass = (count - WIN_CAP + MULTI_STRIDE - 1) / MULTI_STRIDE + 1;
+        const bool ok = r.ear[0].ds <= MULTI_DS_MAX && r.ear[1].ds <= MULTI_DS_MAX && !(fl & (SFLAG_FAST_L | SFLAG_FAST_R)) && npass <= MULTI_PASS_MAX;
+        path = ok ? PATH_LDS : PATH_GENERIC;
+        fl &= ~SFLAG_PAD;
+    }
     if (path != PATH_LDS) { r.info = (uint32_t)path; return r; }
     if (s.fixed_gain != 1.0f) fl |= SFLAG_FG;
-    const int nvec = (count + 3) >> 2;
-    const int4 d = window_desc(s.clip, (int)((s.clip_len + 3u) & ~3u), ws, nvec);
+    const int nvec_all = (count + 3) >> 2;
+    const int nvec = npass > 1 ? WIN_CAP / 4 : nvec_all;      // per DMA: a whole sub-window (the descriptor clips the last one)
+    const int4 d = window_desc(s.clip, (int)((s.clip_len + 3u) & ~3u), ws, nvec_all);
     r.desc[0] = (uint32_t)d.x; r.desc[1] = (uint32_t)d.y; r.desc[2] = (uint32_t)d.z;
     // a window that starts before the clip: the descriptor base is the clip start and the first -ws/4 vectors are out
     // of range (zeros); one that lies entirely before it has a zero-byte descriptor, any offset reads zeros
     const int negvec = (d.z > 0) ? ((-d.w) >> 4) : 0;
-    (void)ODDIO_BOUNDS_CHECK(P.bounds_err, nvec >= 1 && nvec * 4 <= WIN_CAP && negvec >= 0 && negvec <= 255 && d.z >= 0 && d.z <= nvec * 16 &&
+    if (negvec > 255) { r.info = (uint32_t)PATH_GENERIC; return r; }   // (a large window that starts far before its clip)
+    (void)ODDIO_BOUNDS_CHECK(P.bounds_err, nvec >= 1 && nvec * 4 <= WIN_CAP && negvec >= 0 && negvec <= 255 && d.z >= 0 && d.z <= nvec_all * 16 &&
                              wbase[0][0] - ws >= 0 && wbase[1][1] - ws <= 65535, BOUNDS_RECORD, nvec, tile);
-    r.info = (uint32_t)path | ((uint32_t)fl << 3) | ((uint32_t)nvec << 8) | ((uint32_t)negvec << 16);
+    r.info = (uint32_t)path | ((uint32_t)fl << 3) | ((uint32_t)nvec << 8) | ((uint32_t)negvec << 16) | ((uint32_t)(npass > 1 ? npass : 0) << 24);
 #pragma unroll
     for (int e = 0; e < 2; ++e) {
         const int w0 = min(max(wbase[e][0] - ws, 0), 65535), w1 = min(max(wbase[e][1] - ws, 0), 65535);
@@ -674,16 +691,16 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 // which would serialise the prefetch of the next source with the reads of the current one.  Completion is awaited
 // with window_wait().  d0..d2, info: wave-uniform words of the source's TileRec; lane16 = 16 * lane.
 constexpr int WIN_LAST_LANES = (WIN_BYTES - 2048) / 16;   // lanes of the third piece that stay inside the window buffer
-__device__ __forceinline__ void window_dma(uint32_t lds_dst, uint32_t d0, uint32_t d1, uint32_t d2, uint32_t info, int lane16) {
+__device__ __forceinline__ void window_dma(uint32_t lds_dst, uint32_t d0, uint32_t d1, uint32_t d2, uint32_t info, int lane16, int extra = 0) {
     u32x4 rsrc;
     rsrc.x = d0; rsrc.y = d1; rsrc.z = d2;
     rsrc.w = 0x00020000u;
     const int nvec = (int)((info >> 8) & 255u);
     const int neg = -16 * (int)((info >> 16) & 255u);
 #ifdef ODDIO_HIP_BOUNDS
-    if (nvec * 16 > WIN_BYTES || (int)d2 > nvec * 16 + neg + 16) asm volatile("s_trap 2");   // a window larger than its buffer would overwrite a neighbour's LDS
+    if (nvec * 16 > WIN_BYTES || (!(info >> 24) && (int)d2 > nvec * 16 + neg + 16)) asm volatile("s_trap 2");   // a window larger than its buffer would overwrite a neighbour's LDS
 #endif
-    const int voff = neg + lane16;   // negative offsets wrap to huge unsigned values: out of range -> 0
+    const int voff = neg + lane16 + extra;   // negative offsets wrap to huge unsigned values: out of range -> 0  (extra: the sub-window's byte offset)
     uint32_t keep;
     // pieces 0 and 1 from every lane: lanes past the window write zeros inside the buffer (harmless, no traffic)
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 4\n\t"
@@ -1132,7 +1149,11 @@ __global__ __launch_bounds__(64 * MIX_WG_WAVES, MIX_WAVES_PER_SIMD) void spatial
         // VAR: 0 the common source (no FixedGain, non-negative cursor), 1 padded layout (resample ratio within PAD_EPS
         // of 1), 2 FixedGain and/or a cursor that starts negative; -1: decided here (wave-uniform branches)
 #define ODDIO_VARIANT(INFO) (RING ? ((((INFO) >> 3) & SFLAG_WRAP) ? 3 : ((((INFO) >> 3) & SFLAG_PAD) ? 1 : 0)) \
-                                  : ((((INFO) >> 3) & SFLAG_PAD) ? 1 : ((((INFO) >> 3) & (SFLAG_FG | SFLAG_NEG)) ? 2 : 0)))
+                                  : ((((INFO) >> 24) & 7u) ? 2 : ((((INFO) >> 3) & SFLAG_PAD) ? 1 : ((((INFO) >> 3) & (SFLAG_FG | SFLAG_NEG)) ? 2 : 0))))
+        // A source whose window is larger than the stage (info bits 24-26 = its number of sub-windows) takes variant 2's loop
+        // once per sub-window: `mpass` counts them; a pass starts the next sub-window instead of the next source's window, and
+        // only the lanes whose runs lie in its sub-window render.
+        int mpass = 0;
 #define ODDIO_STAGED_SOURCE(VAR, PRE)                                                                                        \
     {                                                                                                                     \
         const int flags_j = (int)((cur_info >> 3) & 31u);                                                                 \
@@ -1149,7 +1170,13 @@ __global__ __launch_bounds__(64 * MIX_WG_WAVES, MIX_WAVES_PER_SIMD) void spatial
         uint32_t nxt_info = 0;                                                                                            \
         float nx0 = 0.0f;                                                                                                 \
         float4 nt = make_float4(0.0f, 0.0f, 0.0f, 0.0f);                                                                  \
-        if (nxt >= 0) {   /* start the next staged source of this group; lands while we compute */                       \
+        const int npass_ = (!RING && (var_j == 2)) ? (int)((cur_info >> 24) & 7u) : 0;                                    \
+        const bool more_ = mpass + 1 < npass_;                                                                            \
+        if (more_) {      /* the source's next sub-window */                                                              \
+            window_dma(lds_slice + (uint32_t)((buf ^ 1) ? LDS_WIN1 : LDS_WIN0), (uint32_t)__builtin_amdgcn_readlane((int)vdesc.x, cur), \
+                       (uint32_t)__builtin_amdgcn_readlane((int)vdesc.y, cur), (uint32_t)__builtin_amdgcn_readlane((int)vdesc.z, cur), cur_info, lane16, \
+                       4 * MULTI_STRIDE * (mpass + 1));                                                                   \
+        } else if (nxt >= 0) {   /* start the next staged source of this group; lands while we compute */                \
             nxt_info = (uint32_t)__builtin_amdgcn_readlane((int)vdesc.w, nxt);                                            \
             ODDIO_ISSUE_WINDOW(nxt, buf ^ 1)                                                                              \
             ODDIO_LANE_DATA(nxt, nx0, nt)                                                                                 \
@@ -1159,7 +1186,7 @@ __global__ __launch_bounds__(64 * MIX_WG_WAVES, MIX_WAVES_PER_SIMD) void spatial
             if (nm_) { ODDIO_ISSUE_WINDOW_OF(pv, 31 - __builtin_clz(nm_), buf ^ 1) pre_issued = true; }                   \
         }                                                                                                                 \
         const int wrel4 = __float_as_int(ct.x);                                                                           \
-        if (RING && var_j == 3) {                                                                                         \
+        if (RING && var_j == 3) {                                                                                  \
             /* a lane whose checkpoint lies behind its stream's start has already been rewritten: its window position is */ \
             /* one ring length further on */                                                                              \
             const int rlen_ = __builtin_amdgcn_readlane((int)vdesc.z, cur);                                               \
@@ -1176,10 +1203,19 @@ __global__ __launch_bounds__(64 * MIX_WG_WAVES, MIX_WAVES_PER_SIMD) void spatial
             mix_source_lds<FULL, false, true, false, FUSED>(win_bytes, wrel4, cx0, bB, 0, 0.0f, acc, fi, frame0, n_frames, 1.0f, ct.y, ct.z, ct.w, 4 * (int)((cur_info >> 8) & 255u), P.bounds_err); \
         } else {                                                                                                          \
             const float fg = (!RING && (flags_j & SFLAG_FG)) ? st[g * MIX_GROUP + (uint32_t)cur].fixed_gain : 1.0f;       \
-            mix_source_lds<FULL, true, false, false, FUSED>(win_bytes, wrel4, cx0, bB, 0, 0.0f, acc, fi, frame0, n_frames, fg, ct.y, ct.z, ct.w, 4 * (int)((cur_info >> 8) & 255u), P.bounds_err); \
+            bool on_ = true;                                                                                              \
+            int w4_ = wrel4;                                                                                              \
+            if (npass_) {   /* the lanes whose runs lie in this sub-window (the last one takes what lies beyond it too) */ \
+                int lp_ = ((wrel4 >> 2) + (int)cx0) / MULTI_STRIDE;                                                       \
+                lp_ = lp_ < 0 ? 0 : (lp_ > npass_ - 1 ? npass_ - 1 : lp_);                                                \
+                on_ = lp_ == mpass;                                                                                       \
+                w4_ = wrel4 - 4 * MULTI_STRIDE * mpass;                                                                   \
+            }                                                                                                             \
+            if (on_) mix_source_lds<FULL, true, false, false, FUSED>(win_bytes, w4_, cx0, bB, 0, 0.0f, acc, fi, frame0, n_frames, fg, ct.y, ct.z, ct.w, 4 * (int)((cur_info >> 8) & 255u), P.bounds_err); \
         }                                                                                                                 \
         buf ^= 1;                                                                                                         \
-        cur = nxt; cur_info = nxt_info; cx0 = nx0; ct = nt;                                                               \
+        if (more_) ++mpass;                                                                                               \
+        else { mpass = 0; cur = nxt; cur_info = nxt_info; cx0 = nx0; ct = nt; }                                           \
     }
         // STORE: the accumulators hold exactly one source's contribution (0 + p); write the rows, start the next from zero
         // (a skipped source -- stopped, or no frames in this tile -- leaves a row of zeros: x + 0.0 == x for every x the
@@ -1241,7 +1277,7 @@ __global__ __launch_bounds__(64 * MIX_WG_WAVES, MIX_WAVES_PER_SIMD) void spatial
 #pragma unroll 1
             for (int j = MIX_GROUP - 1; j >= 0; --j) {
                 if (j == cur) {
-                    ODDIO_STAGED_SOURCE(-1, false)
+                    do ODDIO_STAGED_SOURCE(-1, false) while (!RING && mpass != 0);   // (every sub-window of a large window)
                 } else if ((rare_mask >> j) & 1u) {
                     ODDIO_RARE_SOURCE(j)
                 }

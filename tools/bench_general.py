@@ -42,6 +42,31 @@ def main():
             control.play(g)
         print(f"mixer general path (Gain<MonoToStereo<FramesSignal>>): {n_src:5d} -> {time_calls(mixer):8.3f} ms / 1024-frame callback")
         mixer.close()
+    # Seek-set sources beside the 48 kHz FramesSignal (round 4: the cliffs of the Seek set -- resample ratios above 1.11, Sine,
+    # Downmix, Cycle -- against the staged-window path at the same source count)
+    n_src = 4096
+    sc = synth.make_scene(5, n_src)
+    clips = {rate: oa.Frames.from_slice(rate, synth.noise_clip(9, rate // 1000, 40 * rate)) for rate in (48000, 96000, 192000)}
+    st2 = oa.Frames.from_slice(48000, np.stack([synth.noise_clip(4, 0, 480000), synth.noise_clip(4, 1, 480000)], axis=1))
+    cyc4 = oa.Frames.from_slice(48000, synth.noise_clip(2, 0, 5000))
+    makers = [
+        ("FramesSignal, 48 kHz clip (the staged-window path)", lambda i: oa.FramesSignal(clips[48000], 1.0), n_src),
+        ("FramesSignal, 96 kHz clip (resample ratio 2)", lambda i: oa.FramesSignal(clips[96000], 1.0), n_src),
+        ("FramesSignal, 192 kHz clip (resample ratio 4)", lambda i: oa.FramesSignal(clips[192000], 1.0), n_src),
+        ("Sine", lambda i: oa.Sine(0.1 * i, 110.0 + 0.25 * i), n_src),
+        ("Downmix<FramesSignal<[f32;2]>>", lambda i: oa.Downmix(oa.FramesSignal(st2, 1.0)), n_src),
+        ("Cycle", lambda i: oa.Cycle(cyc4), 1024),
+    ]
+    base_ms = None
+    for name, mk, count in makers:
+        control, scene = oa.SpatialScene(max_sources=8192, max_frames=1024)
+        for i in range(count):
+            control.play(mk(i), oa.SpatialOptions(sc["position"][i], sc["velocity"][i], 0.1))
+        ms = time_calls(scene)
+        if base_ms is None:
+            base_ms = ms
+        print(f"Seek-set {name}: {count:5d} -> {ms:8.3f} ms / 1024-frame callback ({ms / base_ms * (n_src / count):5.2f}x the 48 kHz FramesSignal time per source)")
+        scene.close()
     for n_src in (64, 4096):
         control, scene = oa.SpatialScene(max_sources=8192, max_frames=1024)
         sc = synth.make_scene(5, n_src)
