@@ -301,7 +301,7 @@ constexpr float MULTI_DS_MAX = 4.5f;
 constexpr int MULTI_PASS_MAX = 7;
 static_assert(MULTI_STRIDE % 4 == 0 && WIN_CAP - MULTI_STRIDE >= 16 * 4.5f + 3, "a lane's run fits the overlap of two sub-windows");
 
-enum : int { PATH_SKIP = 0, PATH_LDS = 1, PATH_GENERIC = 2, PATH_SINE = 3, PATH_CONST = 4, PATH_ROW = 5 };
+enum : int { PATH_SKIP = 0, PATH_LDS = 1, PATH_GENERIC = 2, PATH_SINE = 3, PATH_CONST = 4, PATH_ROW = 5, PATH_SINE_INLINE = 6 };
 
 // LDS map of one wave (bytes)
 //   WIN0/WIN1 two window buffers.  General sources: plain (sample s at 4*s), pairs read with
@@ -523,7 +523,30 @@ __device__ __forceinline__ int4 window_desc(const float* clip, int clip_len4, in
 __device__ __forceinline__ TileRec make_tile_rec(const SceneParams& P, const SrcStatic& s, const EarParams& e0, const EarParams& e1, uint32_t tile) {
     TileRec r = {};                                  // info == 0: PATH_SKIP
     if (e0.flags & EAR_SKIP) return r;
-    if (s.kind == KIND_SINE) { r.info = PATH_SINE; return r; }
+    if (s.kind == KIND_SINE) {
+        // sine.rs:34-40 inside the spatial chunk loop.  The record carries what a lane needs -- frequency, FixedGain factor, per
+        // ear {dt, g0, dg}, per chunk the phase the chunk starts from (the `fmodf` chain of sine.rs:39 over the chunks before) --
+        // so that spatial_mix renders the source inline, accumulators in registers, unless the argument of `sin` can leave the
+        // range its argument reduction is exact for (then: the out-of-line path with the library's sinf).
+        r.info = PATH_SINE;
+        r.desc[0] = __float_as_uint(s.freq_or_value); r.desc[1] = __float_as_uint(s.fixed_gain);
+        bool small = true;
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const EarParams& ep = e ? e1 : e0;
+            r.ear[e].ds = ep.dt; r.ear[e].g0 = ep.g0; r.ear[e].dg = ep.dg; r.ear[e].wrel = 0u;
+            float ph = ep.phase_ear;
+            for (uint32_t cc = 0; cc < tile * TILE_CHUNKS; ++cc) ph = fmodf(ph + (ep.dt * 256.0f) * s.freq_or_value, ODDIO_TAU);
+#pragma unroll
+            for (int c = 0; c < TILE_CHUNKS; ++c) {
+                r.frac0[e][c] = ph;
+                ph = fmodf(ph + (ep.dt * 256.0f) * s.freq_or_value, ODDIO_TAU);
+            }
+            if (!(fabsf((ep.dt * 255.0f) * s.freq_or_value) < 12000.0f)) small = false;     // (also false for NaN)
+        }
+        if (small) r.info = PATH_SINE_INLINE;
+        return r;
+    }
     if (s.kind == KIND_CONSTANT) { r.info = PATH_CONST; return r; }
     if (s.kind == KIND_CYCLE) { r.info = PATH_ROW; return r; }
     if (s.kind != KIND_FRAMES) { r.info = PATH_GENERIC; return r; }   // Downmix: exact per-lane path
@@ -840,6 +863,45 @@ __device__ __forceinline__ void mix_source_lds(const unsigned char* win_bytes, i
         __builtin_amdgcn_sched_barrier(0);
     }
 #undef ODDIO_ISSUE
+}
+
+// sin(x) for |x| < ~12 600: three-constant Cody-Waite reduction by 2 pi (exact products for |k| <= 2^11), a fold to
+// [-pi/2, pi/2] and the odd Taylor polynomial to x^11 (5.7e-8 at the interval's ends).  ~1e-7 absolute, against the
+// reference's libm sinf: inside the Sine tolerance of the tests (1e-5 of max|ref|), like the library's device sinf.
+__device__ __forceinline__ float sin_small(float x) {
+    const float k = __builtin_rintf(x * 0.15915494309189535f);
+    float r = __builtin_fmaf(-k, 6.28125f, x);                               // 2 pi = 6.28125 + 1.9350051879882812e-3 + 3.0199159819e-7
+    r = __builtin_fmaf(-k, 1.9350051879882812e-3f, r);
+    r = __builtin_fmaf(-k, 3.0199159819e-7f, r);
+    const float pi = 3.14159265358979323846f;
+    const float f = __builtin_copysignf(pi, r) - r;                          // sin(r) == sin(pi - r) (r > 0), sin(-pi - r) (r < 0)
+    r = fabsf(r) > 1.57079632679489661923f ? f : r;
+    const float r2 = r * r;
+    float p = -2.5052108385441720e-8f;
+    p = __builtin_fmaf(p, r2, 2.7557319223985893e-6f);
+    p = __builtin_fmaf(p, r2, -1.9841269841269841e-4f);
+    p = __builtin_fmaf(p, r2, 8.3333333333333332e-3f);
+    p = __builtin_fmaf(p, r2, -1.6666666666666666e-1f);
+    return __builtin_fmaf(r * r2, p, r);
+}
+
+// One Sine source on accumulators parked in LDS (slot i of lane l at acc_lds[i * 64 + l], like mix_source_rare -- inline, with the
+// accumulators in registers, the sine's temporaries push the hot kernel into scratch memory):
+// acc[i] += (sin((dt * i) * freq + phase) * fixed_gain) * gain for this lane's 16 frames of its chunk (sine.rs:34-38,
+// gain.rs:32-37, spatial.rs:459-460).  The argument is the reference's, operation for operation; every parameter comes from the
+// source's tile record (no global loads here).
+__device__ __noinline__ void mix_source_sine(float* acc_lds, int lane, uint32_t frame0, uint32_t n_frames, float phase, float dt, float freq,
+                                            float fixed_gain, float g0, float dg) {
+    const float ib = (float)(16 * (lane & 15));
+    const float fbase = (float)frame0;
+#pragma unroll 4
+    for (int i = 0; i < 16; ++i) {
+        const float t = dt * (ib + (float)i);                                // interval * (i as f32): exact integer in f32
+        float v = sin_small(t * freq + phase);
+        v = v * fixed_gain;
+        const float p = v * (g0 + (fbase + (float)i) * dg);
+        if (frame0 + (uint32_t)i < n_frames) acc_lds[i * 64 + lane] = acc_lds[i * 64 + lane] + p;
+    }
 }
 
 // frames.rs:105-123 straight from global memory
@@ -1239,11 +1301,18 @@ __global__ __launch_bounds__(64 * MIX_WG_WAVES, MIX_WAVES_PER_SIMD) void spatial
     {                                                                                                                     \
         const int path_j = __builtin_amdgcn_readlane((int)vdesc.w, (J)) & 7;                                              \
         float* park = reinterpret_cast<float*>(smem);                                                                     \
+        /* (a Sine's parameters: its stream block holds the chunk's phase and {., g0, dg, dt}; read before the park area is written) */ \
+        float ph_ = 0.0f;                                                                                                 \
+        float4 t_ = make_float4(0.0f, 0.0f, 0.0f, 0.0f);                                                                  \
+        if (!RING && path_j == PATH_SINE_INLINE) { ODDIO_LANE_DATA((J), ph_, t_) ph_ = reinterpret_cast<const float*>(blkB0 + (J) * BLK_SRC)[0]; } \
         window_wait();                                                                                                    \
         wave_sync();                                                                                                      \
         _Pragma("unroll") for (int k = 0; k < 16; ++k) park[k * 64 + lane] = acc[k];                                      \
         wave_sync();                                                                                                      \
-        if (RING) mix_source_slab(park, lane, frame0, n_frames, P.cycle_rows + (size_t)(g * MIX_GROUP + (uint32_t)(J)) * P.cycle_plane);    \
+        if (!RING && path_j == PATH_SINE_INLINE)                                                                          \
+            mix_source_sine(park, lane, frame0, n_frames, ph_, t_.w, __int_as_float(__builtin_amdgcn_readlane((int)vdesc.x, (J))), \
+                            __int_as_float(__builtin_amdgcn_readlane((int)vdesc.y, (J))), t_.y, t_.z);                    \
+        else if (RING) mix_source_slab(park, lane, frame0, n_frames, P.cycle_rows + (size_t)(g * MIX_GROUP + (uint32_t)(J)) * P.cycle_plane);    \
         else mix_source_rare(park, lane, frame0, n_frames, cB_abs, path_j, st, ear, g * MIX_GROUP + (uint32_t)(J), P.cycle_rows, P.cycle_plane); \
         wave_sync();                                                                                                      \
         _Pragma("unroll") for (int k = 0; k < 16; ++k) acc[k] = park[k * 64 + lane];                                      \
