@@ -453,7 +453,6 @@ __device__ __forceinline__ void leaf_repack_padded(unsigned char* win_bytes, int
     wave_sync();
 }
 
-typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
 
 // grid = waves (one 64-thread workgroup each); wave w renders groups [w * groups_per_wave, ...) of 16 slots.
 __global__ __launch_bounds__(64) void buffered_write(const WriteRec* __restrict__ wrecs, const uint32_t* __restrict__ len_snap,

@@ -371,84 +371,148 @@ __device__ __forceinline__ void cycle_step(uint32_t& base, float& offset, uint32
     offset = offset + ds;
 }
 
-constexpr int CYCLE_WAVES = 4;   // slots per workgroup (independent waves)
-__global__ __launch_bounds__(64 * CYCLE_WAVES) void cycle_sources(SceneParams P, const SrcStatic* __restrict__ st, SrcDyn* __restrict__ dyn,
-                                                                 const EarParams* __restrict__ ear, const uint32_t* __restrict__ d_len) {
-    __shared__ uint32_t ck_base[CYCLE_WAVES][64];
-    __shared__ float ck_off[CYCLE_WAVES][64];
-    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const uint32_t i = blockIdx.x * CYCLE_WAVES + (uint32_t)wv;
-    if (i >= d_len[0]) return;
+typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));   // four floats at any 4-byte aligned address
+
+// The Seek-set Cycle sources of a callback, two kernels over the list the walk makes of them (cycle_list: [par] = their number
+// this callback -- par = callback parity, the walk zeroes the other counter for the next one -- [2..] their slots):
+//   cycle_scan    one LANE per source: the serial cursor arithmetic of both ears and every chunk (no memory reads), 64 sources
+//                 per wavefront, a (base, offset) checkpoint every 16 frames; advances the cursor.  (Rounds 2-3 ran this scan in
+//                 lane 0 of a wave per source: 45 us of dependent arithmetic per source and wave slot.)
+//   cycle_render  one WAVE per source: the 64 lanes restart from their checkpoints with the same step function and render 16
+//                 frames each into the source's row.
+struct CycleCk { uint32_t base; float offset; };
+__global__ __launch_bounds__(64) void cycle_scan(SceneParams P, const SrcStatic* __restrict__ st, SrcDyn* __restrict__ dyn,
+                                                 const EarParams* __restrict__ ear, const uint32_t* __restrict__ list, uint32_t par,
+                                                 CycleCk* __restrict__ ck, uint32_t ck_stride) {
+    const uint32_t q = blockIdx.x * 64u + threadIdx.x;
+    if (q >= list[par]) return;
+    const uint32_t i = list[2u + q];
     const SrcStatic s = st[i];
-    if (s.kind != KIND_CYCLE) return;
     const EarParams e0 = ear[2 * i], e1 = ear[2 * i + 1];
-    if (e0.flags & EAR_SKIP) return;
-    double cursor = dyn[i].t;                                                 // meaningful in lane 0 from here on
+    double cursor = dyn[i].t;
     const double rate = (double)s.clip_rate, lenf = (double)s.clip_len;
     const uint32_t len = s.clip_len;
     const uint32_t n = P.n_frames;
-    float* row = P.cycle_rows + (size_t)__float_as_uint(s.freq_or_value) * 2u * P.cycle_plane;
+    const uint32_t row = __float_as_uint(s.freq_or_value);
     for (int e = 0; e < 2; ++e) {
         const EarParams ep = e ? e1 : e0;
         const float off0 = ep.phase_ear, eff = (float)ep.t_ear;
+        const float ds = ep.dt * (float)s.clip_rate;                              // cycle.rs:27
+        CycleCk* c = ck + ((size_t)row * 2u + (uint32_t)e) * ck_stride;
+        cursor = f64_rem_euclid(cursor + (double)off0 * rate, lenf);              // spatial.rs:449 -> cycle.rs:57-60
+        for (uint32_t done = 0; done < n; done += 256u) {                         // spatial.rs:456
+            const uint32_t len_c = (n - done) < 256u ? (n - done) : 256u;
+            uint32_t base = (uint32_t)f64_as_isize(cursor);                       // cycle.rs:28 (0 <= cursor < len + 256 * ds)
+            float offset = (float)(cursor - (double)base);                        // :29
+            for (uint32_t k0 = 0; k0 < len_c; k0 += 16u) {
+                CycleCk v; v.base = base; v.offset = offset;
+                c[(done + k0) >> 4] = v;
+                const uint32_t cnt = (len_c - k0) < 16u ? (len_c - k0) : 16u;
+                uint32_t ia, ib; float fract;
+                if (cnt == 16u) {
+#pragma unroll
+                    for (int k = 0; k < 16; ++k) cycle_step(base, offset, len, ds, ia, ib, fract);
+                } else {
+                    for (uint32_t k = 0; k < cnt; ++k) cycle_step(base, offset, len, ds, ia, ib, fract);
+                }
+            }
+            cursor = (double)base + (double)offset;                               // cycle.rs:52
+        }
+        cursor = f64_rem_euclid(cursor + (double)(-eff - off0) * rate, lenf);     // spatial.rs:465
+    }
+    cursor = f64_rem_euclid(cursor + (double)P.elapsed * rate, lenf);             // spatial.rs:468
+    dyn[i].t = cursor;
+}
+
+constexpr int CYCLE_WAVES = 4;   // sources per workgroup (independent waves)
+constexpr int CYCLE_WIN_CAP = 1280;   // samples staged per source, ear and 1024-frame pass (ds <= ~1.24)
+__global__ __launch_bounds__(64 * CYCLE_WAVES) void cycle_render(SceneParams P, const SrcStatic* __restrict__ st, const EarParams* __restrict__ ear,
+                                                                const uint32_t* __restrict__ list, uint32_t par,
+                                                                const CycleCk* __restrict__ ck, uint32_t ck_stride) {
+    __shared__ float win_all[CYCLE_WAVES][CYCLE_WIN_CAP];
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    float* win = win_all[wv];
+    const uint32_t q = blockIdx.x * CYCLE_WAVES + (uint32_t)wv;
+    if (q >= list[par]) return;
+    const uint32_t i = list[2u + q];
+    const SrcStatic s = st[i];
+    const uint32_t len = s.clip_len;
+    const uint32_t n = P.n_frames;
+    const uint32_t rowi = __float_as_uint(s.freq_or_value);
+    float* row = P.cycle_rows + (size_t)rowi * 2u * P.cycle_plane;
+    for (int e = 0; e < 2; ++e) {
+        const EarParams ep = ear[2 * i + e];
         float* plane = row + (size_t)e * P.cycle_plane;
-        const float ds = ep.dt * (float)s.clip_rate;                          // cycle.rs:27
-        if (lane == 0) cursor = f64_rem_euclid(cursor + (double)off0 * rate, lenf);   // spatial.rs:449 -> cycle.rs:57-60
+        const CycleCk* c = ck + ((size_t)rowi * 2u + (uint32_t)e) * ck_stride;
+        const float ds = ep.dt * (float)s.clip_rate;
         for (uint32_t pass0 = 0; pass0 < n; pass0 += 1024u) {
             const uint32_t m = (n - pass0) < 1024u ? (n - pass0) : 1024u;
-            if (lane == 0) {
-                for (uint32_t done = 0; done < m; done += 256u) {             // spatial.rs:456
-                    const uint32_t len_c = (m - done) < 256u ? (m - done) : 256u;
-                    uint32_t base = (uint32_t)f64_as_isize(cursor);           // cycle.rs:28 (0 <= cursor < len + 256 * ds)
-                    float offset = (float)(cursor - (double)base);            // :29
-                    for (uint32_t k0 = 0; k0 < len_c; k0 += 16u) {
-                        ck_base[wv][(done + k0) >> 4] = base; ck_off[wv][(done + k0) >> 4] = offset;
-                        uint32_t ia, ib; float fract;
-                        if (len_c - k0 >= 16u) {
-#pragma unroll
-                            for (int k = 0; k < 16; ++k) cycle_step(base, offset, len, ds, ia, ib, fract);
-                        } else {
-                            for (uint32_t k = k0; k < len_c; ++k) cycle_step(base, offset, len, ds, ia, ib, fract);
-                        }
-                    }
-                    cursor = (double)base + (double)offset;                   // cycle.rs:52
+            // The stretch of the clip this pass reads, staged in LDS with coalesced loads (every lane fetching its own 32
+            // samples touched ~35 lines per load instruction: the kernel was bound by that).  It starts at the first frame's
+            // index and is linear modulo the clip length; a pass that needs more than the stage, or more than one lap of the
+            // clip, reads global memory directly.
+            const CycleCk v0 = c[pass0 >> 4];
+            const float span = (float)m * ds;
+            const bool staged = ds > 0.0f && span * 1.0001f + 8.0f < (float)CYCLE_WIN_CAP && span * 1.0001f + 8.0f < (float)len;
+            const uint32_t w_count = staged ? (uint32_t)(span * 1.0001f) + 8u : 0u;
+            uint32_t w_start = v0.base + f32_as_index(v0.offset);
+            w_start = w_start >= len ? w_start % len : w_start;
+            if (staged) {
+                for (uint32_t p = (uint32_t)lane; p < w_count; p += 64u) {
+                    uint32_t idx = w_start + p;
+                    idx = idx >= len ? idx - len : idx;
+                    win[p] = s.clip[idx];
                 }
             }
             wave_sync();
-            const uint32_t f0 = 16u * (uint32_t)lane;
-            if (f0 < m) {
+            const uint32_t f0 = pass0 + 16u * (uint32_t)lane;
+            if (f0 < n) {
                 const uint32_t done = f0 & ~255u;
-                const uint32_t len_c = (m - done) < 256u ? (m - done) : 256u;
+                const uint32_t len_c = (n - done) < 256u ? (n - done) : 256u;
                 const uint32_t cnt = (len_c - (f0 - done)) < 16u ? (len_c - (f0 - done)) : 16u;
-                uint32_t base = ck_base[wv][lane];
-                float offset = ck_off[wv][lane];
+                const CycleCk v = c[f0 >> 4];
+                uint32_t base = v.base;
+                float offset = v.offset;
                 // the 16 index pairs first (registers only), then all the loads together, then the arithmetic
                 uint32_t ia[16], ib[16]; float fract[16], a[16], b[16];
 #pragma unroll
                 for (int k = 0; k < 16; ++k) cycle_step(base, offset, len, ds, ia[k], ib[k], fract[k]);   // steps past cnt touch nothing
+                if (staged) {
 #pragma unroll
-                for (int k = 0; k < 16; ++k) {
-                    const bool on = (uint32_t)k < cnt;
-                    a[k] = on ? s.clip[ia[k]] : 0.0f;
-                    b[k] = on ? s.clip[ib[k]] : 0.0f;
-                }
+                    for (int k = 0; k < 16; ++k) {
+                        // the stage is linear modulo the clip length: the pair's second sample (ia + 1, or 0 after len - 1) is the next slot
+                        uint32_t pa = ia[k] >= w_start ? ia[k] - w_start : ia[k] + len - w_start;
+                        pa = pa < w_count - 1u ? pa : w_count - 2u;     // (frames past cnt, not stored)
+                        a[k] = win[pa];
+                        b[k] = win[pa + 1u];
+                    }
+                } else {
 #pragma unroll
-                for (int k = 0; k < 16; ++k) {
-                    if ((uint32_t)k < cnt) {
-                        float v = a[k] + fract[k] * (b[k] - a[k]);            // frame::lerp
-                        v = v * s.fixed_gain;                                 // FixedGain, gain.rs:32-37
-                        const uint32_t frame = pass0 + f0 + (uint32_t)k;
-                        plane[frame] = v * (ep.g0 + (float)frame * ep.dg);    // spatial.rs:459-460
+                    for (int k = 0; k < 16; ++k) {
+                        const bool on = (uint32_t)k < cnt;
+                        a[k] = on ? s.clip[ia[k]] : 0.0f;
+                        b[k] = on ? s.clip[ib[k]] : 0.0f;
                     }
                 }
+                float o[16];
+#pragma unroll
+                for (int k = 0; k < 16; ++k) {
+                    float vv = a[k] + fract[k] * (b[k] - a[k]);                   // frame::lerp
+                    vv = vv * s.fixed_gain;                                       // FixedGain, gain.rs:32-37
+                    o[k] = vv * (ep.g0 + (float)(f0 + (uint32_t)k) * ep.dg);      // spatial.rs:459-460
+                }
+                if (cnt == 16u) {
+#pragma unroll
+                    for (int k4 = 0; k4 < 4; ++k4) {
+                        f4u w = {o[4 * k4], o[4 * k4 + 1], o[4 * k4 + 2], o[4 * k4 + 3]};
+                        *reinterpret_cast<f4u*>(plane + f0 + 4 * k4) = w;
+                    }
+                } else {
+                    for (uint32_t k = 0; k < cnt; ++k) plane[f0 + k] = o[k];
+                }
             }
-            wave_sync();   // before the next pass overwrites the checkpoints
+            wave_sync();      // before the next pass / ear refills the stage
         }
-        if (lane == 0) cursor = f64_rem_euclid(cursor + (double)(-eff - off0) * rate, lenf);   // spatial.rs:465
-    }
-    if (lane == 0) {
-        cursor = f64_rem_euclid(cursor + (double)P.elapsed * rate, lenf);     // spatial.rs:468
-        dyn[i].t = cursor;
     }
 }
 
@@ -650,13 +714,13 @@ __global__ __launch_bounds__(256) void spatial_prepass(SceneParams P, const SrcS
                                                        EarParams* __restrict__ ear, uint32_t* __restrict__ stopped_hdr,
                                                        uint32_t stopped_cap, int check_pending, const uint32_t* __restrict__ d_len,
                                                        uint32_t* __restrict__ len_snap, TileRec* __restrict__ recs, uint32_t rec_stride,
-                                                       uint32_t n_rec_tiles, int ear_always) {
+                                                       uint32_t n_rec_tiles, int ear_always, uint32_t* __restrict__ cycle_list, uint32_t cycle_par) {
     __shared__ uint32_t stage[4][64 * 17];
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     const int lane = threadIdx.x & 63;
     uint32_t* lds = stage[threadIdx.x >> 6];
     const uint32_t len = d_len[0];
-    if (i == 0) *len_snap = len;
+    if (i == 0) { *len_snap = len; if (cycle_list) cycle_list[cycle_par ^ 1u] = 0u; }
     const uint32_t first = i - (uint32_t)lane;
     if (first >= len) return;                                       // whole wave past the end
     const uint32_t n_valid = (len - first) < 64u ? (len - first) : 64u;
@@ -667,6 +731,10 @@ __global__ __launch_bounds__(256) void spatial_prepass(SceneParams P, const SrcS
     EarPair ep = {};
     ep.e[0].flags = EAR_SKIP; ep.e[1].flags = EAR_SKIP;
     if (i < len) prepass_source(P, i, d, s, pend, ep.e[0], ep.e[1], stopped_hdr, stopped_cap, check_pending);
+    if (cycle_list && i < len && s.kind == KIND_CYCLE && !(ep.e[0].flags & EAR_SKIP)) {   // the Cycle sources rendered this callback (cycle_scan / cycle_render)
+        const uint32_t k = atomicAdd(&cycle_list[cycle_par], 1u);
+        cycle_list[2u + k] = i;
+    }
     bool needs_ear = false;
     for (uint32_t t = 0; t < n_rec_tiles; ++t) {
         const TileRec r = make_tile_rec(P, s, ep.e[0], ep.e[1], t);
@@ -926,6 +994,14 @@ __device__ __noinline__ void mix_source_rare(float* acc_lds, int lane, uint32_t 
     if (path == PATH_ROW) {
         // Seek-set Cycle: the contribution was rendered by cycle_sources; add it at this source's position
         const float* plane = cycle_rows + ((size_t)__float_as_uint(s.freq_or_value) * 2u + (uint32_t)eB) * cycle_plane;
+        if (frame0 + 16u <= n_frames) {   // all 16 loads in flight together (one at a time, a row cost 16 memory latencies)
+            f4u r[4];
+#pragma unroll
+            for (int k4 = 0; k4 < 4; ++k4) r[k4] = *reinterpret_cast<const f4u*>(plane + frame0 + 4 * k4);
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc_lds[i * 64 + lane] = acc_lds[i * 64 + lane] + r[i >> 2][i & 3];
+            return;
+        }
 #pragma unroll 1
         for (int i = 0; i < 16; ++i)
             if (frame0 + (uint32_t)i < n_frames) acc_lds[i * 64 + lane] = acc_lds[i * 64 + lane] + plane[frame0 + (uint32_t)i];
