@@ -922,7 +922,8 @@ def main():
             line["parity"] = line["cpu_baseline"].pop("parity")
             line["cpu_baseline"]["gpu_over_cpu"] = value / line["cpu_baseline"]["value"]
             if line["cpu_baseline"]["all_cores"]["valid"]:
-                line["cpu_baseline"]["gpu_over_cpu_all_cores"] = value / line["cpu_baseline"]["all_cores"]["value"]
+                # (named after the number of cores the host really gave this job: see cpu_baseline.all_cores.cores / .sample)
+                line["cpu_baseline"][f"gpu_over_cpu_usable_cores_{line['cpu_baseline']['all_cores']['cores']}"] = value / line["cpu_baseline"]["all_cores"]["value"]
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.barrier()

@@ -216,15 +216,20 @@ __global__ void apply_motion_dev(const uint32_t* __restrict__ ids, const float* 
 // The slab is fine-grained memory; everything that crosses a process goes through system-scope atomics (the
 // per-XCD L2s and a peer's caches are not coherent for plain accesses inside a kernel).
 //   slab layout (floats after the header): [header 256 B: arrived[world] | done][result: stride][partial of rank 1..]
-// Waits are bounded (~2 s): a rank that never arrives must not hang the GPU; *err is set instead.
+// Waits are bounded (~2 s): a rank that never arrives must not hang the GPU; *err is set instead, and the host makes the
+// failure sticky for the scene (every later sample call returns ODDIO_HIP_ESTATE until the group is destroyed and re-made:
+// the ranks' source cursors are a callback apart by then, nothing inside the group can re-align them).  The ranks must
+// have passed a barrier of the host program between reduce_init_p2p and the first sample call.
 // ---------------------------------------------------------------------------------------------------------------
 constexpr uint32_t P2P_HEADER_WORDS = 64;      // 256 bytes: arrived[r] at word r (r < 60), done at word 63
 constexpr uint32_t P2P_MAX_WORLD = 60;
 constexpr unsigned long long P2P_TIMEOUT_TICKS = 200000000ull;   // wall_clock64 ticks of 10 ns: 2 s
 
+// waits until *flag has reached `epoch` (wrap-safe: a peer that is already a callback further on satisfies the wait, so one
+// late rank costs one timeout, not one per callback)
 __device__ __forceinline__ bool p2p_wait_equal(const uint32_t* flag, uint32_t epoch) {
     const unsigned long long t0 = wall_clock64();
-    while (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != epoch) {
+    while ((int32_t)(__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) - epoch) < 0) {
         if (wall_clock64() - t0 > P2P_TIMEOUT_TICKS) return false;
         __builtin_amdgcn_s_sleep(16);
     }

@@ -64,6 +64,11 @@ def exchange_p2p_handle(scene, rank: int, world: int, dist=None, src: int = 0) -
     hands its handle to the other ranks over the host program's process group (any backend)."""
     if dist is None:
         import torch.distributed as dist
+    if src != 0:
+        raise ValueError("the slab of the peer-to-peer reduce lives on rank 0 (the rank-ordered sum runs there): src must be 0")
+    if world > 1 and not (dist.is_initialized() and dist.get_world_size() == world):
+        raise RuntimeError(f"exchange_p2p_handle: a process group of {world} ranks is needed to hand the slab's handle over "
+                           f"(torch.distributed is {'not initialised' if not dist.is_initialized() else 'of another size'})")
     if rank == src:
         handle = scene.reduce_init_p2p(0, world)
         if dist.is_initialized() and dist.get_world_size() > 1:
