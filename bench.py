@@ -830,11 +830,20 @@ def main():
         scene.set_mode(oa.MODE_FAST)
 
     ranks_seen = 1
+    per_rank_ms = [elapsed / args.steps * 1e3]
+    reduce_info = scene.reduce_info() if hasattr(scene, "reduce_info") else {"kind": "none", "world": 1, "rccl_version": 0, "rccl_lib": None}
     if dist is not None:
+        # every rank's own time (the line's ms_per_step is their maximum) and what every rank's library says about its reduce group
+        gathered = [None] * world
+        dist.all_gather_object(gathered, {"ms": elapsed / args.steps * 1e3, "reduce": reduce_info})
+        per_rank_ms = [g_["ms"] for g_ in gathered]
         t = torch.tensor([elapsed], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-        ranks_seen = dist.get_world_size()
+        # ranks_seen: from the data path's own communicator when there is one (ncclCommCount / the P2P slab's rank count, on every
+        # rank), else the number of ranks that reported a time
+        worlds = {g_["reduce"]["world"] for g_ in gathered if g_["reduce"]["kind"] != "none"}
+        ranks_seen = worlds.pop() if len(worlds) == 1 else len(gathered)
 
     if rank == 0:
         total_units = float(S) * N_FRAMES * args.steps * world
@@ -883,6 +892,8 @@ def main():
                             "timed in ordered_mode_ms_per_step / ordered_mode_latency_ms",
                 "parallelism": ("single-gpu" if world == 1 else ((f"source-sharded scene + stereo-buffer reduce ({args.reduce})") if sharded else "scene-parallel")),
                 "ranks_seen": ranks_seen,
+                "ms_per_step_by_rank": per_rank_ms,
+                "reduce_group": reduce_info,            # rank 0's: kind, world (ncclCommCount / slab), librccl path and version
             },
             # the figure that conforms to the north_star tolerance at this source count: ORDERED mode (the reference's sum order,
             # bit-exact), callbacks enqueued back to back (`parity` below: FAST is outside 1e-5 of the reference at this size

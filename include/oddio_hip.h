@@ -281,6 +281,11 @@ int oddio_hip_reduce_unique_id(void* unique_id, size_t unique_id_bytes);
 int oddio_hip_scene_reduce_init(oddio_hip_scene* scene, int rank, int world, const void* unique_id,
                                 size_t unique_id_bytes);
 int oddio_hip_scene_reduce_destroy(oddio_hip_scene* scene);
+/* The reduce group as the library sees it: kind 0 none / 1 RCCL all-reduce / 2 peer-to-peer slab; world =
+ * ncclCommCount of the communicator (or the slab's rank count); the librccl the functions were resolved
+ * from and its ncclGetVersion.  For reports: bench.py prints them next to its multi-GPU numbers. */
+int oddio_hip_scene_reduce_info(oddio_hip_scene* scene, int* kind, int* world, int* rccl_version,
+                                char* lib_path, size_t lib_path_bytes);
 /* The same reduction WITHOUT RCCL and with a fixed summation order: every peer writes its
  * 2*n_frames-float partial into a slab in rank 0's device memory (hipIpc: peer-to-peer over xGMI, or the same HBM
  * when ranks share a GPU), rank 0 adds  ((p0 + p1) + p2) + ...  and every rank copies the mix back -- run-to-run and

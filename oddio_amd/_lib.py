@@ -141,6 +141,7 @@ def lib():
         "oddio_hip_reduce_unique_id": (i32, [vp, sz]),
         "oddio_hip_scene_reduce_init": (i32, [vp, i32, i32, vp, sz]),
         "oddio_hip_scene_reduce_destroy": (i32, [vp]),
+        "oddio_hip_scene_reduce_info": (i32, [vp, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32), C.c_char_p, sz]),
         "oddio_hip_scene_reduce_init_p2p": (i32, [vp, i32, i32, vp, sz]),
         "oddio_hip_scene_stream": (i32, [vp, vpp]),
         "oddio_hip_scene_set_stream": (i32, [vp, vp]),

@@ -457,6 +457,13 @@ class _SceneSignal(Signal):
         """(bench) FramesSignal::t = seconds for every buffered FramesSignal leaf, in stream order."""
         _lib.check(_lib.lib().oddio_hip_debug_reset_buffered_clock(self._h, float(seconds)))
 
+    def reduce_info(self) -> dict:
+        """The reduce group as the library sees it: {"kind": "none" | "rccl" | "p2p", "world", "rccl_version", "rccl_lib"}."""
+        kind, world, ver = C.c_int(), C.c_int(), C.c_int()
+        buf = C.create_string_buffer(512)
+        _lib.check(_lib.lib().oddio_hip_scene_reduce_info(self._h, C.byref(kind), C.byref(world), C.byref(ver), buf, 512))
+        return {"kind": ("none", "rccl", "p2p")[kind.value], "world": world.value, "rccl_version": ver.value, "rccl_lib": buf.value.decode() or None}
+
     def set_buffered_fast(self, enable: bool):
         """Which kernels render the buffered set (identical results): the batched path (default) or the general kernel for everything."""
         _lib.check(_lib.lib().oddio_hip_scene_set_buffered_fast(self._h, int(bool(enable))))

@@ -77,6 +77,10 @@ def exchange_p2p_handle(scene, rank: int, world: int, dist=None, src: int = 0) -
         box = [None]
         dist.broadcast_object_list(box, src=src)
         scene.reduce_init_p2p(rank, world, box[0])
+    # every rank has the slab open before any of them renders a callback: the in-kernel waits of the reduce are bounded (2 s),
+    # and a rank that started sampling that much ahead of the others would fail the group (oddio_hip_scene_reduce_init_p2p)
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        dist.barrier()
 
 
 class ShardedSpatialScene:

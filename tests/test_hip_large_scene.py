@@ -273,7 +273,7 @@ def _run_sharded_workers(tmp_path, world, own_gpu, reduce):
     return [np.load(tmp_path / f"rank{r}.npy") for r in range(world)]
 
 
-@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("world", [2, 3, 8])
 def test_sharded_scene_p2p_reduce_ranks_share_one_gpu(tmp_path, world):
     """One seeded scene in `world` contiguous index shards, one PROCESS per rank, all on device 0, through the library's
     deterministic peer-to-peer reduce (rank-ordered sum on rank 0) -- against the same scene unsharded on the HIP path,
@@ -316,6 +316,17 @@ def test_bench_self_launch_two_ranks_sharded():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["config"]["ranks_seen"] == 2 and d["value"] > 0
     assert "p2p" in d["config"]["parallelism"]
+
+
+def test_sharded_scene_two_gpus_p2p(tmp_path):
+    """The peer-to-peer reduce ACROSS devices (hipIpcOpenMemHandle with peer access, stores over xGMI): two ranks, one GPU
+    each, against the rank-ordered sum -- the first thing to look at on a multi-GPU box (conftest.py runs the two-GPU tests first)."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs 2 GPUs; the 1-GPU box runs the same reduce between processes that share the device")
+    got = _run_sharded_workers(tmp_path, 2, own_gpu=True, reduce="p2p")
+    np.testing.assert_array_equal(got[0], got[1])
+    assert np.isfinite(got[0]).all() and np.abs(got[0]).max() > 0
 
 
 def test_sharded_scene_two_gpus_rccl(tmp_path):
