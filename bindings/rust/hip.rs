@@ -66,6 +66,12 @@ extern "C" {
     fn oddio_hip_source_set_gain(s: *mut RawScene, id: u32, filter_index: c_int, amplitude_ratio: f32) -> c_int;
     fn oddio_hip_source_set_gain_db(s: *mut RawScene, id: u32, filter_index: c_int, db: f32) -> c_int;
     fn oddio_hip_source_set_speed(s: *mut RawScene, id: u32, filter_index: c_int, factor: f32) -> c_int;
+    fn oddio_hip_source_get_amplitude_ratio(s: *mut RawScene, id: u32, filter_index: c_int, amplitude_ratio: *mut f32) -> c_int;
+    fn oddio_hip_source_get_gain_db(s: *mut RawScene, id: u32, filter_index: c_int, db: *mut f32) -> c_int;
+    fn oddio_hip_source_get_speed(s: *mut RawScene, id: u32, filter_index: c_int, factor: *mut f32) -> c_int;
+    fn oddio_hip_scene_reserve_buffered(s: *mut RawScene, max_buffered: u32) -> c_int;
+    fn oddio_hip_scene_play_buffered_batch(s: *mut RawScene, n: usize, frames: *const *mut RawFrames, start_seconds: *const f64, filter_kinds: *const c_int, n_filters: c_int, filter_params: *const f32, positions: *const f32, velocities: *const f32, radii: *const f32, max_distance: f32, rate: u32, buffer_duration: f32, ids: *mut u32) -> c_int;
+    fn oddio_hip_scene_set_control_batch(s: *mut RawScene, n: usize, ids: *const u32, filter_index: c_int, values: *const f32) -> c_int;
     fn oddio_hip_source_set_motion(s: *mut RawScene, id: u32, position: *const f32, velocity: *const f32, discontinuity: c_int) -> c_int;
     fn oddio_hip_source_is_finished(s: *mut RawScene, id: u32, finished: *mut c_int) -> c_int;
     fn oddio_hip_source_release(s: *mut RawScene, id: u32) -> c_int;
@@ -83,6 +89,8 @@ extern "C" {
     fn oddio_hip_mixer_play_chain(m: *mut RawMixer, leaf_kind: c_int, f: *mut RawFrames, start_seconds: f64, phase: f32, frequency_hz_or_value: f32, filters: *const RawFilter, n_filters: c_int, id: *mut u32) -> c_int;
     fn oddio_hip_mixer_set_gain(m: *mut RawMixer, id: u32, filter_index: c_int, amplitude_ratio: f32) -> c_int;
     fn oddio_hip_mixer_set_speed(m: *mut RawMixer, id: u32, filter_index: c_int, factor: f32) -> c_int;
+    fn oddio_hip_mixer_get_amplitude_ratio(m: *mut RawMixer, id: u32, filter_index: c_int, amplitude_ratio: *mut f32) -> c_int;
+    fn oddio_hip_mixer_get_speed(m: *mut RawMixer, id: u32, filter_index: c_int, factor: *mut f32) -> c_int;
     fn oddio_hip_mixer_stop(m: *mut RawMixer, id: u32) -> c_int;
     fn oddio_hip_mixer_source_release(m: *mut RawMixer, id: u32) -> c_int;
     fn oddio_hip_mixer_is_stopped(m: *mut RawMixer, id: u32, stopped: *mut c_int) -> c_int;
@@ -242,6 +250,27 @@ impl HipSpatialSceneControl {
         });
         self.spatial(id)
     }
+    /// Capacity of the buffered set, before the first play_buffered (default 256)
+    pub fn reserve_buffered(&mut self, max_buffered: u32) {
+        check(unsafe { oddio_hip_scene_reserve_buffered((self.0).0, max_buffered) });
+    }
+    /// `n` x play_buffered(filters(FramesSignal::new(frames[i], start[i])), ..) under one lock, the rings from one stretch of
+    /// device memory (scenes with 10^5..10^6 Gain / Speed sources); `filter_params` is [n][filter_kinds.len()].  Returns the handle
+    /// ids; `set_control_batch(ids, filter_index, values)` stores to their GainControls / SpeedControls.
+    pub fn play_buffered_frames_batch(&mut self, frames: &[Arc<HipFrames>], start_seconds: &[f64], filter_kinds: &[c_int], filter_params: &[f32], positions: &[[f32; 3]], velocities: &[[f32; 3]], radii: &[f32], max_distance: f32, rate: u32, buffer_duration: f32) -> Vec<u32> {
+        let n = frames.len();
+        assert!(start_seconds.len() == n && positions.len() == n && velocities.len() == n && radii.len() == n && filter_params.len() == n * filter_kinds.len());
+        let raw: Vec<*mut RawFrames> = frames.iter().map(|f| f.0).collect();
+        let mut ids = vec![0u32; n];
+        check(unsafe {
+            oddio_hip_scene_play_buffered_batch((self.0).0, n, raw.as_ptr(), start_seconds.as_ptr(), filter_kinds.as_ptr(), filter_kinds.len() as c_int, filter_params.as_ptr(), positions.as_ptr() as *const f32, velocities.as_ptr() as *const f32, radii.as_ptr(), max_distance, rate, buffer_duration, ids.as_mut_ptr())
+        });
+        ids
+    }
+    pub fn set_control_batch(&mut self, ids: &[u32], filter_index: i32, values: &[f32]) {
+        assert_eq!(ids.len(), values.len());
+        check(unsafe { oddio_hip_scene_set_control_batch((self.0).0, ids.len(), ids.as_ptr(), filter_index, values.as_ptr()) });
+    }
     pub fn set_listener_rotation(&mut self, rotation: mint::Quaternion<f32>) {
         // src/spatial.rs:345-349 (the library stores the inverse, like the reference)
         let q = [rotation.s, rotation.v.x, rotation.v.y, rotation.v.z];
@@ -272,6 +301,24 @@ impl HipSpatial {
     /// SpeedControl::set_speed (src/speed.rs:52-54)
     pub fn set_speed(&mut self, index: i32, factor: f32) {
         check(unsafe { oddio_hip_source_set_speed(self.scene.0, self.id, index, factor) });
+    }
+    /// GainControl::amplitude_ratio (src/gain.rs:147-150)
+    pub fn amplitude_ratio(&self, index: i32) -> f32 {
+        let mut v = 1.0f32;
+        check(unsafe { oddio_hip_source_get_amplitude_ratio(self.scene.0, self.id, index, &mut v) });
+        v
+    }
+    /// GainControl::gain (src/gain.rs:133-135), decibels
+    pub fn gain(&self, index: i32) -> f32 {
+        let mut v = 0.0f32;
+        check(unsafe { oddio_hip_source_get_gain_db(self.scene.0, self.id, index, &mut v) });
+        v
+    }
+    /// SpeedControl::speed (src/speed.rs:47-49)
+    pub fn speed(&self, index: i32) -> f32 {
+        let mut v = 1.0f32;
+        check(unsafe { oddio_hip_source_get_speed(self.scene.0, self.id, index, &mut v) });
+        v
     }
 }
 impl Drop for HipSpatial {
@@ -377,5 +424,17 @@ impl HipMixed {
     }
     pub fn set_speed(&mut self, index: i32, factor: f32) {
         check(unsafe { oddio_hip_mixer_set_speed(self.mixer.0, self.id, index, factor) });
+    }
+    /// GainControl::amplitude_ratio (src/gain.rs:147-150)
+    pub fn amplitude_ratio(&self, index: i32) -> f32 {
+        let mut v = 1.0f32;
+        check(unsafe { oddio_hip_mixer_get_amplitude_ratio(self.mixer.0, self.id, index, &mut v) });
+        v
+    }
+    /// SpeedControl::speed (src/speed.rs:47-49)
+    pub fn speed(&self, index: i32) -> f32 {
+        let mut v = 1.0f32;
+        check(unsafe { oddio_hip_mixer_get_speed(self.mixer.0, self.id, index, &mut v) });
+        v
     }
 }

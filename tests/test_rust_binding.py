@@ -26,6 +26,10 @@ RUST_TO_C = {
     "*mut RawMixer": {"oddio_hip_mixer*"},
     "*mut *mut RawMixer": {"oddio_hip_mixer**"},
     "*const RawFilter": {"const oddio_hip_filter*"},
+    "*const *mut RawFrames": {"oddio_hip_frames* const*"},
+    "*const f64": {"const double*"},
+    "*const c_int": {"const int*"},
+    "*const u32": {"const uint32_t*"},
 }
 
 
