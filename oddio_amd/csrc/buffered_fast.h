@@ -371,6 +371,8 @@ __global__ __launch_bounds__(128) void buffered_walk(SceneParams P, const BufSta
                         wr.info = BW_FAST | fl | ((uint32_t)nvec << 8) | ((uint32_t)negvec << 20);
                         wr.ring = s.ring; wr.ring_len = rlen; wr.start_idx = (uint32_t)start_idx;
                         wr.ds = ds;
+                        (void)ODDIO_BOUNDS_CHECK(P.bounds_err, nvec >= 1 && nvec * 4 <= BW_WIN_CAP && base_s[0] - ws >= 0 && base_s[0] - ws < count &&
+                                                 (!seg2 || (base_s[1] - ws >= 0 && base_s[1] - ws < count)) && dd.z >= 0 && dd.z <= nvec * 16, BOUNDS_RECORD, nvec, i);
                         wr.wrel = (uint32_t)(base_s[0] - ws) | ((uint32_t)((seg2 ? base_s[1] : base_s[0]) - ws) << 16);
                         wr.cnt = cnt1 | ((cnt1 + cnt2) << 16);
                         wr.ops = ops;
@@ -455,8 +457,9 @@ __device__ __forceinline__ void leaf_repack_padded(unsigned char* win_bytes, int
 
 
 // grid = waves (one 64-thread workgroup each); wave w renders groups [w * groups_per_wave, ...) of 16 slots.
+// (bounds_err: the bounds-checked build's violation record -- device_types.h; null otherwise)
 __global__ __launch_bounds__(64) void buffered_write(const WriteRec* __restrict__ wrecs, const uint32_t* __restrict__ len_snap,
-                                                     BufDyn* __restrict__ dyn, uint32_t groups_per_wave) {
+                                                     BufDyn* __restrict__ dyn, uint32_t groups_per_wave, uint32_t* __restrict__ bounds_err) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[BW_LDS_TOTAL];
     const int lane = threadIdx.x;
     const int lane16 = 16 * lane;
@@ -582,11 +585,18 @@ __global__ __launch_bounds__(64) void buffered_write(const WriteRec* __restrict_
             const float* win = reinterpret_cast<const float*>(win_bytes);
             const uint32_t f0 = 16u * (uint32_t)lane;
             float out[16];
+            const int win_slots = pad ? 4 * nvec + (4 * nvec >> 4) + 1 : 4 * nvec;    // (debug build: what a stored frame may read)
+            (void)win_slots;
             const float* ckl = ck + lane * BW_CK_STRIDE;
             // ---- the leaf: FramesSignal::sample (frames.rs:176-201) for this lane's 16 frames ----
             if (!seg2) {
                 if (leaf_fast) {          // :180-187 constant fract, consecutive pairs (padded layout)
                     const int w0 = wrel0 + (int)f0;
+                    {   // (the frames this lane stores: the last of them reads the pair (w0 + kv - 1, w0 + kv))
+                        const int kv = f0 >= cnt ? 0 : (int)((cnt - f0) < 16u ? (cnt - f0) : 16u);
+                        (void)kv;
+                        (void)ODDIO_BOUNDS_CHECK(bounds_err, kv == 0 || (w0 >= 0 && (w0 + kv) + ((w0 + kv) >> 4) < win_slots), BOUNDS_PAD_INDEX, w0, src);
+                    }
                     float a = win[w0 + (w0 >> 4)];
 #pragma unroll
                     for (int k = 0; k < 16; ++k) {
@@ -603,6 +613,7 @@ __global__ __launch_bounds__(64) void buffered_write(const WriteRec* __restrict_
                             const int tr = (int)xx;
                             const float fr = xx - (float)tr;
                             int w = wrel0 + tr; w = w + (w >> 4);
+                            (void)ODDIO_BOUNDS_CHECK(bounds_err, f0 + (uint32_t)k >= cnt || (w >= 0 && w + 1 < win_slots), BOUNDS_PAD_INDEX, w, src);
                             const float a = win[w], bb = win[w + 1];
                             out[k] = a + fr * (bb - a);
                             xx = xx + ds;
@@ -613,6 +624,7 @@ __global__ __launch_bounds__(64) void buffered_write(const WriteRec* __restrict_
                         for (int k = 0; k < 16; ++k) {
                             const int tr = (int)xx;
                             const float fr = xx - (float)tr;
+                            (void)ODDIO_BOUNDS_CHECK(bounds_err, f0 + (uint32_t)k >= cnt || (wrel0 + tr >= 0 && wrel0 + tr + 1 < win_slots), BOUNDS_WINDOW_INDEX, wrel0 + tr, src);
                             const float a = wb[tr], bb = wb[tr + 1];
                             out[k] = a + fr * (bb - a);
                             xx = xx + ds;
@@ -634,6 +646,7 @@ __global__ __launch_bounds__(64) void buffered_write(const WriteRec* __restrict_
                     else { tr = (int)xx; fr = xx - (float)tr; xx = xx + ds; }
                     int w = wrel + tr;
                     if (pad) w = w + (w >> 4);
+                    (void)ODDIO_BOUNDS_CHECK(bounds_err, f >= cnt || (w >= 0 && w + 1 < win_slots), BOUNDS_WINDOW_INDEX, w, src);
                     w = min(max(w, 0), BW_WIN_CAP - 2);          // frames past cnt (not stored) may run off the window
                     const float a = win[w], bb = win[w + 1];
                     out[k] = a + fr * (bb - a);

@@ -36,6 +36,23 @@ for n_src, n_frames in ((17, 700), (65, 1300), (257, 1024), (1000, 1024), (5000,
 # (the round-2 overrun): regression seeds of the fuzz test
 for seed in (5094, 5173):
     t.test_random_operations_bit_exact(seed)
+# round 4: the batched path of the buffered set (leaf windows of buffered_write, ring windows of spatial_mix<RING> incl. the
+# ring's end), windows rendered in sub-windows, the Cycle render's stage
+import test_hip_buffered_fast as tb
+import test_hip_subwindows as tw
+import test_hip_cycle as tc
+tb.test_every_fast_shape_bit_exact_over_ring_wraps()
+tb.test_ragged_callbacks_and_unit_speed_fast_branch()
+tb.test_removal_motion_and_rotation_with_a_seek_set_beside()
+tb.test_ordered_rows_path_above_the_serial_threshold()
+tw.test_large_windows_ordered_bit_exact(700)
+tw.test_long_callback_with_large_windows()
+for name in dir(tc):
+    if name.startswith("test_") and getattr(getattr(tc, name), "pytestmark", None) is None:
+        try:
+            getattr(tc, name)()
+        except TypeError:
+            pass      # parametrised tests are covered by the plain run
 print("bounds soak ok:", n, "seeds")
 """
 
