@@ -339,6 +339,16 @@ def buffered_algorithmic_bytes(speeds: np.ndarray, n_frames: int) -> dict:
             "total": leaf + ring_w + ring_r + par + 8.0 * n_frames}
 
 
+def buffered_traffic(n_sources: int):
+    """HBM bytes per callback of the buffered path's kernels from the last PMC passes (tools/make_pmc_json.py), or None."""
+    path = os.path.join(ROOT, "profiles", "pmc_buffered_latest.json")
+    try:
+        j = json.load(open(path))
+        return j.get("hbm_bytes_per_callback") if j.get("sources") == n_sources else None
+    except Exception:
+        return None
+
+
 def buffered_cpu_and_parity(device: int, seed: int, budget_s: float) -> tuple[dict, dict]:
     """The oracle (C restatement of the reference) on the same kind of scene: throughput of one thread, and parity of the HIP
     path against it -- 4 096 Gain<Speed<FramesSignal>> sources, 6 callbacks with a gain store to every source before the third."""
@@ -550,10 +560,11 @@ def bench_buffered(args, device: int, shared=None) -> dict:
         "precondition_ms": args.precondition_ms,
         "roofline": {
             "bound": "hbm", "achieved": gbps(b["total"], path_ms), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": gbps(b["total"], path_ms) / HBM_PEAK_GBPS,
-            "traffic": None, "traffic_source": None,
+            "traffic": buffered_traffic(S), "traffic_source": "profiles/pmc_buffered_latest.json (rocprofv3 --pmc passes of the three kernels, not measured in this run)",
             "kernel": "buffered_walk + buffered_write + spatial_mix<RING> (+ its reduce): the buffered set's whole path",
             "avg_kernel_ms": path_ms, "algorithmic_bytes_per_launch": b["total"], "bytes": b,
             "frac_callback": gbps(b["total"], ms_per_step) / HBM_PEAK_GBPS,
+            "frac_host_output": gbps(b["total"], host_ms) / HBM_PEAK_GBPS,
             "walk_ms": walk_ms,
             "write_ms": write_ms, "write_frac": gbps(b["write_kernel"], write_ms) / HBM_PEAK_GBPS,
             "read_ms": read_ms, "read_frac": gbps(b["read_kernel"], read_ms) / HBM_PEAK_GBPS,
@@ -911,6 +922,9 @@ def main():
                 "traffic": traffic, "traffic_source": traffic_source,
                 "kernel": "spatial_mix", "avg_kernel_ms": mix_ms, "algorithmic_bytes_per_launch": b_alg,
                 "frac_callback": b_alg / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                # through the reference's own boundary -- a host slice per call (oddio::run, src/lib.rs:90-93): + an 8 KiB D2H copy and a
+                # stream synchronisation per callback, the GPU idle while the host turns around
+                "frac_host_output": b_alg / (host_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
                 "prepass_ms": float(stages[:, 0].mean()),
                 ("reduce_incl_collective_ms" if sharded else "reduce_ms"): float(stages[:, 2].mean()),
                 "stage_timing": f"prepass/reduce: 8 untimed callbacks after the timed region; avg_kernel_ms: hipEvents around spatial_mix on every "

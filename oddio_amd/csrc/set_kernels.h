@@ -285,6 +285,15 @@ __global__ void seek_all_live(SrcDyn* __restrict__ dyn, const SrcStatic* __restr
     else if (st[i].kind == KIND_CYCLE) dyn[i].t = f64_rem_euclid(dyn[i].t + (double)seconds * (double)st[i].clip_rate, (double)st[i].clip_len);
 }
 
+// Host-output calls: the callback's frames into pinned host memory, then the call's ticket (system-scope release): the audio
+// thread spins on the ticket instead of paying a D2H copy and a stream synchronisation.  One block.
+__global__ __launch_bounds__(1024) void publish_out(const float* __restrict__ out_dev, float* host_out, uint32_t n, uint32_t* flag, uint32_t ticket) {
+    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) __hip_atomic_store(host_out + i, out_dev[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_store(flag, ticket, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 // (bench) FramesSignal::t = seconds for the FramesSignal leaves of the buffered set
 __global__ void reset_buffered_clock(BufDyn* __restrict__ dyn, const BufStatic* __restrict__ st, const uint32_t* __restrict__ d_len, double seconds) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;

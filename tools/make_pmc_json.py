@@ -10,6 +10,24 @@ import sys
 
 summary, sources, out = sys.argv[1], int(sys.argv[2]), sys.argv[3]
 d = json.load(open(summary))
+if len(sys.argv) > 4 and sys.argv[4] == "buffered":
+    # the buffered set's path: buffered_walk + buffered_write + spatial_mix<.., RING> (+ the reduce of its partial tiles)
+    ks = {"walk": [k for k in d if k.startswith("buffered_walk")], "write": [k for k in d if k.startswith("buffered_write")],
+          "reads": [k for k in d if k.startswith("spatial_mix<") and k.rstrip(">").endswith("true") and k.count(",") == 3]}
+    res = {"sources": sources, "kernels": {}, "correction": "read side x2 (gfx950 FETCH_SIZE counts 64 B per 128 B request on wide coalesced loads)"}
+    total = 0.0
+    for name, cand in ks.items():
+        if not cand:
+            continue
+        k = max(cand, key=lambda k: d[k].get("_dispatches") or 0)
+        c = d[k]
+        b = (2.0 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0
+        total += b
+        res["kernels"][name] = {"kernel": k, "dispatches": c.get("_dispatches"), "hbm_bytes_per_launch": b, "counters": {n: v for n, v in c.items() if not n.startswith("_")}}
+    res["hbm_bytes_per_callback"] = total
+    json.dump(res, open(out, "w"), indent=1)
+    print(json.dumps({"hbm_bytes_per_callback": total}))
+    sys.exit(0)
 # the FAST instantiation the timed region runs -- spatial_mix<FULL, false, true> (fused arithmetic) -- not the row render of the
 # ORDERED-mode callbacks (<.., true, ..>) nor the unfused repeat of the timed region (<.., false, false>); older trees: <FULL, false>
 cands = [k for k in d if k.startswith("spatial_mix<true, false, true") or k.startswith("spatial_mix<false, false, true")]
