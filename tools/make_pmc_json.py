@@ -30,6 +30,10 @@ if len(sys.argv) > 4 and sys.argv[4] == "buffered":
     sys.exit(0)
 # the FAST instantiation the timed region runs -- spatial_mix<FULL, false, true> (fused arithmetic) -- not the row render of the
 # ORDERED-mode callbacks (<.., true, ..>) nor the unfused repeat of the timed region (<.., false, false>); older trees: <FULL, false>
+def _ring(k):      # spatial_mix<FULL, STORE, FUSED, RING>: the buffered set's ring reads
+    return k.count(",") == 3 and k.rstrip(">").rstrip().endswith("true")
+d_all = d
+d = {k: v for k, v in d.items() if not (k.startswith("spatial_mix<") and _ring(k))}
 cands = [k for k in d if k.startswith("spatial_mix<true, false, true") or k.startswith("spatial_mix<false, false, true")]
 if not cands:
     cands = [k for k in d if k.startswith("spatial_mix<true, false") or k.startswith("spatial_mix<false, false")]
