@@ -185,19 +185,23 @@ __global__ void apply_control_by_id(const ControlById* __restrict__ up, uint32_t
 // an engine that computes gains or positions on the GPU hands them over without a trip through the host; one message
 // per batch on the control queue, applied in message order.
 __global__ void apply_control_dev(const uint32_t* __restrict__ ids, const float* __restrict__ values, uint32_t n, uint32_t index,
-                                  const uint32_t* __restrict__ slot_of_id, BufDyn* __restrict__ bdyn) {
+                                  const uint32_t* __restrict__ slot_of_id, uint32_t id_cap, BufDyn* __restrict__ bdyn) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const uint32_t sl = slot_of_id[ids[i]];
+    const uint32_t id = ids[i];
+    if (id >= id_cap) return;                                  // not a handle id of this scene: ignored (the arrays are the caller's)
+    const uint32_t sl = slot_of_id[id];
     if (sl == SLOT_INVALID || !(sl & SLOT_BUFFERED_BIT)) return;
     bdyn[sl & ~SLOT_BUFFERED_BIT].shared[index] = values[i];
 }
 __global__ void apply_motion_dev(const uint32_t* __restrict__ ids, const float* __restrict__ pos, const float* __restrict__ vel, uint32_t n,
-                                 uint32_t discontinuity, const uint32_t* __restrict__ slot_of_id, SrcPending* __restrict__ pend,
+                                 uint32_t discontinuity, const uint32_t* __restrict__ slot_of_id, uint32_t id_cap, SrcPending* __restrict__ pend,
                                  SrcPending* __restrict__ pend_b) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const uint32_t sl = slot_of_id[ids[i]];
+    const uint32_t id = ids[i];
+    if (id >= id_cap) return;
+    const uint32_t sl = slot_of_id[id];
     if (sl == SLOT_INVALID) return;
     SrcPending p;
     p.pos[0] = pos[3 * i]; p.pos[1] = pos[3 * i + 1]; p.pos[2] = pos[3 * i + 2];

@@ -327,3 +327,53 @@ def test_65536_buffered_sources_ordered_bit_exact_fast_vs_f64():
         assert scale > 0
         assert e_exact <= fast_vs_exact_tol * scale, (cb, e_exact / scale)
         assert e_ref <= max(FAST_TOL * scale, e_exact + e_refexact), (cb, e_ref / scale, e_refexact / scale)
+
+
+def test_control_and_motion_updates_from_device_memory():
+    """oddio_hip_scene_set_control_device / _set_motion_device: handle ids and values in device memory, one message, applied in
+    message order between ordinary control calls -- against the same stores made through the oracle's controls, bit-exact.  Ids
+    that are not the scene's (beyond the handle table) are ignored."""
+    import torch
+
+    import oddio_amd as oa
+    dev = torch.device("cuda", 0)
+    n_src = 48
+    control, scene = oa.SpatialScene(max_sources=64, max_frames=1024)
+    scene.reserve_buffered(256)
+    scene.set_mode(oa.MODE_ORDERED)
+    ref = oc.SpatialScene()
+    sc = synth.make_scene(33, n_src, cube=10.0, vmax=8.0)
+    sc2 = synth.make_scene(34, n_src, cube=9.0, vmax=5.0)
+    rng = np.random.default_rng(33)
+    hh, rh, gains = [], [], []
+    for i in range(n_src):
+        clip = synth.noise_clip(33, i, 40000)
+        gc, g_h = oa.Gain.new(oa.FramesSignal(oa.Frames.from_slice(48000, clip), 0.01))
+        g_o = oc.Gain(oc.FramesSignal(oc.Frames(48000, clip), 0.01))
+        hh.append(control.play_buffered(g_h, opts(oa, sc["position"][i], sc["velocity"][i]), 30.0, 48000, 0.03))
+        rh.append(ref.play_buffered(g_o, opts(oc, sc["position"][i], sc["velocity"][i]), 30.0, 48000, 0.03))
+        gains.append((gc, g_o))
+    ids = np.array([h.id for h in hh], dtype=np.uint32)
+    keep = []
+    for cb in range(9):
+        if cb == 1:      # a gain store to every source from device memory (+ an id that is nobody's), then an ordinary store behind it
+            vals = rng.uniform(0.1, 1.4, n_src).astype(np.float32)
+            d_ids = torch.from_numpy(np.concatenate([ids, [4000000000]]).astype(np.int64)).to(dev).to(torch.int32)
+            d_vals = torch.from_numpy(np.concatenate([vals, [9.0]]).astype(np.float32)).to(dev)
+            keep += [d_ids, d_vals]
+            gains[5][0].set_amplitude_ratio(0.77); gains[5][1].set_amplitude_ratio(0.77)      # ahead of the batch: the batch wins
+            control.set_control_device(n_src + 1, d_ids.data_ptr(), 0, d_vals.data_ptr())
+            for i in range(n_src):
+                gains[i][1].set_amplitude_ratio(vals[i])
+            gains[0][0].set_amplitude_ratio(0.33); gains[0][1].set_amplitude_ratio(0.33)      # behind it: this one wins
+        if cb == 4:      # Spatial::set_motion for every source from device memory
+            d_ids = torch.from_numpy(ids.astype(np.int64)).to(dev).to(torch.int32)
+            d_pos = torch.from_numpy(sc2["position"]).to(dev).contiguous()
+            d_vel = torch.from_numpy(sc2["velocity"]).to(dev).contiguous()
+            keep += [d_ids, d_pos, d_vel]
+            control.set_motion_device(n_src, d_ids.data_ptr(), d_pos.data_ptr(), d_vel.data_ptr(), False)
+            for i in range(n_src):
+                rh[i].set_motion(sc2["position"][i], sc2["velocity"][i], False)
+        a, b = ref.sample_n(INTERVAL, 1024), scene.sample_n(INTERVAL, 1024)
+        np.testing.assert_array_equal(b, a, err_msg=f"callback {cb}")
+    scene.close()
