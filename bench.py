@@ -475,7 +475,7 @@ def bench_buffered(args, device: int, shared=None) -> dict:
     span = max(4, int((L - int(start_seconds * RATE)) / (N_FRAMES * 1.1)) - 4)
     step_no = 0
 
-    def one_step():
+    def before_step():
         nonlocal step_no
         if step_no and step_no % span == 0:
             scene.debug_reset_buffered_clock(start_seconds)
@@ -483,8 +483,11 @@ def bench_buffered(args, device: int, shared=None) -> dict:
             control.set_motion_device(S, d_ids.data_ptr(), d_pos.data_ptr(), d_vel.data_ptr(), True)
         if step_no % 4 == 0:      # GainControl::set_amplitude_ratio on every source: a 0.1 s ramp (4.7 callbacks) is always running
             control.set_control_device(S, d_ids.data_ptr(), 1, gain_sets[(step_no // 4) % 4].data_ptr())
-        scene.sample_device(interval, out.data_ptr(), N_FRAMES)
         step_no += 1
+
+    def one_step():
+        before_step()
+        scene.sample_device(interval, out.data_ptr(), N_FRAMES)
 
     def sync_all():
         scene.synchronize()
@@ -519,10 +522,10 @@ def bench_buffered(args, device: int, shared=None) -> dict:
     # host-output calls (the reference's boundary hands a host slice), untimed by `value`
     host_buf = np.zeros((N_FRAMES, 2), dtype=np.float32)
     for _ in range(2):
-        scene.sample(interval, host_buf); step_no += 1
+        before_step(); scene.sample(interval, host_buf)
     th0 = time.perf_counter()
     for _ in range(6):
-        scene.sample(interval, host_buf); step_no += 1
+        before_step(); scene.sample(interval, host_buf)
     host_ms = (time.perf_counter() - th0) / 6 * 1e3
     # the general kernel on the same scene (what every buffered source took before round 4), a few callbacks
     scene.set_buffered_fast(False)
@@ -535,6 +538,28 @@ def bench_buffered(args, device: int, shared=None) -> dict:
     scene.synchronize()
     general_ms = (time.perf_counter() - tg0) / 4 * 1e3
     scene.set_buffered_fast(True)
+    if os.environ.get("ODDIO_BENCH_DEBUG"):
+        print("len after general leg", scene.len_buffered(), "step_no", step_no, "span", span, file=sys.stderr)
+    # ORDERED mode (the reference's sum order: contribution rows + ordered_sum), the figure that conforms to the 1e-5 tolerance at
+    # this source count (tests/test_hip_buffered_fast.py: bit-exact at 65 536 buffered sources)
+    scene.set_mode(oa.MODE_ORDERED)
+    for _ in range(3):
+        one_step()
+    scene.synchronize()
+    to0 = time.perf_counter()
+    for _ in range(8):
+        one_step()
+    scene.synchronize()
+    ordered_ms = (time.perf_counter() - to0) / 8 * 1e3
+    if os.environ.get("ODDIO_BENCH_DEBUG"):
+        scene.set_profiling(1)
+        for _ in range(4):
+            one_step()
+        scene.synchronize()
+        print("ORDERED stages", scene.buffered_ms_history(4), "slow", scene.debug_buffered_slow(), "len", scene.len_buffered(), "ms", ordered_ms, file=sys.stderr)
+        scene.set_profiling(False)
+    scene.set_mode(oa.MODE_FAST)
+    assert scene.len_buffered() == S, "sources finished inside the ORDERED leg"
 
     b = buffered_algorithmic_bytes(speeds, N_FRAMES)
     walk_ms, write_ms, read_ms = (float(stages[:, k].mean()) for k in range(3))
@@ -554,6 +579,8 @@ def bench_buffered(args, device: int, shared=None) -> dict:
             "sum_mode": "FAST: deterministic tree sum over waves and workgroups; ring contents are the reference's bits in every mode",
             "parallelism": "single-gpu", "play_seconds": t_play, "sources_on_general_kernel": int(n_slow),
         },
+        "value_conforming": float(S) * N_FRAMES / (ordered_ms * 1e-3),      # ORDERED mode: bit-exact (the reference's sum order)
+        "ordered_mode_ms_per_step": ordered_ms,
         "max_realtime_sources": value / RATE,
         "host_output_ms_per_step": host_ms,
         "general_kernel_ms_per_step": general_ms,
