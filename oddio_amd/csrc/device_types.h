@@ -99,7 +99,7 @@ struct SceneParams {
     uint32_t n_sources;     // live slots
     float* cycle_rows;      // Seek-set Cycle contribution rows: [row][ear][cycle_plane] (null: none played)
     uint32_t cycle_plane;   // floats per ear plane (= max_frames)
-    uint32_t pad;
+    uint32_t dmx;           // the callback's mix kernels are the Downmix-capable ones (spatial_mix<.., DMX>): the walk may stage stereo windows
     uint32_t* bounds_err;   // debug build (-DODDIO_HIP_BOUNDS): {count, first code, first value, first source}; null otherwise
 };
 

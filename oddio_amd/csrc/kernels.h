@@ -299,6 +299,8 @@ constexpr float PAD_EPS = ODDIO_PAD_EPS;           // |ds - 1| below this: lanes
 constexpr int MULTI_STRIDE = 532;
 constexpr float MULTI_DS_MAX = 4.5f;
 constexpr int MULTI_PASS_MAX = 7;
+constexpr float MULTI_DS_MAX_STEREO = 2.2f;      // interleaved stereo windows (Downmix): a lane's run is 2 * (16 * ds + 2) floats
+static_assert(WIN_CAP - MULTI_STRIDE >= 2 * (16 * 2.2f + 2) + 1, "a stereo lane's run fits the overlap of two sub-windows");
 static_assert(MULTI_STRIDE % 4 == 0 && WIN_CAP - MULTI_STRIDE >= 16 * 4.5f + 3, "a lane's run fits the overlap of two sub-windows");
 
 enum : int { PATH_SKIP = 0, PATH_LDS = 1, PATH_GENERIC = 2, PATH_SINE = 3, PATH_CONST = 4, PATH_ROW = 5, PATH_SINE_INLINE = 6 };
@@ -324,7 +326,11 @@ constexpr int SFLAG_NEG = 1, SFLAG_FAST_L = 2, SFLAG_FAST_R = 4, SFLAG_PAD = 8, 
 constexpr int SFLAG_WRAP = 16;
 static_assert(WIN_BYTES % 16 == 0 && LDS_TOTAL % 16 == 0, "per-wave LDS slices and window buffers stay 16-byte aligned");
 static_assert(LDS_TOTAL <= 10240, "16 waves per CU need <= 10 KB of LDS each");
-static_assert(LDS_STREAM >= 16 * 64 * 4, "accumulator parking / cross-wave reduction use 4 KB at offset 0 and must not reach the stream blocks");
+// accumulators parked for an out-of-line source: slot i of lane l at word i * PARK_STRIDE + l (65, not 64: the exact per-lane path
+// walks the frames lane-major -- adjacent lanes on adjacent frames, for its global loads -- and so reaches the slots of one
+// lane from 16 lanes at once: 64 apart they would share a bank)
+constexpr int PARK_STRIDE = 65;
+static_assert(LDS_STREAM >= 16 * PARK_STRIDE * 4, "accumulator parking / cross-wave reduction use ~4 KB at offset 0 and must not reach the stream blocks");
 static_assert(WIN_PIECES * 1024 <= 4095 + 1024, "the DMA's 12-bit instruction offset reaches every piece");
 
 __device__ __forceinline__ void wave_sync() {
@@ -381,10 +387,21 @@ typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));   // four flo
 //   cycle_render  one WAVE per source: the 64 lanes restart from their checkpoints with the same step function and render 16
 //                 frames each into the source's row.
 struct CycleCk { uint32_t base; float offset; };
+__device__ __forceinline__ int4 window_desc(const float* clip, int clip_len4, int ws, int nvec);
+// `lanes`: lanes of a wavefront that carry a source.  The scan is one serial chain per source, and a block of 16 steps in which
+// ANY lane's cursor reaches its clip's end sends the whole wave through the step-by-step branch (5000-sample clips, 64 sources
+// per wave: a fifth of all blocks, 44 us per callback); small sets therefore spread over more waves.
+// Round 4: the scan also knows, per (ear, 256-frame chunk), where the cursor starts and ends -- a tile whose four streams never
+// reach the clip's last sample is, bit for bit, a FramesSignal tile (cycle.rs:30-36 == frames.rs:188-196 while x < len - 1): it gets
+// a PATH_LDS record and spatial_mix renders it from the staged window like any clip; only tiles that touch the clip's end (and
+// callbacks longer than the record tiles) keep the row path, and `rlist` ([par] counter, [2..] slot | pass-0 flag << 31) names the
+// sources cycle_render has rows to make for.
 __global__ __launch_bounds__(64) void cycle_scan(SceneParams P, const SrcStatic* __restrict__ st, SrcDyn* __restrict__ dyn,
                                                  const EarParams* __restrict__ ear, const uint32_t* __restrict__ list, uint32_t par,
-                                                 CycleCk* __restrict__ ck, uint32_t ck_stride) {
-    const uint32_t q = blockIdx.x * 64u + threadIdx.x;
+                                                 CycleCk* __restrict__ ck, uint32_t ck_stride, uint32_t lanes, TileRec* __restrict__ recs,
+                                                 uint32_t rec_stride, uint32_t n_rec_tiles, uint32_t* __restrict__ rlist) {
+    if (threadIdx.x >= lanes) return;
+    const uint32_t q = blockIdx.x * lanes + threadIdx.x;
     if (q >= list[par]) return;
     const uint32_t i = list[2u + q];
     const SrcStatic s = st[i];
@@ -394,6 +411,10 @@ __global__ __launch_bounds__(64) void cycle_scan(SceneParams P, const SrcStatic*
     const uint32_t len = s.clip_len;
     const uint32_t n = P.n_frames;
     const uint32_t row = __float_as_uint(s.freq_or_value);
+    constexpr int RC = REC_TILES * TILE_CHUNKS;          // chunks the tile records cover
+    uint32_t sb[2][RC] = {}, shi[2][RC] = {};             // per (ear, chunk): the base the chunk starts from, the last index it reads
+    float so[2][RC] = {};                                 //                   the offset it starts from
+    uint32_t nonlin = 0u;                                 // bit e * RC + c: the chunk reads the clip's last sample or wraps
     for (int e = 0; e < 2; ++e) {
         const EarParams ep = e ? e1 : e0;
         const float off0 = ep.phase_ear, eff = (float)ep.t_ear;
@@ -404,6 +425,9 @@ __global__ __launch_bounds__(64) void cycle_scan(SceneParams P, const SrcStatic*
             const uint32_t len_c = (n - done) < 256u ? (n - done) : 256u;
             uint32_t base = (uint32_t)f64_as_isize(cursor);                       // cycle.rs:28 (0 <= cursor < len + 256 * ds)
             float offset = (float)(cursor - (double)base);                        // :29
+            const uint32_t cidx = done >> 8;
+            const uint32_t base0 = base; const float offset0 = offset;
+            uint32_t last = base; bool hit = !(ds > 0.0f);
             for (uint32_t k0 = 0; k0 < len_c; k0 += 16u) {
                 CycleCk v; v.base = base; v.offset = offset;
                 c[(done + k0) >> 4] = v;
@@ -416,35 +440,119 @@ __global__ __launch_bounds__(64) void cycle_scan(SceneParams P, const SrcStatic*
                     float o = offset, o15 = offset;
 #pragma unroll
                     for (int k = 0; k < 16; ++k) { o15 = o; o = o + ds; }
-                    const bool plain = ds > 0.0f && base + f32_as_index(o15) < len;
-                    if (plain) offset = o;
+                    const uint32_t xl = base + f32_as_index(o15);
+                    const bool plain = ds > 0.0f && xl < len;
+                    if (plain) { offset = o; last = xl; hit = hit || xl + 1u >= len; }
                     else {
+                        hit = true;
 #pragma unroll 1
                         for (int k = 0; k < 16; ++k) cycle_step(base, offset, len, ds, ia, ib, fract);
                     }
                 } else {
-                    for (uint32_t k = 0; k < cnt; ++k) cycle_step(base, offset, len, ds, ia, ib, fract);
+                    // (the lanes of spatial_mix render whole blocks of 16 frames: the frames past the callback's end are
+                    // discarded, but their reads happen -- the window covers them: 15 plain steps from the block's start)
+                    float o15 = offset;
+#pragma unroll
+                    for (int k = 0; k < 15; ++k) o15 = o15 + ds;
+                    const uint32_t reach = base + f32_as_index(o15);
+                    for (uint32_t k = 0; k < cnt; ++k) {
+                        last = base + f32_as_index(offset);
+                        hit = hit || last + 1u >= len;
+                        cycle_step(base, offset, len, ds, ia, ib, fract);
+                    }
+                    last = max(last, reach);
                 }
             }
+#pragma unroll
+            for (int ee = 0; ee < 2; ++ee)
+#pragma unroll
+                for (int cc = 0; cc < RC; ++cc)
+                    if (e == ee && cidx == (uint32_t)cc) { sb[ee][cc] = base0; so[ee][cc] = offset0; shi[ee][cc] = last; if (hit) nonlin |= 1u << (ee * RC + cc); }
             cursor = (double)base + (double)offset;                               // cycle.rs:52
         }
         cursor = f64_rem_euclid(cursor + (double)(-eff - off0) * rate, lenf);     // spatial.rs:465
     }
     cursor = f64_rem_euclid(cursor + (double)P.elapsed * rate, lenf);             // spatial.rs:468
     dyn[i].t = cursor;
+
+    // ---- the tile records (the walk left PATH_ROW for every tile of a Cycle source) ----
+    const float ds_e[2] = {e0.dt * (float)s.clip_rate, e1.dt * (float)s.clip_rate};
+    bool rows_pass0 = false;
+#pragma unroll
+    for (int t = 0; t < REC_TILES; ++t) {
+        if ((uint32_t)t >= n_rec_tiles) break;
+        TileRec r = {};
+        r.info = PATH_ROW;
+        uint32_t lo = 0xffffffffu, hi = 0u; bool lin = true, any = false; int fl = 0;
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            if (fabsf(ds_e[e] - 1.0f) < PAD_EPS) fl |= SFLAG_PAD;
+#pragma unroll
+            for (int c = 0; c < TILE_CHUNKS; ++c) {
+                const int cc = t * TILE_CHUNKS + c;
+                r.frac0[e][c] = so[e][cc];
+                if ((uint32_t)cc * 256u < n) {
+                    any = true;
+                    lin = lin && !((nonlin >> (e * RC + cc)) & 1u);
+                    lo = min(lo, sb[e][cc]); hi = max(hi, shi[e][cc]);
+                }
+            }
+            const EarParams& ep = e ? e1 : e0;
+            r.ear[e].ds = ds_e[e]; r.ear[e].g0 = ep.g0; r.ear[e].dg = ep.dg;
+        }
+        bool staged = any && lin && lo <= hi;      // (hi may lie past the clip: reads of discarded frames, zero-filled by the descriptor)
+        if (staged) {
+            const int ws = (int)(lo & ~3u);
+            const int count = (int)hi + 2 - ws;
+            const int vec_samples = ((count + 3) >> 2) << 2;
+            if ((fl & SFLAG_PAD) && vec_samples + (vec_samples >> 4) + 1 > WIN_CAP) fl &= ~SFLAG_PAD;
+            int npass = 1;
+            if (count > WIN_CAP) {
+                npass = (count - WIN_CAP + MULTI_STRIDE - 1) / MULTI_STRIDE + 1;
+                staged = ds_e[0] <= MULTI_DS_MAX && ds_e[1] <= MULTI_DS_MAX && npass <= MULTI_PASS_MAX;
+                fl &= ~SFLAG_PAD;
+            }
+            // (both ears' cursors on the same lap of the clip: otherwise the window would span the clip)
+            staged = staged && (int)sb[0][t * TILE_CHUNKS] - ws <= 65535 && (int)sb[1][t * TILE_CHUNKS] - ws <= 65535 && (int)sb[0][t * TILE_CHUNKS + 1] - ws <= 65535 &&
+                     (int)sb[1][t * TILE_CHUNKS + 1] - ws <= 65535;
+            if (staged) {
+                if (s.fixed_gain != 1.0f) fl |= SFLAG_FG;
+                const int nvec_all = (count + 3) >> 2;
+                const int nvec = npass > 1 ? WIN_CAP / 4 : nvec_all;
+                const int4 d = window_desc(s.clip, (int)((s.clip_len + 3u) & ~3u), ws, nvec_all);
+                r.desc[0] = (uint32_t)d.x; r.desc[1] = (uint32_t)d.y; r.desc[2] = (uint32_t)d.z;
+                (void)ODDIO_BOUNDS_CHECK(P.bounds_err, nvec >= 1 && nvec * 4 <= WIN_CAP && d.z >= 0 && d.z <= nvec_all * 16 && d.w == 0, BOUNDS_RECORD, nvec, t);
+                r.info = (uint32_t)PATH_LDS | ((uint32_t)fl << 3) | ((uint32_t)nvec << 8) | ((uint32_t)(npass > 1 ? npass : 0) << 24);
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    const int w0 = min(max((int)sb[e][t * TILE_CHUNKS] - ws, 0), 65535), w1 = min(max((int)sb[e][t * TILE_CHUNKS + 1] - ws, 0), 65535);
+                    r.ear[e].wrel = (uint32_t)w0 | ((uint32_t)w1 << 16);
+                }
+            }
+        }
+        if (!staged) rows_pass0 = true;
+        recs[(size_t)t * rec_stride + i] = r;
+    }
+    if (rows_pass0 || n > (uint32_t)(REC_TILES * TILE_FRAMES)) {
+        const uint32_t k = atomicAdd(&rlist[par], 1u);
+        rlist[2u + k] = i | (rows_pass0 ? 0x80000000u : 0u);
+    }
 }
 
+static_assert(REC_TILES * TILE_FRAMES == 1024, "cycle_render's pass 0 is exactly the tiles cycle_scan writes records for");
 constexpr int CYCLE_WAVES = 4;   // sources per workgroup (independent waves)
 constexpr int CYCLE_WIN_CAP = 1280;   // samples staged per source, ear and 1024-frame pass (ds <= ~1.24)
 __global__ __launch_bounds__(64 * CYCLE_WAVES) void cycle_render(SceneParams P, const SrcStatic* __restrict__ st, const EarParams* __restrict__ ear,
-                                                                const uint32_t* __restrict__ list, uint32_t par,
+                                                                const uint32_t* __restrict__ rlist, uint32_t par,
                                                                 const CycleCk* __restrict__ ck, uint32_t ck_stride) {
     __shared__ float win_all[CYCLE_WAVES][CYCLE_WIN_CAP];
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
     float* win = win_all[wv];
     const uint32_t q = blockIdx.x * CYCLE_WAVES + (uint32_t)wv;
-    if (q >= list[par]) return;
-    const uint32_t i = list[2u + q];
+    if (q >= rlist[par]) return;
+    const uint32_t entry = rlist[2u + q];
+    const uint32_t i = entry & 0x7fffffffu;
+    const uint32_t first_pass = (entry >> 31) ? 0u : (uint32_t)(REC_TILES * TILE_FRAMES);    // (pass 0 = the record tiles: rows only if cycle_scan asked for them)
     const SrcStatic s = st[i];
     const uint32_t len = s.clip_len;
     const uint32_t n = P.n_frames;
@@ -455,7 +563,7 @@ __global__ __launch_bounds__(64 * CYCLE_WAVES) void cycle_render(SceneParams P, 
         float* plane = row + (size_t)e * P.cycle_plane;
         const CycleCk* c = ck + ((size_t)rowi * 2u + (uint32_t)e) * ck_stride;
         const float ds = ep.dt * (float)s.clip_rate;
-        for (uint32_t pass0 = 0; pass0 < n; pass0 += 1024u) {
+        for (uint32_t pass0 = first_pass; pass0 < n; pass0 += 1024u) {
             const uint32_t m = (n - pass0) < 1024u ? (n - pass0) : 1024u;
             // The stretch of the clip this pass reads, staged in LDS with coalesced loads (every lane fetching its own 32
             // samples touched ~35 lines per load instruction: the kernel was bound by that).  It starts at the first frame's
@@ -642,7 +750,12 @@ __device__ __forceinline__ TileRec make_tile_rec(const SceneParams& P, const Src
     }
     if (s.kind == KIND_CONSTANT) { r.info = PATH_CONST; return r; }
     if (s.kind == KIND_CYCLE) { r.info = PATH_ROW; return r; }
-    if (s.kind != KIND_FRAMES) { r.info = PATH_GENERIC; return r; }   // Downmix: exact per-lane path
+    if (s.kind != KIND_FRAMES && s.kind != KIND_DOWNMIX) { r.info = PATH_GENERIC; return r; }
+    // Downmix<FramesSignal<[f32;2]>> (downmix.rs:24-29 over frames.rs:176-201): the same cursor, the window holds interleaved
+    // stereo frames -- `mul` floats per frame; always variant 2 of spatial_mix (sub-windows when the window is larger than the stage)
+    const bool stereo = s.kind == KIND_DOWNMIX;
+    if (stereo && !P.dmx) { r.info = PATH_GENERIC; return r; }   // (the scene was launched without its Downmix-capable kernels)
+    const int mul = stereo ? 2 : 1;
     int lo = 0x7fffffff, hi = (int)0x80000000, generic = 0, fl = 0;
     int wbase[2][2];
     const double rate = (double)s.clip_rate;
@@ -688,7 +801,8 @@ __device__ __forceinline__ TileRec make_tile_rec(const SceneParams& P, const Src
         r.ear[e].ds = ds; r.ear[e].g0 = ep.g0; r.ear[e].dg = ep.dg;
     }
     const int ws = lo & ~3;
-    const int count = hi + 2 - ws;
+    const int count = (hi + 2 - ws) * mul;           // floats
+    if (stereo) fl &= ~SFLAG_PAD;                    // (the padded layout is the mono kernels')
     {   // the padded layout (one extra slot per 16 samples, written a whole 16-byte vector at a time) must fit the
         // window buffer too.  Near-unit windows are ~550 samples, but a listener rotation inside the callback can pull
         // one ear's ratio to 1 while the other's window grows to the full 608: re-laid, that window would run 12 floats
@@ -708,7 +822,8 @@ __device__ __forceinline__ TileRec make_tile_rec(const SceneParams& P, const Src
         // larger than the stage: sub-windows, if both ears step forward slowly enough for a lane's run to fit their overlap
         // (the constant-fract branch exists for the padded single window only)
         npass = (count - WIN_CAP + MULTI_STRIDE - 1) / MULTI_STRIDE + 1;
-        const bool ok = r.ear[0].ds <= MULTI_DS_MAX && r.ear[1].ds <= MULTI_DS_MAX && !(fl & (SFLAG_FAST_L | SFLAG_FAST_R)) && npass <= MULTI_PASS_MAX;
+        const float ds_max = stereo ? MULTI_DS_MAX_STEREO : MULTI_DS_MAX;
+        const bool ok = r.ear[0].ds <= ds_max && r.ear[1].ds <= ds_max && (stereo || !(fl & (SFLAG_FAST_L | SFLAG_FAST_R))) && npass <= MULTI_PASS_MAX;
         path = ok ? PATH_LDS : PATH_GENERIC;
         fl &= ~SFLAG_PAD;
     }
@@ -716,18 +831,19 @@ __device__ __forceinline__ TileRec make_tile_rec(const SceneParams& P, const Src
     if (s.fixed_gain != 1.0f) fl |= SFLAG_FG;
     const int nvec_all = (count + 3) >> 2;
     const int nvec = npass > 1 ? WIN_CAP / 4 : nvec_all;      // per DMA: a whole sub-window (the descriptor clips the last one)
-    const int4 d = window_desc(s.clip, (int)((s.clip_len + 3u) & ~3u), ws, nvec_all);
+    const int4 d = window_desc(s.clip, (int)((s.clip_len * (uint32_t)mul + 3u) & ~3u), ws * mul, nvec_all);
     r.desc[0] = (uint32_t)d.x; r.desc[1] = (uint32_t)d.y; r.desc[2] = (uint32_t)d.z;
     // a window that starts before the clip: the descriptor base is the clip start and the first -ws/4 vectors are out
     // of range (zeros); one that lies entirely before it has a zero-byte descriptor, any offset reads zeros
     const int negvec = (d.z > 0) ? ((-d.w) >> 4) : 0;
     if (negvec > 255) { r.info = (uint32_t)PATH_GENERIC; return r; }   // (a large window that starts far before its clip)
     (void)ODDIO_BOUNDS_CHECK(P.bounds_err, nvec >= 1 && nvec * 4 <= WIN_CAP && negvec >= 0 && negvec <= 255 && d.z >= 0 && d.z <= nvec_all * 16 &&
-                             wbase[0][0] - ws >= 0 && wbase[1][1] - ws <= 65535, BOUNDS_RECORD, nvec, tile);
-    r.info = (uint32_t)path | ((uint32_t)fl << 3) | ((uint32_t)nvec << 8) | ((uint32_t)negvec << 16) | ((uint32_t)(npass > 1 ? npass : 0) << 24);
+                             wbase[0][0] - ws >= 0 && (wbase[1][1] - ws) * mul <= 65535, BOUNDS_RECORD, nvec, tile);
+    r.info = (uint32_t)path | ((uint32_t)fl << 3) | ((uint32_t)nvec << 8) | ((uint32_t)negvec << 16) | ((uint32_t)(npass > 1 ? npass : 0) << 24) |
+             ((uint32_t)(stereo ? 1 : 0) << 27);
 #pragma unroll
-    for (int e = 0; e < 2; ++e) {
-        const int w0 = min(max(wbase[e][0] - ws, 0), 65535), w1 = min(max(wbase[e][1] - ws, 0), 65535);
+    for (int e = 0; e < 2; ++e) {      // a chunk's base in floats from the window start
+        const int w0 = min(max((wbase[e][0] - ws) * mul, 0), 65535), w1 = min(max((wbase[e][1] - ws) * mul, 0), 65535);
         r.ear[e].wrel = (uint32_t)w0 | ((uint32_t)w1 << 16);
     }
     return r;
@@ -749,7 +865,7 @@ __global__ __launch_bounds__(256) void spatial_prepass(SceneParams P, const SrcS
     const int lane = threadIdx.x & 63;
     uint32_t* lds = stage[threadIdx.x >> 6];
     const uint32_t len = d_len[0];
-    if (i == 0) { *len_snap = len; if (cycle_list) cycle_list[cycle_par ^ 1u] = 0u; }
+    if (i == 0) { *len_snap = len; if (cycle_list) { cycle_list[cycle_par ^ 1u] = 0u; cycle_list[rec_stride + 2u + (cycle_par ^ 1u)] = 0u; } }   // (cycle_scan's render list follows the list)
     const uint32_t first = i - (uint32_t)lane;
     if (first >= len) return;                                       // whole wave past the end
     const uint32_t n_valid = (len - first) < 64u ? (len - first) : 64u;
@@ -885,10 +1001,12 @@ __device__ __forceinline__ void acc_add(float& acc, float v, float g, bool on) {
         else if (on) acc = acc + p;
     }
 }
-template <bool FULL, bool HAS_FG, bool NONNEG, bool PAD, bool FUSED, bool WRAP = false>
+// ST (variant 2 only): `stereo` (wave-uniform) marks a window of interleaved stereo frames -- Downmix<FramesSignal<[f32;2]>>,
+// downmix.rs:24-29: each channel interpolated (frames.rs:180-196, incl. the constant-fract branch `fast`), then channels().sum().
+template <bool FULL, bool HAS_FG, bool NONNEG, bool PAD, bool FUSED, bool WRAP = false, bool ST = false>
 __device__ __forceinline__ void mix_source_lds(const unsigned char* win_bytes, int wrel4, float x, int b, int fast, float frac0, float (&acc)[16],
                                                const float (&fi)[16], uint32_t frame0, uint32_t n_frames, float fixed_gain, float g0, float dg,
-                                               float ds, int win_samples, uint32_t* err, int ring_len = 0) {
+                                               float ds, int win_samples, uint32_t* err, int ring_len = 0, int stereo = 0) {
     if (!FULL && frame0 >= n_frames) return;   // this lane's 16 frames lie past the end of `out`
     const float* win = reinterpret_cast<const float*>(win_bytes);
     if (WRAP) {
@@ -933,6 +1051,29 @@ __device__ __forceinline__ void mix_source_lds(const unsigned char* win_bytes, i
     // sample i is consumed; sched_barrier keeps hipcc from sinking them back next to their use.
     const float* wbase = reinterpret_cast<const float*>(win_bytes + wrel4);
     const int wrel = wrel4 >> 2;
+    if (ST && stereo) {
+        // Interleaved stereo frames (not pipelined by hand: a handful of sources): frame index w -> floats 2 w .. 2 w + 3
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            int tr = (int)x;
+            float f = x - (float)tr;                                           // frames.rs:192
+            if (fast) { tr = 16 * b + i; f = frac0; }                          // frames.rs:180-187
+            x = x + ds;
+            float l0 = 0.0f, r0 = 0.0f, l1 = 0.0f, r1 = 0.0f;
+            if (ODDIO_BOUNDS_CHECK(err, wrel + 2 * tr >= 0 && wrel + 2 * tr + 3 < win_samples, BOUNDS_WINDOW_INDEX, wrel + 2 * tr, win_samples)) {
+                const float* q_ = wbase + 2 * tr;
+                l0 = q_[0]; r0 = q_[1]; l1 = q_[2]; r1 = q_[3];
+            }
+            asm volatile("" : "+v"(dg));
+            const float vl = FUSED ? __builtin_fmaf(f, l1 - l0, l0) : l0 + f * (l1 - l0);   // frame.rs:39-41 per channel
+            const float vr = FUSED ? __builtin_fmaf(f, r1 - r0, r0) : r0 + f * (r1 - r0);
+            float v = (0.0f + vl) + vr;                                        // downmix.rs:27-29: channels().sum() from 0.0
+            if (HAS_FG) v = v * fixed_gain;
+            acc_add<FULL, FUSED>(acc[i], v, FUSED ? __builtin_fmaf(fi[i], dg, g0) : g0 + fi[i] * dg, frame0 + (uint32_t)i < n_frames);
+            __builtin_amdgcn_sched_barrier(0);     // one frame at a time: the kernel has no registers to spare for reads hoisted across frames
+        }
+        return;
+    }
     float a[16], bb[16], fr[16];
 #define ODDIO_ISSUE(I)                                                                  \
     {                                                                                   \
@@ -982,7 +1123,7 @@ __device__ __forceinline__ float sin_small(float x) {
     return __builtin_fmaf(r * r2, p, r);
 }
 
-// One Sine source on accumulators parked in LDS (slot i of lane l at acc_lds[i * 64 + l], like mix_source_rare -- inline, with the
+// One Sine source on accumulators parked in LDS (slot i of lane l at acc_lds[i * PARK_STRIDE + l], like mix_source_rare -- inline, with the
 // accumulators in registers, the sine's temporaries push the hot kernel into scratch memory):
 // acc[i] += (sin((dt * i) * freq + phase) * fixed_gain) * gain for this lane's 16 frames of its chunk (sine.rs:34-38,
 // gain.rs:32-37, spatial.rs:459-460).  The argument is the reference's, operation for operation; every parameter comes from the
@@ -997,7 +1138,7 @@ __device__ __noinline__ void mix_source_sine(float* acc_lds, int lane, uint32_t 
         float v = sin_small(t * freq + phase);
         v = v * fixed_gain;
         const float p = v * (g0 + (fbase + (float)i) * dg);
-        if (frame0 + (uint32_t)i < n_frames) acc_lds[i * 64 + lane] = acc_lds[i * 64 + lane] + p;
+        if (frame0 + (uint32_t)i < n_frames) acc_lds[i * PARK_STRIDE + lane] = acc_lds[i * PARK_STRIDE + lane] + p;
     }
 }
 
@@ -1006,10 +1147,11 @@ __device__ __forceinline__ float clip_at(const float* clip, uint32_t len, long l
     return (i >= 0 && i < (long long)len) ? clip[i] : 0.0f;
 }
 
+constexpr int GEN_BATCH = 2;   // frames whose loads are in flight together in the exact per-lane path (its registers count against the kernels that call it)
 // ---- rare paths -------------------------------------------------------------------------------
 // Sources that do not take the staged-window path (windows larger than the LDS stage, backwards
 // or absurd cursors, Sine / Constant sources).  Kept out of line and working on accumulators
-// parked in LDS (slot i of lane l at acc_lds[i * 64 + l]) so that their register needs (sinf range
+// parked in LDS (slot i of lane l at acc_lds[i * PARK_STRIDE + l]) so that their register needs (sinf range
 // reduction, 64-bit indices) do not inflate the hot kernel's allocation.  They fetch the source's
 // parameters from global memory themselves.
 __device__ __noinline__ void mix_source_rare(float* acc_lds, int lane, uint32_t frame0, uint32_t n_frames, uint32_t c_abs, int path,
@@ -1028,12 +1170,12 @@ __device__ __noinline__ void mix_source_rare(float* acc_lds, int lane, uint32_t 
 #pragma unroll
             for (int k4 = 0; k4 < 4; ++k4) r[k4] = *reinterpret_cast<const f4u*>(plane + frame0 + 4 * k4);
 #pragma unroll
-            for (int i = 0; i < 16; ++i) acc_lds[i * 64 + lane] = acc_lds[i * 64 + lane] + r[i >> 2][i & 3];
+            for (int i = 0; i < 16; ++i) acc_lds[i * PARK_STRIDE + lane] = acc_lds[i * PARK_STRIDE + lane] + r[i >> 2][i & 3];
             return;
         }
 #pragma unroll 1
         for (int i = 0; i < 16; ++i)
-            if (frame0 + (uint32_t)i < n_frames) acc_lds[i * 64 + lane] = acc_lds[i * 64 + lane] + plane[frame0 + (uint32_t)i];
+            if (frame0 + (uint32_t)i < n_frames) acc_lds[i * PARK_STRIDE + lane] = acc_lds[i * PARK_STRIDE + lane] + plane[frame0 + (uint32_t)i];
         return;
     }
     if (path == PATH_SINE || path == PATH_CONST) {
@@ -1052,7 +1194,7 @@ __device__ __noinline__ void mix_source_rare(float* acc_lds, int lane, uint32_t 
             }
             v = v * fixed_gain;
             const float p = v * (g0 + (fbase + (float)i) * dg);
-            if (frame0 + (uint32_t)i < n_frames) acc_lds[i * 64 + lane] = acc_lds[i * 64 + lane] + p;
+            if (frame0 + (uint32_t)i < n_frames) acc_lds[i * PARK_STRIDE + lane] = acc_lds[i * PARK_STRIDE + lane] + p;
         }
         return;
     }
@@ -1067,30 +1209,60 @@ __device__ __noinline__ void mix_source_rare(float* acc_lds, int lane, uint32_t 
     const long long base = f64_as_isize(s0);
     const float frac0 = (float)(s0 - (double)base);
     const bool fast = fabsf(ds - 1.0f) <= FLT_EPSILON;
+    // Lane-major over the chunk: in step i the lane renders frame 16 * i + b of its chunk -- the 16 lanes of a chunk read 16
+    // adjacent frames, a few cache lines per load instruction (block-major, each lane on its own 16 frames 16 * ds samples from
+    // its neighbour's, every load instruction touched 64 lines: Downmix sources cost 6x a staged FramesSignal) -- and adds it to
+    // slot b of the lane that owns the frame, (lane & ~15) | i.  The cursor is the same serial chain: b adds to the lane's
+    // first frame, 16 more per step.
+    const uint32_t chunk0 = frame0 - 16u * (uint32_t)b;          // first frame of the lane's chunk (callback-relative)
     float x = frac0;
-    if (!fast) for (int k = 0; k < 16 * b; ++k) x = x + ds;
+    if (!fast) for (int k = 0; k < b; ++k) x = x + ds;
+    // GEN_BATCH frames at a time: the indices first (registers only), then all the loads together, then the arithmetic
 #pragma unroll 1
-    for (int i = 0; i < 16; ++i) {
-        long long idx; float fr;
-        if (fast) { idx = base + (long long)(16 * b + i); fr = frac0; }
-        else { const long long tr = (long long)x; idx = base + tr; fr = x - (float)tr; }
-        float v;
-        if (downmix) {   // per-channel lerp of the stereo frame, then channels().sum()
-            const bool in_a = idx >= 0 && idx < (long long)clip_len, in_b = idx + 1 >= 0 && idx + 1 < (long long)clip_len;
-            const float2 fa = in_a ? reinterpret_cast<const float2*>(clip)[idx] : make_float2(0.0f, 0.0f);
-            const float2 fb = in_b ? reinterpret_cast<const float2*>(clip)[idx + 1] : make_float2(0.0f, 0.0f);
-            const float l = fa.x + fr * (fb.x - fa.x), r = fa.y + fr * (fb.y - fa.y);
-            v = 0.0f;
-            v = v + l;
-            v = v + r;
-        } else {
-            const float a = clip_at(clip, clip_len, idx), bb = clip_at(clip, clip_len, idx + 1);
-            v = a + fr * (bb - a);
+    for (int i0 = 0; i0 < 16; i0 += GEN_BATCH) {
+        long long idx[GEN_BATCH]; float fr[GEN_BATCH];
+#pragma unroll
+        for (int k = 0; k < GEN_BATCH; ++k) {
+            if (fast) { idx[k] = base + (long long)(16 * (i0 + k) + b); fr[k] = frac0; }
+            else {
+                const long long tr = (long long)x; idx[k] = base + tr; fr[k] = x - (float)tr;
+#pragma unroll
+                for (int q = 0; q < 16; ++q) x = x + ds;
+            }
         }
-        v = v * fixed_gain;
-        const float p = v * (g0 + (fbase + (float)i) * dg);
-        if (frame0 + (uint32_t)i < n_frames) acc_lds[i * 64 + lane] = acc_lds[i * 64 + lane] + p;
-        x = x + ds;
+        float v[GEN_BATCH];
+        if (downmix) {   // per-channel lerp of the stereo frame, then channels().sum()
+            float2 fa[GEN_BATCH], fb[GEN_BATCH];
+#pragma unroll
+            for (int k = 0; k < GEN_BATCH; ++k) {
+                const bool in_a = idx[k] >= 0 && idx[k] < (long long)clip_len, in_b = idx[k] + 1 >= 0 && idx[k] + 1 < (long long)clip_len;
+                fa[k] = in_a ? reinterpret_cast<const float2*>(clip)[idx[k]] : make_float2(0.0f, 0.0f);
+                fb[k] = in_b ? reinterpret_cast<const float2*>(clip)[idx[k] + 1] : make_float2(0.0f, 0.0f);
+            }
+#pragma unroll
+            for (int k = 0; k < GEN_BATCH; ++k) {
+                const float l = fa[k].x + fr[k] * (fb[k].x - fa[k].x), r = fa[k].y + fr[k] * (fb[k].y - fa[k].y);
+                float sum = 0.0f;
+                sum = sum + l;
+                sum = sum + r;
+                v[k] = sum;
+            }
+        } else {
+            float a[GEN_BATCH], bb[GEN_BATCH];
+#pragma unroll
+            for (int k = 0; k < GEN_BATCH; ++k) { a[k] = clip_at(clip, clip_len, idx[k]); bb[k] = clip_at(clip, clip_len, idx[k] + 1); }
+#pragma unroll
+            for (int k = 0; k < GEN_BATCH; ++k) v[k] = a[k] + fr[k] * (bb[k] - a[k]);
+        }
+#pragma unroll
+        for (int k = 0; k < GEN_BATCH; ++k) {
+            const int i = i0 + k;
+            const uint32_t f = chunk0 + 16u * (uint32_t)i + (uint32_t)b;
+            const float vg = v[k] * fixed_gain;
+            const float p = vg * (g0 + (float)f * dg);
+            float* slot = acc_lds + b * PARK_STRIDE + ((lane & ~15) | i);
+            if (f < n_frames) *slot = *slot + p;
+        }
     }
 }
 
@@ -1100,7 +1272,7 @@ __device__ __noinline__ void mix_source_slab(float* acc_lds, int lane, uint32_t 
     const int eB = lane >> 5;
 #pragma unroll 1
     for (int i = 0; i < 16; ++i)
-        if (frame0 + (uint32_t)i < n_frames) acc_lds[i * 64 + lane] = acc_lds[i * 64 + lane] + row[2 * (frame0 + (uint32_t)i) + eB];
+        if (frame0 + (uint32_t)i < n_frames) acc_lds[i * PARK_STRIDE + lane] = acc_lds[i * PARK_STRIDE + lane] + row[2 * (frame0 + (uint32_t)i) + eB];
 }
 
 // v_mov_b32_dpp quad_perm:[K,K,K,K]: every lane reads lane K of its group of four
@@ -1148,7 +1320,9 @@ __device__ __forceinline__ void rows_store(const float4 (&o)[4], const float4 (&
 // first samples behind its end, so a window never needs clipping), SFLAG_WRAP marks sources whose cursors may pass the
 // ring's end, and an out-of-line source adds the slab row the general kernel rendered (P.cycle_rows = the slabs,
 // [slot][frame][ear]).  The non-RING instantiations compile to what they were before the flag existed.
-template <bool FULL, bool STORE = false, bool FUSED = false, bool RING = false>
+// DMX: the instantiations a scene with Downmix sources runs (variant 2 can render interleaved stereo windows); kept apart because
+// the plain kernels have no register to spare (127 of 128: with the stereo loop compiled in they spill 48-80 bytes per lane).
+template <bool FULL, bool STORE = false, bool FUSED = false, bool RING = false, bool DMX = false>
 __global__ __launch_bounds__(64 * MIX_WG_WAVES, MIX_WAVES_PER_SIMD) void spatial_mix(SceneParams P, const SrcStatic* __restrict__ st,
                                                                                      const EarParams* __restrict__ ear,
                                                                                      const TileRec* __restrict__ recs, uint32_t rec_stride, uint32_t tile0,
@@ -1316,7 +1490,7 @@ __global__ __launch_bounds__(64 * MIX_WG_WAVES, MIX_WAVES_PER_SIMD) void spatial
         // VAR: 0 the common source (no FixedGain, non-negative cursor), 1 padded layout (resample ratio within PAD_EPS
         // of 1), 2 FixedGain and/or a cursor that starts negative; -1: decided here (wave-uniform branches)
 #define ODDIO_VARIANT(INFO) (RING ? ((((INFO) >> 3) & SFLAG_WRAP) ? 3 : ((((INFO) >> 3) & SFLAG_PAD) ? 1 : 0)) \
-                                  : ((((INFO) >> 24) & 7u) ? 2 : ((((INFO) >> 3) & SFLAG_PAD) ? 1 : ((((INFO) >> 3) & (SFLAG_FG | SFLAG_NEG)) ? 2 : 0))))
+                                  : ((((INFO) >> 24) & 15u) ? 2 : ((((INFO) >> 3) & SFLAG_PAD) ? 1 : ((((INFO) >> 3) & (SFLAG_FG | SFLAG_NEG)) ? 2 : 0))))
         // A source whose window is larger than the stage (info bits 24-26 = its number of sub-windows) takes variant 2's loop
         // once per sub-window: `mpass` counts them; a pass starts the next sub-window instead of the next source's window, and
         // only the lanes whose runs lie in its sub-window render.
@@ -1372,13 +1546,17 @@ __global__ __launch_bounds__(64 * MIX_WG_WAVES, MIX_WAVES_PER_SIMD) void spatial
             const float fg = (!RING && (flags_j & SFLAG_FG)) ? st[g * MIX_GROUP + (uint32_t)cur].fixed_gain : 1.0f;       \
             bool on_ = true;                                                                                              \
             int w4_ = wrel4;                                                                                              \
+            const int stereo_ = DMX ? (int)((cur_info >> 27) & 1u) : 0;       /* interleaved stereo frames (Downmix) */      \
+            const int fast_s = stereo_ ? (eB ? (flags_j & SFLAG_FAST_R) : (flags_j & SFLAG_FAST_L)) : 0;                  \
+            const float frac0_s = fast_s ? reinterpret_cast<const float*>(blkB0 + cur * BLK_SRC)[0] : 0.0f;   /* checkpoint 0 */ \
             if (npass_) {   /* the lanes whose runs lie in this sub-window (the last one takes what lies beyond it too) */ \
-                int lp_ = ((wrel4 >> 2) + (int)cx0) / MULTI_STRIDE;                                                       \
+                int lp_ = ((wrel4 >> 2) + ((int)cx0 << stereo_)) / MULTI_STRIDE;                                          \
                 lp_ = lp_ < 0 ? 0 : (lp_ > npass_ - 1 ? npass_ - 1 : lp_);                                                \
                 on_ = lp_ == mpass;                                                                                       \
                 w4_ = wrel4 - 4 * MULTI_STRIDE * mpass;                                                                   \
             }                                                                                                             \
-            if (on_) mix_source_lds<FULL, true, false, false, FUSED>(win_bytes, w4_, cx0, bB, 0, 0.0f, acc, fi, frame0, n_frames, fg, ct.y, ct.z, ct.w, 4 * (int)((cur_info >> 8) & 255u), P.bounds_err); \
+            if (on_) mix_source_lds<FULL, true, false, false, FUSED, false, DMX>(win_bytes, w4_, cx0, bB, fast_s, frac0_s, acc, fi, frame0, n_frames, fg, ct.y, ct.z, ct.w, \
+                                                                                   4 * (int)((cur_info >> 8) & 255u), P.bounds_err, 0, stereo_); \
         }                                                                                                                 \
         buf ^= 1;                                                                                                         \
         if (more_) ++mpass;                                                                                               \
@@ -1412,7 +1590,7 @@ __global__ __launch_bounds__(64 * MIX_WG_WAVES, MIX_WAVES_PER_SIMD) void spatial
         if (!RING && path_j == PATH_SINE_INLINE) { ODDIO_LANE_DATA((J), ph_, t_) ph_ = reinterpret_cast<const float*>(blkB0 + (J) * BLK_SRC)[0]; } \
         window_wait();                                                                                                    \
         wave_sync();                                                                                                      \
-        _Pragma("unroll") for (int k = 0; k < 16; ++k) park[k * 64 + lane] = acc[k];                                      \
+        _Pragma("unroll") for (int k = 0; k < 16; ++k) park[k * PARK_STRIDE + lane] = acc[k];                                      \
         wave_sync();                                                                                                      \
         if (!RING && path_j == PATH_SINE_INLINE)                                                                          \
             mix_source_sine(park, lane, frame0, n_frames, ph_, t_.w, __int_as_float(__builtin_amdgcn_readlane((int)vdesc.x, (J))), \
@@ -1420,7 +1598,7 @@ __global__ __launch_bounds__(64 * MIX_WG_WAVES, MIX_WAVES_PER_SIMD) void spatial
         else if (RING) mix_source_slab(park, lane, frame0, n_frames, P.cycle_rows + (size_t)(g * MIX_GROUP + (uint32_t)(J)) * P.cycle_plane);    \
         else mix_source_rare(park, lane, frame0, n_frames, cB_abs, path_j, st, ear, g * MIX_GROUP + (uint32_t)(J), P.cycle_rows, P.cycle_plane); \
         wave_sync();                                                                                                      \
-        _Pragma("unroll") for (int k = 0; k < 16; ++k) acc[k] = park[k * 64 + lane];                                      \
+        _Pragma("unroll") for (int k = 0; k < 16; ++k) acc[k] = park[k * PARK_STRIDE + lane];                                      \
         wave_sync();                                                                                                      \
         if (cur >= 0) ODDIO_ISSUE_WINDOW(cur, buf)                                                                        \
     }

@@ -60,6 +60,62 @@ def test_cycle_fast_mode_tolerance_and_late_play():
     hb.close()
 
 
+def _cycle_spec(seed, n_src, lens, rates=(48000,), gains=(None,)):
+    spec = scenario.random_spec(seed, n_src, kinds=("cycle",), cycle_len=8)
+    for i, src in enumerate(spec["sources"]):
+        src["clip"] = scenario.synth.noise_clip(seed, i, lens[i % len(lens)])
+        src["rate"] = rates[i % len(rates)]
+        src["gain_db"] = gains[i % len(gains)]
+    return spec
+
+
+@pytest.mark.parametrize("n_frames", [1024, 700, 1536, 40])
+def test_cycle_tiles_from_the_staged_window_bit_exact(n_frames):
+    """Round 4: a tile in which no cursor reaches the clip's last sample is rendered by spatial_mix from the staged window
+    (cycle_scan writes its record); tiles that touch the clip's end keep the row path.  Clips of many lengths -- far longer than
+    a tile (almost every tile staged), a few tiles long (wraps in some tiles, sometimes between the ears), shorter than a tile
+    (rows always) -- in one set, 200 sources (more than one wavefront of the scan at every packing)."""
+    spec = _cycle_spec(71, 200, lens=(48000, 5000, 1500, 2049, 600, 96000, 513, 24001), gains=(None, -4.5, None))
+    ref, got, ob, hb = run_pair(spec, n_frames, 9, mode=1, max_sources=256)
+    assert np.abs(ref).max() > 0
+    np.testing.assert_array_equal(got, ref)
+    hb.close()
+
+
+def test_cycle_resampled_clips_sub_windows_and_motion_bit_exact():
+    """96 / 192 kHz loops in a 48 kHz scene (windows of 2 and 4 stage sub-windows), 44.1 kHz, sources that jump (a
+    discontinuity moves the delay, hence the cursor, by thousands of samples: both ears on different laps)."""
+    spec = _cycle_spec(72, 96, lens=(96000, 30000, 200000, 44100, 7000), rates=(96000, 48000, 192000, 44100))
+    rng = np.random.default_rng(5)
+    events = {}
+    for cb in (1, 2, 4):
+        events[cb] = [("motion", j, (spec["sources"][j]["pos"] + rng.normal(size=3).astype(np.float32) * 30).astype(np.float32), spec["sources"][j]["vel"],
+                       cb == 2) for j in range(0, 96, 7)]
+    events.setdefault(3, []).append(("rotation", [np.cos(0.4), 0.0, np.sin(0.4), 0.0]))
+    ref, got, ob, hb = run_pair(spec, 1024, 7, mode=1, events=events, max_sources=128)
+    np.testing.assert_array_equal(got, ref)
+    hb.close()
+
+
+def test_cycle_staged_tiles_fast_mode_and_large_set():
+    """FAST mode (the fused arithmetic of the staged path applies to Cycle tiles now) and a set large enough for the 16-lane
+    packing of the scan (> 8192 Cycle sources), ORDERED rows path above the serial threshold."""
+    os.environ["ODDIO_HIP_MAX_CYCLE"] = "10000"
+    try:
+        spec = _cycle_spec(73, 9000, lens=(48000, 5000, 20000))
+        clips = {}
+        for src in spec["sources"]:                       # (9000 sources share 3 clips: the oracle side stays fast)
+            src["clip"] = clips.setdefault(len(src["clip"]), src["clip"])
+        ref, got, ob, hb = run_pair(spec, 1024, 3, mode=1, max_sources=10000)
+        np.testing.assert_array_equal(got, ref)
+        hb.close()
+        ref, got, ob, hb = run_pair(spec, 1024, 3, mode=0, max_sources=10000)
+        assert rel_err(got, ref) <= 1e-5
+        hb.close()
+    finally:
+        del os.environ["ODDIO_HIP_MAX_CYCLE"]
+
+
 def test_cycle_row_capacity_error():
     import oddio_amd as oa
     from oddio_amd._lib import OddioHipError

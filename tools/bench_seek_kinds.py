@@ -9,7 +9,8 @@ Every scene has `--sources` moving sources of ONE kind (positions / velocities o
                                     4096 distinct clips, scattered
   sine                              Sine (closed form, sinf per sample)
   downmix                           Downmix<FramesSignal<[f32;2]>> over 48 kHz stereo clips
-  cycle                             Cycle over 5000-sample clips (ODDIO_HIP_MAX_CYCLE raised to the source count)
+  cycle / cycle48k                  Cycle over 5000-sample loops (0.1 s: a tenth of all tiles touches the loop's end and takes the
+                                    row path) / 48000-sample loops (ODDIO_HIP_MAX_CYCLE raised to the source count)
 """
 import argparse
 import os
@@ -28,7 +29,8 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--sources", type=int, default=65536)
     ap.add_argument("--callbacks", type=int, default=24)
-    ap.add_argument("--kinds", default="frames48,frames96,frames192,sine,downmix,cycle")
+    ap.add_argument("--warm", type=int, default=64, help="untimed callbacks first (the chip leaves its idle clock state under load only)")
+    ap.add_argument("--kinds", default="frames48,frames96,frames192,sine,downmix,cycle,cycle48k")
     args = ap.parse_args()
     os.environ.setdefault("ODDIO_HIP_MAX_CYCLE", str(args.sources))
     import torch
@@ -49,7 +51,7 @@ def main():
         if kind.startswith("frames") or kind == "downmix":
             rate = int(kind[6:]) * 1000 if kind.startswith("frames") else RATE
             ch = 2 if kind == "downmix" else 1
-            length = (int(rate * (1.0 + (args.callbacks + 8) * N / RATE * 1.15)) + 4096) & ~3
+            length = (int(rate * (1.0 + (args.callbacks + args.warm + 8) * N / RATE * 1.15)) + 4096) & ~3
             clips = (torch.rand((n_clips, length * ch), device=dev, dtype=torch.float32) * 2.0 - 1.0).contiguous()
             keep.append(clips)
             if ch == 1:
@@ -63,13 +65,13 @@ def main():
         elif kind == "sine":
             for i in range(S):
                 control.play(oa.Sine(float(sc["phase"][i]), float(sc["freq_hz"][i])), oa.SpatialOptions(sc["position"][i], sc["velocity"][i], 0.1))
-        elif kind == "cycle":
-            frames = [oa.Frames.from_slice(RATE, synth.noise_clip(2, i, 5000)) for i in range(64)]
+        elif kind in ("cycle", "cycle48k"):
+            frames = [oa.Frames.from_slice(RATE, synth.noise_clip(2, i, 5000 if kind == "cycle" else 48000)) for i in range(64)]
             for i in range(S):
                 control.play(oa.Cycle(frames[i % 64]), oa.SpatialOptions(sc["position"][i], sc["velocity"][i], 0.1))
         else:
             raise SystemExit(f"unknown kind {kind}")
-        for _ in range(4):
+        for _ in range(args.warm):
             scene.sample_device(interval, out.data_ptr(), N)
         scene.synchronize()
         t0 = time.perf_counter()
