@@ -428,15 +428,15 @@ __global__ __launch_bounds__(64) void cycle_scan(SceneParams P, const SrcStatic*
             const uint32_t cidx = done >> 8;
             const uint32_t base0 = base; const float offset0 = offset;
             uint32_t last = base; bool hit = !(ds > 0.0f);
-            for (uint32_t k0 = 0; k0 < len_c; k0 += 16u) {
+            // one block of up to 16 steps from frame k0 of the chunk, with its checkpoint
+            auto block16 = [&](uint32_t k0) {
                 CycleCk v; v.base = base; v.offset = offset;
                 c[(done + k0) >> 4] = v;
                 const uint32_t cnt = (len_c - k0) < 16u ? (len_c - k0) : 16u;
                 uint32_t ia, ib; float fract;
                 if (cnt == 16u) {
                     // 16 steps at once: unless the cursor reaches the clip's end inside them (checked on the offset the 16th
-                    // step reads), the steps are 16 plain adds -- the chain that matters: 2048 steps per source, 55 us of
-                    // dependent arithmetic when every step carried its index compare; the lanes that do wrap redo the block
+                    // step reads), the steps are 16 plain adds; the lanes that do wrap redo the block step by step
                     float o = offset, o15 = offset;
 #pragma unroll
                     for (int k = 0; k < 16; ++k) { o15 = o; o = o + ds; }
@@ -462,7 +462,30 @@ __global__ __launch_bounds__(64) void cycle_scan(SceneParams P, const SrcStatic*
                     }
                     last = max(last, reach);
                 }
+            };
+            uint32_t k0 = 0;
+            // 64 steps at a time while the chunk has them: the chain of dependent adds IS this kernel (2048 per source: ~10 000
+            // cycles at best), and the end-of-clip test, the loop and the checkpoint bookkeeping per 16 steps nearly doubled it.
+            // Checked on the offset the 64th step reads; a lane that reaches the clip's end redoes the 64 steps in blocks of 16
+            // (which rewrite the three checkpoints stored on the way).
+            for (; k0 + 64u <= len_c; k0 += 64u) {
+                float o = offset, o63 = offset;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    CycleCk v; v.base = base; v.offset = o;
+                    c[((done + k0) >> 4) + (uint32_t)q] = v;
+#pragma unroll
+                    for (int k = 0; k < 16; ++k) { o63 = o; o = o + ds; }
+                }
+                const uint32_t xl = base + f32_as_index(o63);
+                if (ds > 0.0f && xl < len) { offset = o; last = xl; hit = hit || xl + 1u >= len; }
+                else {
+#pragma unroll 1
+                    for (uint32_t q = 0; q < 4u; ++q) block16(k0 + 16u * q);
+                }
             }
+#pragma unroll 1
+            for (; k0 < len_c; k0 += 16u) block16(k0);
 #pragma unroll
             for (int ee = 0; ee < 2; ++ee)
 #pragma unroll
