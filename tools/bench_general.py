@@ -9,6 +9,7 @@ import time
 import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ.setdefault("ODDIO_HIP_MAX_CYCLE", "4096")      # (Seek-set Cycle sources per scene: 1024 by default)
 import oddio_amd as oa  # noqa: E402
 from oddio_amd import synth  # noqa: E402
 
@@ -49,13 +50,15 @@ def main():
     clips = {rate: oa.Frames.from_slice(rate, synth.noise_clip(9, rate // 1000, 40 * rate)) for rate in (48000, 96000, 192000)}
     st2 = oa.Frames.from_slice(48000, np.stack([synth.noise_clip(4, 0, 480000), synth.noise_clip(4, 1, 480000)], axis=1))
     cyc4 = oa.Frames.from_slice(48000, synth.noise_clip(2, 0, 5000))
+    cyc48 = oa.Frames.from_slice(48000, synth.noise_clip(2, 1, 48000))
     makers = [
         ("FramesSignal, 48 kHz clip (the staged-window path)", lambda i: oa.FramesSignal(clips[48000], 1.0), n_src),
         ("FramesSignal, 96 kHz clip (resample ratio 2)", lambda i: oa.FramesSignal(clips[96000], 1.0), n_src),
         ("FramesSignal, 192 kHz clip (resample ratio 4)", lambda i: oa.FramesSignal(clips[192000], 1.0), n_src),
         ("Sine", lambda i: oa.Sine(0.1 * i, 110.0 + 0.25 * i), n_src),
         ("Downmix<FramesSignal<[f32;2]>>", lambda i: oa.Downmix(oa.FramesSignal(st2, 1.0)), n_src),
-        ("Cycle", lambda i: oa.Cycle(cyc4), 1024),
+        ("Cycle, 5000-sample loop (a tenth of the tiles touches the loop's end: row path)", lambda i: oa.Cycle(cyc4), n_src),
+        ("Cycle, 48000-sample loop", lambda i: oa.Cycle(cyc48), n_src),
     ]
     base_ms = None
     for name, mk, count in makers:

@@ -24,5 +24,6 @@ tools/profile_pmc.sh $TAG/pmc_buffered --workload buffered --steps 8 --warmup 2 
 python tools/make_pmc_json.py "$OUT/pmc_buffered/summary.json" 262144 "$OUT/pmc_buffered_latest.json" buffered >> "$OUT/pmc_buffered.log" 2>&1
 python tools/ordered_probe.py > "$OUT/ordered_probe.txt" 2>/dev/null
 python tools/bench_seek_kinds.py > "$OUT/seek_kinds.txt" 2>/dev/null
+python tools/bench_seek_kinds.py --sources 4096 > "$OUT/seek_kinds_4096.txt" 2>/dev/null
 python tools/bench_general.py > "$OUT/bench_general.txt" 2>&1
 ls "$OUT"
