@@ -8,12 +8,16 @@ doubled; WRITE_SIZE is taken as is (uncalibrated, < 1 % of the traffic here)."""
 import json
 import sys
 
+def _targs(k):     # spatial_mix<FULL, STORE, FUSED, RING, DMX> -> its template arguments (older trees: fewer)
+    return [a.strip() for a in k[k.index("<") + 1:k.rindex(">")].split(",")] if "<" in k else []
+
+
 summary, sources, out = sys.argv[1], int(sys.argv[2]), sys.argv[3]
 d = json.load(open(summary))
 if len(sys.argv) > 4 and sys.argv[4] == "buffered":
     # the buffered set's path: buffered_walk + buffered_write + spatial_mix<.., RING> (+ the reduce of its partial tiles)
     ks = {"walk": [k for k in d if k.startswith("buffered_walk")], "write": [k for k in d if k.startswith("buffered_write")],
-          "reads": [k for k in d if k.startswith("spatial_mix<") and k.rstrip(">").endswith("true") and k.count(",") == 3]}
+          "reads": [k for k in d if k.startswith("spatial_mix<") and _targs(k)[3:4] == ["true"]]}
     res = {"sources": sources, "kernels": {}, "correction": "read side x2 (gfx950 FETCH_SIZE counts 64 B per 128 B request on wide coalesced loads)"}
     total = 0.0
     for name, cand in ks.items():
@@ -30,8 +34,8 @@ if len(sys.argv) > 4 and sys.argv[4] == "buffered":
     sys.exit(0)
 # the FAST instantiation the timed region runs -- spatial_mix<FULL, false, true> (fused arithmetic) -- not the row render of the
 # ORDERED-mode callbacks (<.., true, ..>) nor the unfused repeat of the timed region (<.., false, false>); older trees: <FULL, false>
-def _ring(k):      # spatial_mix<FULL, STORE, FUSED, RING>: the buffered set's ring reads
-    return k.count(",") == 3 and k.rstrip(">").rstrip().endswith("true")
+def _ring(k):      # spatial_mix<FULL, STORE, FUSED, RING, DMX>: the buffered set's ring reads
+    return _targs(k)[3:4] == ["true"]
 d_all = d
 d = {k: v for k, v in d.items() if not (k.startswith("spatial_mix<") and _ring(k))}
 cands = [k for k in d if k.startswith("spatial_mix<true, false, true") or k.startswith("spatial_mix<false, false, true")]

@@ -10,7 +10,14 @@ import sys
 path = sys.argv[1]
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 20
 after = int(sys.argv[3]) if len(sys.argv) > 3 else 16
-rows = [r for r in csv.DictReader(open(path)) if r["Kernel_Name"].startswith(("void oddio_hip::spatial_mix<true, false>", "void oddio_hip::spatial_mix<true, false, true>"))]
+def _timed_kernel(name):      # the FAST instantiation of the Seek set: spatial_mix<true, false, true[, false[, false]]> (older trees: <true, false>)
+    if not name.startswith("void oddio_hip::spatial_mix<"):
+        return False
+    a = [x.strip() for x in name[name.index("<") + 1:name.index(">")].split(",")]
+    return a[:2] == ["true", "false"] and (len(a) == 2 or a[2] == "true") and a[3:4] != ["true"]
+
+
+rows = [r for r in csv.DictReader(open(path)) if _timed_kernel(r["Kernel_Name"])]
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 timed = rows[len(rows) - after - steps: len(rows) - after]
 print("launch,start_ns,duration_us,gap_before_us")
