@@ -538,8 +538,6 @@ def bench_buffered(args, device: int, shared=None) -> dict:
     scene.synchronize()
     general_ms = (time.perf_counter() - tg0) / 4 * 1e3
     scene.set_buffered_fast(True)
-    if os.environ.get("ODDIO_BENCH_DEBUG"):
-        print("len after general leg", scene.len_buffered(), "step_no", step_no, "span", span, file=sys.stderr)
     # ORDERED mode (the reference's sum order: contribution rows + ordered_sum), the figure that conforms to the 1e-5 tolerance at
     # this source count (tests/test_hip_buffered_fast.py: bit-exact at 65 536 buffered sources)
     scene.set_mode(oa.MODE_ORDERED)
@@ -551,13 +549,6 @@ def bench_buffered(args, device: int, shared=None) -> dict:
         one_step()
     scene.synchronize()
     ordered_ms = (time.perf_counter() - to0) / 8 * 1e3
-    if os.environ.get("ODDIO_BENCH_DEBUG"):
-        scene.set_profiling(1)
-        for _ in range(4):
-            one_step()
-        scene.synchronize()
-        print("ORDERED stages", scene.buffered_ms_history(4), "slow", scene.debug_buffered_slow(), "len", scene.len_buffered(), "ms", ordered_ms, file=sys.stderr)
-        scene.set_profiling(False)
     scene.set_mode(oa.MODE_FAST)
     assert scene.len_buffered() == S, "sources finished inside the ORDERED leg"
 
