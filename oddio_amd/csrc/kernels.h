@@ -882,13 +882,14 @@ __global__ __launch_bounds__(256) void spatial_prepass(SceneParams P, const SrcS
                                                        EarParams* __restrict__ ear, uint32_t* __restrict__ stopped_hdr,
                                                        uint32_t stopped_cap, int check_pending, const uint32_t* __restrict__ d_len,
                                                        uint32_t* __restrict__ len_snap, TileRec* __restrict__ recs, uint32_t rec_stride,
-                                                       uint32_t n_rec_tiles, int ear_always, uint32_t* __restrict__ cycle_list, uint32_t cycle_par) {
+                                                       uint32_t n_rec_tiles, int ear_always, uint32_t* __restrict__ cycle_list,
+                                                       uint32_t* __restrict__ cycle_rlist, uint32_t cycle_par) {
     __shared__ uint32_t stage[4][64 * 17];
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     const int lane = threadIdx.x & 63;
     uint32_t* lds = stage[threadIdx.x >> 6];
     const uint32_t len = d_len[0];
-    if (i == 0) { *len_snap = len; if (cycle_list) { cycle_list[cycle_par ^ 1u] = 0u; cycle_list[rec_stride + 2u + (cycle_par ^ 1u)] = 0u; } }   // (cycle_scan's render list follows the list)
+    if (i == 0) { *len_snap = len; if (cycle_list) { cycle_list[cycle_par ^ 1u] = 0u; cycle_rlist[cycle_par ^ 1u] = 0u; } }   // (the lists of the callback after this one)
     const uint32_t first = i - (uint32_t)lane;
     if (first >= len) return;                                       // whole wave past the end
     const uint32_t n_valid = (len - first) < 64u ? (len - first) : 64u;
