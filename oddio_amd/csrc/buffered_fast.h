@@ -192,8 +192,7 @@ __global__ __launch_bounds__(128) void buffered_walk(SceneParams P, const BufSta
     const uint32_t n_valid = (len - first) < 64u ? (len - first) : 64u;
     BufStatic s = {};
     BufDyn d = {};
-    wave_aos_load(s, st, first, n_valid, lane, lds);
-    wave_aos_load(d, dyn, first, n_valid, lane, lds);
+    wave_aos_load2(s, st, d, dyn, first, n_valid, lane, lds);
     WriteRec wr = {};
     TileRec tr[REC_TILES];
 #pragma unroll

@@ -701,6 +701,44 @@ template <class T> __device__ __forceinline__ void wave_aos_load(T& out, const T
     __builtin_memcpy(&out, o, sizeof(T));
     wave_sync();
 }
+// Two tables at once: both blocks' global loads are in flight together (one after the other, the second waited behind the
+// first's LDS round trip: a memory latency of the walk, which at small set sizes is nothing but latencies).
+template <class A, class B> __device__ __forceinline__ void wave_aos_load2(A& out_a, const A* __restrict__ arr_a, B& out_b, const B* __restrict__ arr_b,
+                                                                           uint32_t first, uint32_t n_valid, int lane, uint32_t* lds) {
+    constexpr int WA = sizeof(A) / 4, QA = WA / 4, WB = sizeof(B) / 4, QB = WB / 4;
+    const uint4* src_a = reinterpret_cast<const uint4*>(arr_a + first);
+    const uint4* src_b = reinterpret_cast<const uint4*>(arr_b + first);
+    uint4 qa[QA], qb[QB];
+#pragma unroll
+    for (int k = 0; k < QA; ++k) { const int v = lane + 64 * k; qa[k] = (uint32_t)(v / QA) < n_valid ? src_a[v] : make_uint4(0u, 0u, 0u, 0u); }
+#pragma unroll
+    for (int k = 0; k < QB; ++k) { const int v = lane + 64 * k; qb[k] = (uint32_t)(v / QB) < n_valid ? src_b[v] : make_uint4(0u, 0u, 0u, 0u); }
+#pragma unroll
+    for (int k = 0; k < QA; ++k) {
+        const int v = lane + 64 * k;
+        uint32_t* dst = lds + (v / QA) * (WA + 1) + (v % QA) * 4;
+        dst[0] = qa[k].x; dst[1] = qa[k].y; dst[2] = qa[k].z; dst[3] = qa[k].w;
+    }
+    wave_sync();
+    uint32_t oa[WA];
+#pragma unroll
+    for (int w = 0; w < WA; ++w) oa[w] = lds[lane * (WA + 1) + w];
+    __builtin_memcpy(&out_a, oa, sizeof(A));
+    wave_sync();
+#pragma unroll
+    for (int k = 0; k < QB; ++k) {
+        const int v = lane + 64 * k;
+        uint32_t* dst = lds + (v / QB) * (WB + 1) + (v % QB) * 4;
+        dst[0] = qb[k].x; dst[1] = qb[k].y; dst[2] = qb[k].z; dst[3] = qb[k].w;
+    }
+    wave_sync();
+    uint32_t ob[WB];
+#pragma unroll
+    for (int w = 0; w < WB; ++w) ob[w] = lds[lane * (WB + 1) + w];
+    __builtin_memcpy(&out_b, ob, sizeof(B));
+    wave_sync();
+}
+
 template <class T> __device__ __forceinline__ void wave_aos_store(const T& in, T* __restrict__ arr, uint32_t first, uint32_t n_valid, int lane, uint32_t* lds) {
     constexpr int W = sizeof(T) / 4, Q = W / 4;
     uint32_t o[W];
@@ -895,8 +933,7 @@ __global__ __launch_bounds__(256) void spatial_prepass(SceneParams P, const SrcS
     const uint32_t n_valid = (len - first) < 64u ? (len - first) : 64u;
     SrcDyn d = {};
     SrcStatic s = {};
-    wave_aos_load(d, dyn, first, n_valid, lane, lds);
-    wave_aos_load(s, st, first, n_valid, lane, lds);
+    wave_aos_load2(d, dyn, s, st, first, n_valid, lane, lds);
     EarPair ep = {};
     ep.e[0].flags = EAR_SKIP; ep.e[1].flags = EAR_SKIP;
     if (i < len) prepass_source(P, i, d, s, pend, ep.e[0], ep.e[1], stopped_hdr, stopped_cap, check_pending);
