@@ -7,7 +7,7 @@ restatement (oracle/oracle_np.py) on the very same scenario -- the script refuse
 fixture on which the two disagree.  A fixture is data only: scene description arrays, the event
 schedule and the rendered stereo buffers.
 
-    python tests/golden/gen_golden.py        # rewrites tests/golden/*.npz
+    python tests/golden/gen_golden.py [name ...]     # rewrites tests/golden/*.npz (or only the named fixtures)
 """
 import os
 import sys
@@ -23,13 +23,14 @@ import scenario  # noqa: E402
 from oddio_amd import synth  # noqa: E402
 from oracle import oracle_np as on  # noqa: E402
 
-KIND_ID = {"frames": 0, "sine": 1, "constant": 2, "cycle": 3}
+KIND_ID = {"frames": 0, "sine": 1, "constant": 2, "cycle": 3, "downmix": 4}     # (a downmix clip is stored interleaved: [l0, r0, l1, r1, ...])
+ONLY = set(sys.argv[1:])
 
 
 def pack(spec, events, n_frames, n_callbacks, interval, postfx, outputs):
     srcs = spec["sources"]
     n = len(srcs)
-    clips = [s.get("clip", np.zeros(0, np.float32)) for s in srcs]
+    clips = [np.asarray(s.get("clip", np.zeros(0, np.float32)), np.float32).reshape(-1) for s in srcs]
     offs = np.zeros(n + 1, dtype=np.int64)
     offs[1:] = np.cumsum([len(c) for c in clips])
     ev_motion = [(cb, e[1], *e[2], *e[3], int(e[4])) for cb, evs in events.items() for e in evs if e[0] == "motion"]
@@ -62,6 +63,8 @@ def numpy_render(spec, events, n_frames, n_callbacks, interval, postfx):
             src = on.frames_source(s["rate"], s["clip"], s["start"], fixed_gain_db=s.get("gain_db"))
         elif s["kind"] == "cycle":
             src = on.cycle_source(s["rate"], s["clip"], fixed_gain_db=s.get("gain_db"))
+        elif s["kind"] == "downmix":
+            src = on.downmix_source(s["rate"], s["clip"], s["start"], fixed_gain_db=s.get("gain_db"))
         elif s["kind"] == "sine":
             src = on.sine_source(s["phase"], s["hz"], fixed_gain_db=s.get("gain_db"))
         else:
@@ -84,6 +87,8 @@ def numpy_render(spec, events, n_frames, n_callbacks, interval, postfx):
 
 
 def make(name, spec, events, n_frames, n_callbacks, postfx=0):
+    if ONLY and name not in ONLY:
+        return
     interval = np.float32(1.0) / np.float32(48000)
     ob = scenario.play_all(scenario.OracleBackend(), spec)
     if postfx:
@@ -124,6 +129,23 @@ def main():
     spec["sources"][2]["clip"] = spec["sources"][2]["clip"][:7]
     ev = {1: [("motion", 0, spec["sources"][0]["pos"] + np.float32(0.7), spec["sources"][0]["vel"], False)]}
     make("cycle_in_scene", spec, ev, 700, 3)
+    # 6. Cycle loops of several tiles (round 4: most of their tiles are rendered from the staged window like a clip's, the tiles that
+    #    touch the loop's end by the row path), three clip rates, a jump that puts the ears of a source on different laps
+    spec = scenario.random_spec(1006, 7, kinds=("cycle",), cube=9.0, cycle_len=8)
+    for i, (n, rate) in enumerate(((2100, 48000), (9000, 96000), (3001, 44100), (1500, 48000), (20000, 192000), (5000, 48000), (700, 48000))):
+        spec["sources"][i]["clip"] = synth.noise_clip(1006, i, n)
+        spec["sources"][i]["rate"] = rate
+        spec["sources"][i]["gain_db"] = (None, -3.5)[i % 2]
+    ev = {2: [("motion", 1, spec["sources"][1]["pos"] + np.float32(40.0), spec["sources"][1]["vel"], True)],
+          3: [("rotation", [np.cos(0.3), np.sin(0.3), 0.0, 0.0])]}
+    make("cycle_long_loops", spec, ev, 1024, 5)
+    # 7. Downmix<FramesSignal<[f32;2]>> (round 4: interleaved stereo windows): three clip rates, a source at rest (the constant-fract
+    #    branch of frames.rs:180-187), a ragged callback length (downmix.rs:24-29 advances the inner clip a whole buffer per chunk)
+    spec = scenario.random_spec(1007, 6, kinds=("downmix", "downmix", "frames"), gain_db=(None, 2.0, None), clip_len=6000, cube=7.0, start=-0.004)
+    for i, rate in enumerate((48000, 96000, 48000, 44100, 48000, 22050)):
+        spec["sources"][i]["rate"] = rate
+    spec["sources"][4]["vel"] = np.zeros(3, np.float32)
+    make("downmix_rates", spec, {}, 700, 5)
 
 
 if __name__ == "__main__":

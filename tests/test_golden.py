@@ -11,7 +11,7 @@ import pytest
 import scenario
 
 GOLDEN = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "*.npz")))
-KINDS = {0: "frames", 1: "sine", 2: "constant", 3: "cycle"}
+KINDS = {0: "frames", 1: "sine", 2: "constant", 3: "cycle", 4: "downmix"}
 
 
 def load(path):
@@ -29,6 +29,10 @@ def load(path):
         elif kind == "cycle":
             s["clip"] = z["clip_data"][z["clip_offsets"][i]:z["clip_offsets"][i + 1]].copy()
             s["rate"] = int(z["rate"][i])
+        elif kind == "downmix":        # interleaved stereo frames
+            s["clip"] = z["clip_data"][z["clip_offsets"][i]:z["clip_offsets"][i + 1]].copy().reshape(-1, 2)
+            s["rate"] = int(z["rate"][i])
+            s["start"] = float(z["start"][i])
         elif kind == "sine":
             s["phase"], s["hz"] = float(z["phase"][i]), float(z["hz"][i])
         else:
