@@ -428,6 +428,9 @@ int oddio_hip_mixer_set_postfx(oddio_hip_mixer* mixer, int postfx);
 /* Adapt::new(mixer, ..): same as oddio_hip_scene_set_adapt for a Mixer (examples/adapt.rs:6-16). */
 int oddio_hip_mixer_set_adapt(oddio_hip_mixer* mixer, int enable, float initial_rms, float tau,
                               float max_gain, float low, float high);
+/* The sum modes of oddio_hip_scene_set_mode for a Mixer (src/mixer.rs:100-117 walks the set in reverse slot order).  ORDERED on a
+ * mixer created for more than 1024 sources allocates the contribution rows of the two-kernel path (8 bytes per source and frame
+ * of max_frames, on the calling -- control -- thread); without them (out of memory) large mixers keep the one-wavefront walk. */
 int oddio_hip_mixer_set_mode(oddio_hip_mixer* mixer, int mode);
 /* Signal::sample for Mixer (src/mixer.rs:92-119) / oddio::run */
 int oddio_hip_mixer_sample(oddio_hip_mixer* mixer, float interval, float* out, size_t n_frames);

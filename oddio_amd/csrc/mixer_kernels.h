@@ -45,6 +45,7 @@ constexpr int MIXER_TILE = 1024;               // one tile == one Mixer staging 
 constexpr int MIXER_WIN_CAP = 1536;           // padded single-copy window (one pad float per 16 samples)
 constexpr int MIXER_WIN_PAD = MIXER_WIN_CAP + MIXER_WIN_CAP / 16 + 16;
 constexpr int MIXER_CKPT_STRIDE = 65;
+constexpr int MIXER_WIN_VECS = (MIXER_WIN_CAP / 4 + 63) / 64;   // 16-byte vectors per lane that cover the largest staged window
 
 struct MixerLds {
     float ckpt[64 * MIXER_CKPT_STRIDE];   // [phase-A lane = source][64 checkpoints]
@@ -53,10 +54,17 @@ struct MixerLds {
     float win[MIXER_WIN_PAD];
 };
 
-template <bool FULL>
+// `groups_per_wave`: groups of 64 sources a wave walks; with 2^k in its top byte instead, 2^k waves share ONE group and each renders
+// 64 >> k of its sources (small mixers: a wave renders its sources one after the other, ~2.5 us each -- 64 of them were 170 us
+// per callback however few sources the mixer held; round 4).
+// STORE (ORDERED mode above the serial threshold, round 4): instead of accumulating, every source's contribution is written to its
+// rows in the layout ordered_sum reads (kernels.h: [group of 16 sources][ear][16-frame column block][source][16 frames]; MonoToStereo:
+// the same row for both ears), and ordered_sum adds them in the reference's order (mixer.rs:100-117, reverse slot order).
+template <bool FULL, bool STORE = false>
 __global__ __launch_bounds__(64) void mixer_mix(uint32_t n_sources, uint32_t n_frames, float interval,
                                                 const MixStatic* __restrict__ st, const MixParams* __restrict__ par,
-                                                float* __restrict__ partials, uint32_t groups_per_wave, uint32_t n_groups) {
+                                                float* __restrict__ partials, uint32_t groups_per_wave, uint32_t n_groups,
+                                                float* __restrict__ rows, uint32_t rows_ncb) {
     __shared__ MixerLds L;
     const int lane = threadIdx.x;
     const uint32_t wave = blockIdx.x, tile = blockIdx.y;
@@ -64,8 +72,17 @@ __global__ __launch_bounds__(64) void mixer_mix(uint32_t n_sources, uint32_t n_f
 #pragma unroll
     for (int k = 0; k < 16; ++k) acc[k] = 0.0f;
     const uint32_t frame0 = tile * MIXER_TILE + 16u * (uint32_t)lane;
-    const uint32_t g_lo = wave * groups_per_wave;
-    uint32_t g_hi = g_lo + groups_per_wave;
+    const uint32_t split_log2 = groups_per_wave >> 24;
+    uint32_t g_lo = wave * (groups_per_wave & 0xffffffu);
+    uint32_t g_hi = g_lo + (groups_per_wave & 0xffffffu);
+    int j_lo = 0, j_hi = MIXER_GROUP;
+    if (split_log2) {
+        g_lo = wave >> split_log2;
+        g_hi = g_lo + 1u;
+        const int per = MIXER_GROUP >> split_log2;
+        j_lo = (int)(wave & ((1u << split_log2) - 1u)) * per;
+        j_hi = j_lo + per;
+    }
     if (g_hi > n_groups) g_hi = n_groups;
     const int len_tile = (int)n_frames - (int)(tile * MIXER_TILE) > MIXER_TILE ? MIXER_TILE : (int)n_frames - (int)(tile * MIXER_TILE);
 
@@ -133,31 +150,64 @@ __global__ __launch_bounds__(64) void mixer_mix(uint32_t n_sources, uint32_t n_f
         wave_sync();
 
         // ---- phase B: one source at a time, lane l owns frames 16l..16l+15 of the tile ----
+        // a staged source's window travels global memory -> `pre` (registers) -> L.win
+        float4 pre[MIXER_WIN_VECS];
+#define MIXER_FETCH(JN)                                                                                                   \
+    {                                                                                                                     \
+        const int ws_n = __builtin_amdgcn_readfirstlane(L.sinfo[(JN) * 2 + 0]);                                           \
+        const int nvec_n = (__builtin_amdgcn_readfirstlane(L.sinfo[(JN) * 2 + 1]) + 3) >> 2;                              \
+        const uint64_t cp_n = ((uint64_t)(uint32_t)rl_i((int)((uint64_t)ss.clip >> 32), (JN)) << 32) |                    \
+                              (uint64_t)(uint32_t)rl_i((int)((uint64_t)ss.clip & 0xffffffffu), (JN));                     \
+        const float* clip_n = (const float*)cp_n;                                                                         \
+        const int len4_n = (int)((rl_i((int)ss.clip_len, (JN)) + 3) & ~3);                                                \
+        _Pragma("unroll") for (int k = 0; k < MIXER_WIN_VECS; ++k) {                                                      \
+            const int v = lane + 64 * k, idx = ws_n + 4 * v;                                                              \
+            pre[k] = (v < nvec_n && idx >= 0 && idx < len4_n) ? *reinterpret_cast<const float4*>(clip_n + idx) : make_float4(0.f, 0.f, 0.f, 0.f); \
+        }                                                                                                                 \
+    }
+#define MIXER_COMMIT(JN)                                                                                                  \
+    {                                                                                                                     \
+        const int nvec_n = (__builtin_amdgcn_readfirstlane(L.sinfo[(JN) * 2 + 1]) + 3) >> 2;                              \
+        _Pragma("unroll") for (int k = 0; k < MIXER_WIN_VECS; ++k) {                                                      \
+            const int v = lane + 64 * k;                                                                                  \
+            if (v < nvec_n) {                                                                                             \
+                const int li = 4 * v, pos = li + (li >> 4);                                                               \
+                L.win[pos + 0] = pre[k].x; L.win[pos + 1] = pre[k].y; L.win[pos + 2] = pre[k].z; L.win[pos + 3] = pre[k].w; \
+                if ((li & 15) == 0 && li > 0) L.win[pos - 1] = pre[k].x;                                                  \
+            }                                                                                                             \
+        }                                                                                                                 \
+    }
+        {
+            int first = -1;
+            for (int t = j_hi - 1; t >= j_lo; --t)
+                if (__builtin_amdgcn_readfirstlane(L.cinfo[t * 4 + 3]) == PATH_LDS) { first = t; break; }
+            if (first >= 0) MIXER_FETCH(first)
+        }
 #pragma unroll 1
-        for (int j = MIXER_GROUP - 1; j >= 0; --j) {
+        for (int j = j_hi - 1; j >= j_lo; --j) {
             const int path_j = __builtin_amdgcn_readfirstlane(L.cinfo[j * 4 + 3]);
-            if (path_j == PATH_SKIP) continue;
+            if (STORE) {
+                // the previous source's row is out; this one starts from zero (a skipped source leaves a row of zeros: x + 0.0 == x
+                // for every x the running sum can hold, which is never -0.0)
+#pragma unroll
+                for (int k = 0; k < 16; ++k) acc[k] = 0.0f;
+            }
+            if (path_j != PATH_SKIP) {
             const float fg = rl_f(ss.fixed_gain, j);
             const bool active = FULL || frame0 < n_frames;
             if (path_j == PATH_LDS) {
-                const int ws_j = __builtin_amdgcn_readfirstlane(L.sinfo[j * 2 + 0]);
-                const int count_j = __builtin_amdgcn_readfirstlane(L.sinfo[j * 2 + 1]);
-                const uint64_t cp = ((uint64_t)(uint32_t)rl_i((int)((uint64_t)ss.clip >> 32), j) << 32) |
-                                    (uint64_t)(uint32_t)rl_i((int)((uint64_t)ss.clip & 0xffffffffu), j);
-                const float* clip = (const float*)cp;
-                const int clip_len4 = (int)((rl_i((int)ss.clip_len, j) + 3) & ~3);
-                const int nvec = (count_j + 3) >> 2;
+                // this source's window is in `pre` (fetched while the staged source before it was rendered): into the LDS stage,
+                // padded layout; then the next staged source's fetch starts and lands while this one renders (round 4: one
+                // source at a time, load then render, a wave spent 2.5 - 5 us per source waiting)
                 wave_sync();
-                for (int v = lane; v < nvec; v += 64) {
-                    const int idx = ws_j + 4 * v;
-                    float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
-                    if (idx >= 0 && idx < clip_len4) val = *reinterpret_cast<const float4*>(clip + idx);
-                    const int li = 4 * v;
-                    const int pos = li + (li >> 4);
-                    L.win[pos + 0] = val.x; L.win[pos + 1] = val.y; L.win[pos + 2] = val.z; L.win[pos + 3] = val.w;
-                    if ((li & 15) == 0 && li > 0) L.win[pos - 1] = val.x;
+                MIXER_COMMIT(j)
+                wave_sync();
+                {
+                    int nxt = -1;
+                    for (int t = j - 1; t >= j_lo; --t)
+                        if (__builtin_amdgcn_readfirstlane(L.cinfo[t * 4 + 3]) == PATH_LDS) { nxt = t; break; }
+                    if (nxt >= 0) MIXER_FETCH(nxt)
                 }
-                wave_sync();
                 if (active) {
                     const int wrel = rl_i(L.cinfo[j * 4 + 0], 0);
                     const float fracf = __int_as_float(rl_i(L.cinfo[j * 4 + 1], 0));
@@ -238,10 +288,28 @@ __global__ __launch_bounds__(64) void mixer_mix(uint32_t n_sources, uint32_t n_f
                     }
                 }
             }
+            }   // path_j != PATH_SKIP
+            if (STORE) {
+                const uint32_t slot = g * MIXER_GROUP + (uint32_t)j;
+                if (slot < n_sources && (FULL || frame0 < n_frames)) {
+                    // the lane's 16 sums are one 64-byte row: column block tile * 64 + lane of source `slot`, both ears
+                    unsigned char* p = reinterpret_cast<unsigned char*>(rows) + (size_t)(slot >> 4) * (2u * (size_t)rows_ncb * 1024u) +
+                                       ((size_t)tile * 64u + (size_t)lane) * 1024u + (size_t)(slot & 15u) * 64u;
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) {
+                        float4* d4 = reinterpret_cast<float4*>(p + (size_t)e * rows_ncb * 1024u);
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) d4[q] = make_float4(acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]);
+                    }
+                }
+            }
         }
         wave_sync();
     }
+#undef MIXER_FETCH
+#undef MIXER_COMMIT
     (void)len_tile;
+    if (STORE) return;
     // MonoToStereo: duplicate (signal.rs:73-80); Mixer adds per channel (mixer.rs:114-116)
     float4* dst = reinterpret_cast<float4*>(partials + ((size_t)tile * gridDim.x + wave) * (2 * MIXER_TILE) + 32 * lane);
 #pragma unroll

@@ -92,6 +92,131 @@ def test_mixer_frames_sources(mode, n_frames):
     mixer.close()
 
 
+def _big_mixer(n_src, max_frames, seed=21):
+    """n_src MonoToStereo sources of every fast-path kind (FramesSignal at four rates, some under FixedGain, some that run out
+    of clip; Sine; Constant) in a HIP Mixer and the oracle's; a few clips shared (the host side stays small)."""
+    import oddio_amd as oa
+    control, mixer = oa.Mixer(max_sources=n_src + 8, max_frames=max_frames)
+    cm = oc.Mixer(2)
+    rates = (48000, 44100, 96000, 22050)
+    clips = [synth.noise_clip(seed, k, 3000 + 997 * k) for k in range(12)]
+    frames = {}
+    hs, hc = [], []
+    for i in range(n_src):
+        kind = i % 7
+        if kind == 5:
+            sig, osig = oa.Sine(0.1 * i, 100.0 + 0.37 * i), oc.Sine(0.1 * i, 100.0 + 0.37 * i)
+        elif kind == 6:
+            sig, osig = oa.Constant(0.001 * (i % 50) - 0.02), oc.Constant(0.001 * (i % 50) - 0.02)
+        else:
+            k, rate = i % 12, rates[i % 4]
+            if (k, rate) not in frames:
+                frames[(k, rate)] = (oa.Frames.from_slice(rate, clips[k]), oc.Frames(rate, clips[k]))
+            start = -0.002 * (i % 4) + 0.01 * (i % 3)
+            sig, osig = oa.FramesSignal(frames[(k, rate)][0], start), oc.FramesSignal(frames[(k, rate)][1], start)
+        if i % 5 == 0 and kind != 6:
+            sig, osig = oa.FixedGain(sig, -3.0 - (i % 4)), oc.FixedGain(osig, -3.0 - (i % 4))
+        hs.append(control.play(oa.MonoToStereo(sig)))
+        hc.append(cm.play(oc.MonoToStereo(osig)))
+    return mixer, cm, hs, hc
+
+
+@pytest.mark.parametrize("n_src,n_frames", [(3000, 1024), (1500, 700), (1100, 2500)])
+def test_large_mixer_ordered_rows_path_bit_exact(n_src, n_frames):
+    """Round 4: above the serial threshold (1024 sources) ORDERED mode writes every source's contribution to its rows
+    (mixer_mix<.., STORE>) and ordered_sum adds them in the reference's order (mixer.rs:100-117): bit-exact, with sources that
+    finish or are stopped on the way (rows of zeros, then removal) and the post filter."""
+    mixer, cm, hs, hc = _big_mixer(n_src, 4096)
+    mixer.set_mode(1)
+    mixer.set_postfx(1)
+    ref_top = oc.Reinhard(cm)
+    for cb in range(6):
+        if cb == 2:
+            for j in range(5, n_src, 97):
+                hs[j].stop()
+                hc[j].stop()
+        got = mixer.sample_n(np.float32(1.0) / np.float32(48000), n_frames)
+        ref = ref_top.sample_n(np.float32(1.0) / np.float32(48000), n_frames)
+        assert np.abs(got - ref).max() <= 1e-5 * np.abs(ref).max()          # (Sine sources: device sinf)
+        assert len(mixer) == len(cm)
+    mixer.close()
+
+
+@pytest.mark.parametrize("n_src,n_frames", [(2000, 1024), (1300, 1536)])
+def test_large_mixer_ordered_rows_path_exact_kinds_bit_exact(n_src, n_frames):
+    """The same without Sine sources (the one kind whose samples differ from glibc's by an ulp): every bit."""
+    import oddio_amd as oa
+    control, mixer = oa.Mixer(max_sources=n_src, max_frames=2048)
+    cm = oc.Mixer(2)
+    mixer.set_mode(1)
+    clips = [synth.noise_clip(5, k, 2500 + 613 * k) for k in range(9)]
+    fr = [(oa.Frames.from_slice(r, c), oc.Frames(r, c)) for c in clips for r in (48000, 44100)]
+    hs, hc = [], []
+    for i in range(n_src):
+        if i % 6 == 5:
+            sig, osig = oa.Constant(0.01 * (i % 7)), oc.Constant(0.01 * (i % 7))
+        else:
+            f = fr[i % len(fr)]
+            sig, osig = oa.FramesSignal(f[0], 0.004 * (i % 5)), oc.FramesSignal(f[1], 0.004 * (i % 5))
+            if i % 4 == 1:
+                sig, osig = oa.FixedGain(sig, -2.5), oc.FixedGain(osig, -2.5)
+        hs.append(control.play(oa.MonoToStereo(sig)))
+        hc.append(cm.play(oc.MonoToStereo(osig)))
+    for cb in range(7):
+        if cb == 3:
+            for j in range(0, n_src, 41):
+                hs[j].stop()
+                hc[j].stop()
+        got = mixer.sample_n(np.float32(1.0) / np.float32(48000), n_frames)
+        ref = cm.sample_n(np.float32(1.0) / np.float32(48000), n_frames)
+        np.testing.assert_array_equal(got, ref)
+        assert len(mixer) == len(cm)
+    assert len(mixer) < n_src            # clips ran out on the way
+    mixer.close()
+
+
+@pytest.mark.parametrize("mode", [1, 0])
+def test_thousands_of_mixer_sources_finish_in_one_callback(mode):
+    """3000 sources on one 1500-sample clip run out in the same callback (more ids than the stopped list's first copy holds),
+    500 more live on: set sizes, the order of the survivors (ORDERED: every bit) and the handles' flags follow the reference."""
+    import oddio_amd as oa
+    control, mixer = oa.Mixer(max_sources=3600, max_frames=1024)
+    cm = oc.Mixer(2)
+    mixer.set_mode(mode)
+    short, long_ = synth.noise_clip(2, 0, 1500), synth.noise_clip(2, 1, 9000)
+    fs, fl = (oa.Frames.from_slice(48000, short), oc.Frames(48000, short)), (oa.Frames.from_slice(48000, long_), oc.Frames(48000, long_))
+    hs, hc = [], []
+    for i in range(3500):
+        f = fl if i % 7 == 3 else fs
+        hs.append(control.play(oa.MonoToStereo(oa.FramesSignal(f[0], 0.0))))
+        hc.append(cm.play(oc.MonoToStereo(oc.FramesSignal(f[1], 0.0))))
+    for cb in range(5):
+        got = mixer.sample_n(np.float32(1.0) / np.float32(48000), 1024)
+        ref = cm.sample_n(np.float32(1.0) / np.float32(48000), 1024)
+        if mode == 1:
+            np.testing.assert_array_equal(got, ref)
+        else:
+            # (3000 copies of one signal add up coherently: the reference's sequential f32 sum drifts ~4e-5 from the exact sum here,
+            # the tree sum does not -- the same effect as at 262 144 incoherent sources, DESIGN section 2)
+            assert np.abs(got - ref).max() <= 1e-4 * max(np.abs(ref).max(), 1e-30)
+        assert len(mixer) == len(cm)
+        assert [h.is_stopped() for h in hs[::13]] == [h.is_stopped() for h in hc[::13]]
+    assert len(mixer) == 500
+    mixer.close()
+
+
+@pytest.mark.parametrize("n_src", [5, 40, 64, 100, 700, 3000])
+def test_mixer_fast_mode_wave_split_tolerance(n_src):
+    """FAST mode at sizes where 2 .. 16 waves share a group of 64 sources (round 4) and beyond: within 1e-5 of the reference."""
+    mixer, cm, hs, hc = _big_mixer(n_src, 1024, seed=33)
+    for cb in range(3):
+        got = mixer.sample_n(np.float32(1.0) / np.float32(48000), 1024)
+        ref = cm.sample_n(np.float32(1.0) / np.float32(48000), 1024)
+        assert np.abs(got - ref).max() <= 1e-5 * np.abs(ref).max()
+        assert len(mixer) == len(cm)
+    mixer.close()
+
+
 # ---- general path: Cycle, Gain / Speed chains, stereo clips (mixer.rs + cycle.rs + gain.rs + speed.rs) ----
 
 CYCLE_FRAMES = [1.0, 2.0, 3.0]
