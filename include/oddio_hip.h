@@ -54,13 +54,13 @@ enum { /* oddio_hip_scene_set_mode */
                                    reference, not its bits -- use ORDERED for those */
     ODDIO_HIP_MODE_ORDERED = 1, /* the contributions are added in the reference's reverse-index order:
                                    bit-comparable with the sequential f32 sum of src/spatial.rs:204,460.
-                                   Scenes: up to 1024 sources one wavefront walks the set; above that every
-                                   source's contribution is rendered on the whole chip and a second kernel
-                                   adds the rows in order (about 5.5x the FAST callback; set_mode allocates
-                                   2 x 8 KiB per source slot for it, on the calling thread: back-to-back
+                                   Up to 32 sources one wavefront walks the set; above that every source's
+                                   contribution is rendered on the whole chip and a second kernel adds the
+                                   rows in order (about 5.5x the FAST callback at 262 144 sources, 1.5x at
+                                   1024; set_mode allocates 2 x 8 KiB -- mixers: 1 x -- per source slot and
+                                   1024 frames for it, on the calling thread: back-to-back
                                    oddio_hip_scene_sample_device calls on the scene's own stream overlap the
-                                   render of one callback with the sum of the one before).  Mixers: one
-                                   wavefront. */
+                                   render of one callback with the sum of the one before). */
     ODDIO_HIP_MODE_FAST_UNFUSED = 2, /* scenes: FAST's tree sum with the reference's arithmetic in every contribution
                                    (a + t*(b-a), prev_gain + i*d_gain, o += s*gain: each operation rounded by itself,
                                    src/frame.rs:39-41, src/spatial.rs:459-460) -- what FAST was before round 3; ~3-6 %
@@ -429,7 +429,7 @@ int oddio_hip_mixer_set_postfx(oddio_hip_mixer* mixer, int postfx);
 int oddio_hip_mixer_set_adapt(oddio_hip_mixer* mixer, int enable, float initial_rms, float tau,
                               float max_gain, float low, float high);
 /* The sum modes of oddio_hip_scene_set_mode for a Mixer (src/mixer.rs:100-117 walks the set in reverse slot order).  ORDERED on a
- * mixer created for more than 1024 sources allocates the contribution rows of the two-kernel path (8 bytes per source and frame
+ * mixer created for more than 32 sources allocates the contribution rows of the two-kernel path (8 bytes per source and frame
  * of max_frames, on the calling -- control -- thread); without them (out of memory) large mixers keep the one-wavefront walk. */
 int oddio_hip_mixer_set_mode(oddio_hip_mixer* mixer, int mode);
 /* Signal::sample for Mixer (src/mixer.rs:92-119) / oddio::run */

@@ -48,8 +48,10 @@ def main():
         scontrol, scene = oa.SpatialScene(max_sources=S, max_frames=1024)
         scontrol.play_frames_batch([frames[int(k)] for k in pick], np.full(S, 0.25), sc["position"], sc["velocity"], sc["radius"])
         sp = timed(scene)
+        scene.set_mode(oa.MODE_ORDERED)
+        sp_ord = timed(scene, reps=6, warm=2)
         scene.close()
-        print(f"{S:7d} sources: Mixer FAST {fast:8.4f} ms  ORDERED {ordered:8.4f} ms | SpatialScene FAST {sp:8.4f} ms (host-output callbacks)", flush=True)
+        print(f"{S:7d} sources: Mixer FAST {fast:8.4f} ms  ORDERED {ordered:8.4f} ms | SpatialScene FAST {sp:8.4f} ms  ORDERED {sp_ord:8.4f} ms (host-output callbacks)", flush=True)
 
 
 if __name__ == "__main__":
