@@ -205,6 +205,48 @@ def test_thousands_of_mixer_sources_finish_in_one_callback(mode):
     mixer.close()
 
 
+def test_general_path_beyond_1024_sources_bit_exact():
+    """The general path (Gain / Speed chains) held at most 1024 sources until round 4: 2500 Gain<MonoToStereo<FramesSignal>> and
+    Speed sources, gain and speed stores on the way, ORDERED bit-exact and FAST within tolerance."""
+    import oddio_amd as oa
+    for mode in (1, 0):
+        control, mixer = oa.Mixer(max_sources=2600, max_frames=1024)
+        cm = oc.Mixer(2)
+        mixer.set_mode(mode)
+        clips = [synth.noise_clip(8, k, 5000 + 701 * k) for k in range(6)]
+        fr = [(oa.Frames.from_slice(48000, c), oc.Frames(48000, c)) for c in clips]
+        gh, gc = [], []
+        for i in range(2500):
+            f = fr[i % 6]
+            if i % 3 == 2:
+                hsc, hs_ = oa.Speed.new(oa.FramesSignal(f[0], 0.002 * (i % 5)))
+                cs_ = oc.Speed(oc.FramesSignal(f[1], 0.002 * (i % 5)))
+                hsc.set_speed(0.9 + 0.001 * (i % 200))
+                cs_.set_speed(0.9 + 0.001 * (i % 200))
+                control.play(oa.MonoToStereo(hs_))
+                cm.play(oc.MonoToStereo(cs_))
+            else:
+                hgc, hg = oa.Gain.new(oa.MonoToStereo(oa.FramesSignal(f[0], 0.001 * (i % 7))))
+                cg = oc.Gain(oc.MonoToStereo(oc.FramesSignal(f[1], 0.001 * (i % 7))))
+                control.play(hg)
+                cm.play(cg)
+                gh.append(hgc)
+                gc.append(cg)
+        for cb in range(4):
+            if cb == 1:
+                for k in range(0, len(gh), 3):
+                    gh[k].set_amplitude_ratio(0.25 + 0.001 * (k % 300))
+                    gc[k].set_amplitude_ratio(0.25 + 0.001 * (k % 300))
+            got = mixer.sample_n(np.float32(1.0) / np.float32(48000), 1024)
+            ref = cm.sample_n(np.float32(1.0) / np.float32(48000), 1024)
+            if mode == 1:
+                np.testing.assert_array_equal(got, ref)
+            else:
+                assert np.abs(got - ref).max() <= 1e-5 * np.abs(ref).max()
+            assert len(mixer) == len(cm)
+        mixer.close()
+
+
 @pytest.mark.parametrize("n_src", [5, 40, 64, 100, 700, 3000])
 def test_mixer_fast_mode_wave_split_tolerance(n_src):
     """FAST mode at sizes where 2 .. 16 waves share a group of 64 sources (round 4) and beyond: within 1e-5 of the reference."""

@@ -44,6 +44,16 @@ def main():
         mixer.set_mode(oa.MODE_ORDERED)
         ordered = timed(mixer, reps=6, warm=2)
         mixer.close()
+        # the general path: a Gain around every source (GainControl per sound: what a game's mixer holds)
+        control, mixer = oa.Mixer(max_sources=S, max_frames=1024)
+        for i in range(S):
+            gc, g = oa.Gain.new(oa.MonoToStereo(oa.FramesSignal(frames[int(pick[i])], 0.25)))
+            control.play(g)
+        gen_fast = timed(mixer, reps=8, warm=4)
+        mixer.set_mode(oa.MODE_ORDERED)
+        gen_ord = timed(mixer, reps=4, warm=2)
+        mixer.close()
+        print(f"{S:7d} sources: Mixer of Gain<MonoToStereo<FramesSignal>> (general path) FAST {gen_fast:8.4f} ms  ORDERED {gen_ord:8.4f} ms", flush=True)
         sc = synth.make_scene(3, S)
         scontrol, scene = oa.SpatialScene(max_sources=S, max_frames=1024)
         scontrol.play_frames_batch([frames[int(k)] for k in pick], np.full(S, 0.25), sc["position"], sc["velocity"], sc["radius"])
