@@ -344,6 +344,34 @@ __global__ __launch_bounds__(1024) void mixer_reduce(const float* __restrict__ p
     }
 }
 
+// ORDERED mode of the general path above the serial threshold (round 4): the slabs ([slot][frame][channels of the leaf]) re-laid as
+// the rows ordered_sum reads ([group of 16 sources][ear][16-frame column block][source][16 frames]); a mono slab feeds both ears
+// (MonoToStereo, signal.rs:73-80), a stopped source leaves rows of zeros.  One thread per (source, column block).
+__global__ __launch_bounds__(256) void mixer_general_rows(const float* __restrict__ slabs, const uint32_t* __restrict__ skip,
+                                                          const BufStatic* __restrict__ st, uint32_t n_sources, uint32_t n_frames,
+                                                          float* __restrict__ rows, uint32_t rows_ncb) {
+    const uint32_t slot = blockIdx.y, cb = blockIdx.x * blockDim.x + threadIdx.x;
+    if (slot >= n_sources || cb * 16u >= n_frames) return;
+    const uint32_t C = st[slot].channels == 2u ? 2u : 1u;
+    const bool live = skip[slot] == 0u;
+    const float* my = slabs + (size_t)slot * 2 * n_frames + (size_t)cb * 16u * C;
+    float l[16], r[16];
+#pragma unroll
+    for (int f = 0; f < 16; ++f) {
+        const bool in = live && cb * 16u + (uint32_t)f < n_frames;
+        l[f] = in ? my[(uint32_t)f * C] : 0.0f;
+        r[f] = in ? my[(uint32_t)f * C + (C - 1u)] : 0.0f;
+    }
+    unsigned char* p = reinterpret_cast<unsigned char*>(rows) + (size_t)(slot >> 4) * (2u * (size_t)rows_ncb * 1024u) + (size_t)cb * 1024u + (size_t)(slot & 15u) * 64u;
+    float4* d0 = reinterpret_cast<float4*>(p);
+    float4* d1 = reinterpret_cast<float4*>(p + (size_t)rows_ncb * 1024u);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        d0[q] = make_float4(l[4 * q], l[4 * q + 1], l[4 * q + 2], l[4 * q + 3]);
+        d1[q] = make_float4(r[4 * q], r[4 * q + 1], r[4 * q + 2], r[4 * q + 3]);
+    }
+}
+
 // ---- general path: any leaf (FramesSignal mono/stereo, Sine, Constant, Cycle, Stream) inside any chain of
 // FixedGain / Gain / Speed filters, optionally inside a Fader.  One wave per source replays Mixer::sample's per-source
 // work (mixer.rs:100-117) through the filter chain into the source's own slab (inner_sample_wave / fader_sample_wave,
