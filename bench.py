@@ -422,6 +422,42 @@ def buffered_cpu_and_parity(device: int, seed: int, budget_s: float) -> tuple[di
     return cpu, parity
 
 
+def bench_mixer(device: int, frames_bank) -> dict:
+    """The Mixer leg (mixer.rs is on the north_star's path; BASELINE configs[0] is a Mixer): host-output callbacks (the Mixer has no
+    device-output entry point), a few of each, reported only.  `frames_bank`: Frames of the Seek workload's clips."""
+    import oddio_amd as oa
+    interval = np.float32(1.0) / np.float32(RATE)
+
+    def timed(sig, reps, warm):
+        for _ in range(warm):
+            sig.sample_n(interval, N_FRAMES)
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            sig.sample_n(interval, N_FRAMES)
+        return (time.perf_counter() - t0) / reps * 1e3
+
+    out = {"frames_per_callback": N_FRAMES, "boundary": "oddio_hip_mixer_sample (host slice: stream sync + D2H per callback)"}
+    # BASELINE configs[0]: 64 static Sine sources into one Mixer (examples/offline.rs style)
+    control, mixer = oa.Mixer(device=device, max_sources=64, max_frames=N_FRAMES)
+    for k in range(64):
+        control.play(oa.MonoToStereo(oa.Sine(0.1 * k, float(110.0 * 2.0 ** (k / 12.0)))))
+    out["config0_64_sines_ms_per_callback"] = timed(mixer, 24, 8)
+    mixer.close()
+    # a large Mixer<[f32;2]> of MonoToStereo<FramesSignal> sources, FAST and ORDERED (the reference's reverse slot order: bit-exact,
+    # tests/test_hip_mixer.py)
+    S = min(65536, len(frames_bank) * 16)
+    control, mixer = oa.Mixer(device=device, max_sources=S, max_frames=N_FRAMES)
+    for i in range(S):
+        control.play(oa.MonoToStereo(oa.FramesSignal(frames_bank[(i * 2654435761) % len(frames_bank)], 0.25)))
+    fast = timed(mixer, 16, 8)
+    mixer.set_mode(oa.MODE_ORDERED)
+    ordered = timed(mixer, 8, 3)
+    mixer.close()
+    out.update({"sources": S, "fast_ms_per_callback": fast, "ordered_ms_per_callback": ordered,
+                "fast_source_frames_per_s": float(S) * N_FRAMES / (fast * 1e-3), "ordered_source_frames_per_s": float(S) * N_FRAMES / (ordered * 1e-3)})
+    return out
+
+
 def bench_buffered(args, device: int, shared=None) -> dict:
     """One SpatialScene whose sources are all played with play_buffered as Gain<Speed<FramesSignal>>: own clip each, speeds in
     [0.9, 1.1], a new gain target for every source before every 4th callback (so that every Gain is always ramping).
@@ -653,7 +689,7 @@ def main():
     ap.add_argument("--workload", choices=["seek", "buffered"], default="seek",
                     help="'seek' (default): BASELINE's FramesSignal sources played with play(); 'buffered': the same number of "
                          "Gain<Speed<FramesSignal>> sources played with play_buffered (single GPU)")
-    ap.add_argument("--no-buffered", action="store_true", help="skip the nested buffered_path line of the default (seek) workload")
+    ap.add_argument("--no-buffered", action="store_true", help="skip the nested buffered_path and mixer_path objects of the default (seek) workload")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-worker", default=None, help=argparse.SUPPRESS)
     ap.add_argument("--cpu-budget", type=float, default=20.0)
@@ -960,6 +996,8 @@ def main():
         if world == 1 and not args.no_buffered:
             # the path Gain / Speed sources take into a scene (play_buffered), same source count, same clips: its own line, nested
             line["buffered_path"] = bench_buffered(args, device, shared={"clips": g["clips"], "frames": g["frames"]})
+        if world == 1 and not args.no_buffered:
+            line["mixer_path"] = bench_mixer(device, g["frames"])
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args.seed, args.cpu_budget, parity_device=device, parity_sources=S)
             line["parity"] = line["cpu_baseline"].pop("parity")
