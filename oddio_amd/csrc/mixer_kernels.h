@@ -47,8 +47,10 @@ constexpr int MIXER_WIN_PAD = MIXER_WIN_CAP + MIXER_WIN_CAP / 16 + 16;
 constexpr int MIXER_CKPT_STRIDE = 65;
 constexpr int MIXER_WIN_VECS = (MIXER_WIN_CAP / 4 + 63) / 64;   // 16-byte vectors per lane that cover the largest staged window
 
+constexpr int MIXER_SUB = 16;                  // sources whose cursor checkpoints are in LDS at a time (round 4: 64 -> 16.6 KB of the 24.7 a wave
+                                               // took, six waves per CU; with 16 a wave takes 12.3 KB and the registers decide: twelve)
 struct MixerLds {
-    float ckpt[64 * MIXER_CKPT_STRIDE];   // [phase-A lane = source][64 checkpoints]
+    float ckpt[MIXER_SUB * MIXER_CKPT_STRIDE];   // [source of the batch][64 checkpoints]
     int cinfo[64 * 4];                    // per source: {wrel, frac bits, fast, path}
     int sinfo[64 * 2];                    // per source: {ws, count}
     float win[MIXER_WIN_PAD];
@@ -111,31 +113,21 @@ __global__ __launch_bounds__(64) void mixer_mix(uint32_t n_sources, uint32_t n_f
         } else if (live && ss.kind == KIND_SINE) {
             for (uint32_t cc = 0; cc < tile; ++cc) ph = fmodf(ph + (interval * 1024.0f) * ss.freq_or_value, ODDIO_TAU);
         }
-        float x = frac0;
-        {
-            float* ck = &L.ckpt[lane * MIXER_CKPT_STRIDE];
-#pragma unroll 1
-            for (int b = 0; b < 63; ++b) {
-                ck[b] = x;
-#pragma unroll
-                for (int i = 0; i < 16; ++i) x = x + ds;
-            }
-            ck[63] = x;
-#pragma unroll
-            for (int i = 0; i < 15; ++i) x = x + ds;   // offset at frame 1023
-        }
         if (live) {
             if (ss.kind == KIND_SINE) path = PATH_SINE;
             else if (ss.kind == KIND_CONSTANT) path = PATH_CONST;
             else {
-                int i0, i1;
-                if (fast) { i0 = wbase; i1 = wbase + 1023; }
+                // the window only has to contain every index the 1024 sequentially rounded `offset += ds` steps can reach: the
+                // cursor at frame 1023 is within 1023 half-ulps of its own magnitude (6.1e-5 relative) of the closed form
+                int lo, hi;
+                if (fast) { lo = wbase; hi = wbase + 1023; }
                 else {
-                    if (!(fabsf(x) < 8.0e6f)) generic = 1;
-                    i0 = wbase + (int)frac0;
-                    i1 = wbase + (int)x;
+                    const float xb = frac0 + 1023.0f * ds;
+                    const float m = fabsf(xb) * 1.0e-4f + 1.0e-2f;
+                    if (!(fabsf(xb) < 8.0e6f)) generic = 1;
+                    lo = wbase + (int)floorf(fminf(frac0, xb - m));
+                    hi = wbase + (int)ceilf(fmaxf(frac0, xb + m));
                 }
-                const int lo = i0 < i1 ? i0 : i1, hi = i0 < i1 ? i1 : i0;
                 ws = lo & ~3;
                 count = hi + 2 - ws;
                 path = (generic || count > MIXER_WIN_CAP) ? PATH_GENERIC : PATH_LDS;
@@ -185,6 +177,23 @@ __global__ __launch_bounds__(64) void mixer_mix(uint32_t n_sources, uint32_t n_f
         }
 #pragma unroll 1
         for (int j = j_hi - 1; j >= j_lo; --j) {
+            if (j == j_hi - 1 || (j & (MIXER_SUB - 1)) == MIXER_SUB - 1) {
+                // a new batch of 16 sources: the exact f32 cursor scan (frames.rs:189-196) of each, by the lane that holds its
+                // parameters, a checkpoint every 16 frames
+                wave_sync();
+                if ((lane / MIXER_SUB) == (j / MIXER_SUB)) {
+                    float x = frac0;
+                    float* ck = &L.ckpt[(lane & (MIXER_SUB - 1)) * MIXER_CKPT_STRIDE];
+#pragma unroll 1
+                    for (int b = 0; b < 63; ++b) {
+                        ck[b] = x;
+#pragma unroll
+                        for (int i = 0; i < 16; ++i) x = x + ds;
+                    }
+                    ck[63] = x;
+                }
+                wave_sync();
+            }
             const int path_j = __builtin_amdgcn_readfirstlane(L.cinfo[j * 4 + 3]);
             if (STORE) {
                 // the previous source's row is out; this one starts from zero (a skipped source leaves a row of zeros: x + 0.0 == x
@@ -226,7 +235,7 @@ __global__ __launch_bounds__(64) void mixer_mix(uint32_t n_sources, uint32_t n_f
                             a = bb;
                         }
                     } else {
-                        float xx = L.ckpt[j * MIXER_CKPT_STRIDE + lane];
+                        float xx = L.ckpt[(j & (MIXER_SUB - 1)) * MIXER_CKPT_STRIDE + lane];
 #pragma unroll
                         for (int i = 0; i < 16; ++i) {
                             const int tr = (int)xx;
