@@ -388,9 +388,10 @@ int oddio_hip_mixer_play_constant(oddio_hip_mixer* mixer, float value, uint32_t*
 /* MixerControl::play of any supported signal: leaf (ODDIO_HIP_LEAF_*, arguments as above; mono
  * leaves are implicitly MonoToStereo'd, stereo clips play as is) inside up to 4 filters, innermost
  * first (FixedGain / Gain / Speed; see oddio_hip_filter).  A mixer that has ever been given a Gain,
- * Speed, Cycle, a stereo clip or more than one filter renders through the general (one wavefront per
- * source) path from then on (65 536 Gain<MonoToStereo<FramesSignal>> sources: 1.5 ms per 1024-frame callback, 1.1 in ORDERED
- * mode; its per-source slabs take 8 bytes per source and frame of max_frames). */
+ * Speed, Cycle, a stereo clip or more than one filter renders through the general path from then on: chains over a mono
+ * FramesSignal 16 sources per wavefront, every other shape one wavefront per source, a slab per source (8 bytes per source and
+ * frame of max_frames) summed afterwards (65 536 Gain<MonoToStereo<FramesSignal>> sources: 0.28 ms per 1024-frame callback,
+ * 0.64 in ORDERED mode). */
 int oddio_hip_mixer_play_chain(oddio_hip_mixer* mixer, int leaf_kind, oddio_hip_frames* frames,
                                double start_seconds, float phase, float frequency_hz_or_value,
                                const oddio_hip_filter* filters, int n_filters, uint32_t* source_id);

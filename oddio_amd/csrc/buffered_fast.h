@@ -170,6 +170,119 @@ __device__ __forceinline__ bool ring_tile_rec(TileRec& r, const SceneParams& P, 
     return true;
 }
 
+// The record of one Ring::write-shaped render through the filter chain (what buffered_write consumes): `cnt1` (+ `cnt2` after the
+// ring's end when `seg2`) frames from `start_idx` on, each segment one inner.sample call at `interval` seconds per frame at the top
+// of the chain.  Works on copies of the Smoothed state (`sm_*`) and of the leaf clock (`t_new`): the caller commits them if the
+// result is true, and leaves the source to the general kernel otherwise.  Shared by the scene's buffered set (buffered_walk) and the
+// Mixer's chain sources (mixer_chain_walk, mixer_kernels.h), whose "ring" is the source's slab.
+__device__ __forceinline__ bool chain_write_rec(WriteRec& wr, uint32_t* bounds_err, const BufStatic& s, const BufDyn& d, const SrcDyn& c, float interval,
+                                                uint32_t cnt1, uint32_t cnt2, bool seg2, size_t start_idx, float* ring, uint32_t rlen, uint32_t src_index,
+                                                bool fast, double& t_new, float (&sm_prev)[MAX_WRAP], float (&sm_next)[MAX_WRAP], float (&sm_prog)[MAX_WRAP]) {
+    // the chain: interval per level (speed.rs:32-35), Smoothed::set (gain.rs:106-109) -- on copies; committed only if fast
+    uint32_t ops = s.n_wrap & 7u;
+    t_new = c.t;
+    if (fast) {
+        float level_interval[MAX_WRAP];
+        float cur = interval;
+#pragma unroll
+        for (int w = MAX_WRAP - 1; w >= 0; --w) {
+            level_interval[w] = cur;
+            if ((uint32_t)w < s.n_wrap && s.wrap_kind[w] == WRAP_SPEED) cur = cur * d.shared[w];
+        }
+        int n_ramp = 0;
+#pragma unroll
+        for (uint32_t w = 0; w < MAX_WRAP; ++w) {
+            sm_prev[w] = d.sm_prev[w]; sm_next[w] = d.sm_next[w]; sm_prog[w] = d.sm_progress[w];
+            wr.c[w] = 1.0f;
+            if (w >= s.n_wrap) continue;
+            if (s.wrap_kind[w] == WRAP_FIXED_GAIN) wr.c[w] = s.wrap_param[w];                  // gain.rs:32-37
+            else if (s.wrap_kind[w] == WRAP_GAIN) {
+                const float shared = d.shared[w];
+                if (sm_next[w] != shared) {
+                    sm_prev[w] = sm_prev[w] + sm_prog[w] * (sm_next[w] - sm_prev[w]);
+                    sm_next[w] = shared;
+                    sm_prog[w] = 0.0f;
+                }
+                if (sm_prog[w] != 1.0f) {                                                       // a running ramp (gain.rs:114-120)
+                    const float step = level_interval[w] / 0.1f;                                 // SMOOTHING_PERIOD, gain.rs:163
+                    if (n_ramp == 0) {   // (no array indexed by n_ramp: that would put the record in scratch memory)
+                        wr.rprev[0] = sm_prev[w]; wr.rnext[0] = sm_next[w]; wr.rp0[0] = sm_prog[w]; wr.rstep[0] = step;
+                        ops |= 1u << (4 + 2 * w);
+                        ops |= w << 12;
+                    } else if (n_ramp == 1) {
+                        wr.rprev[1] = sm_prev[w]; wr.rnext[1] = sm_next[w]; wr.rp0[1] = sm_prog[w]; wr.rstep[1] = step;
+                        ops |= 2u << (4 + 2 * w);
+                        ops |= w << 14;
+                    }
+                    n_ramp++;
+                } else {
+                    wr.c[w] = sm_prev[w] + sm_prog[w] * (sm_next[w] - sm_prev[w]);               // gain.rs:110-113 (x * 1.0 == x: no need to skip)
+                }
+            }
+        }
+        if (n_ramp > 2) fast = false;
+        // leaf: frames.rs:176-181 per inner.sample call
+        const float ds = cur * (float)s.clip_rate;
+        if (!(ds > 0.0f) || !(ds < 64.0f)) fast = false;
+        const bool leaf_fast = fabsf(ds - 1.0f) <= FLT_EPSILON;
+        int lo = 0x7fffffff, hi = (int)0x80000000;
+        int base_s[2] = {0, 0};
+        const uint32_t cnts[2] = {cnt1, cnt2};
+#pragma unroll
+        for (int sg = 0; sg < 2; ++sg) {
+            if (sg == 1 && !seg2) break;
+            const double s0 = t_new * (double)s.clip_rate;
+            const long long base = f64_as_isize(s0);
+            const float frac0 = (float)(s0 - (double)base);
+            if (!(fabs(s0) < 1.0e9)) fast = false;
+            base_s[sg] = (int)base;
+            wr.frac0[sg] = frac0;
+            if (cnts[sg] > 0 && fast) {
+                int i0, i1;
+                if (leaf_fast) { i0 = (int)base; i1 = (int)base + (int)cnts[sg] - 1; }
+                else {
+                    const float xb = frac0 + (float)(cnts[sg] - 1u) * ds;
+                    const float xu = xb + fabsf(xb) * 1.0e-4f + 1.0e-2f;
+                    if (!(xu < 8.0e6f)) fast = false;
+                    i0 = (int)base + (int)frac0;
+                    i1 = (int)base + (int)xu;
+                }
+                lo = min(lo, i0); hi = max(hi, i1);
+            }
+            t_new = t_new + (double)cur * (double)cnts[sg];                                      // frames.rs:198
+        }
+        if (fast) {
+            const int ws = lo & ~3;
+            const int count = hi + 2 - ws;
+            const int nvec = (count + 3) >> 2;
+            uint32_t fl = 0;
+            if (leaf_fast) fl |= BWF_LEAF_FAST;
+            if (seg2) fl |= BWF_SEG2;
+            if (seg2 || start_idx < RING_MIRROR || cnt1 + cnt2 != BW_FRAMES) fl |= BWF_SPECIAL;
+            if (fabsf(ds - 1.0f) < PAD_EPS) {
+                if (nvec * 4 + (nvec * 4 >> 4) + 1 <= BW_WIN_CAP) fl |= BWF_PAD;
+                else if (leaf_fast) fast = false;         // the constant-fract loop exists for the padded layout only
+            }
+            if (count < 2 || nvec * 4 > BW_WIN_CAP) fast = false;
+            if (fast) {
+                const int4 dd = window_desc(s.clip, (int)((s.clip_len + 3u) & ~3u), ws, nvec);
+                const int negvec = (dd.z > 0) ? ((-dd.w) >> 4) : 0;
+                if (negvec > 255) fast = false;
+                wr.desc[0] = (uint32_t)dd.x; wr.desc[1] = (uint32_t)dd.y; wr.desc[2] = (uint32_t)dd.z;
+                wr.info = BW_FAST | fl | ((uint32_t)nvec << 8) | ((uint32_t)negvec << 20);
+                wr.ring = ring; wr.ring_len = rlen; wr.start_idx = (uint32_t)start_idx;
+                wr.ds = ds;
+                (void)ODDIO_BOUNDS_CHECK(bounds_err, nvec >= 1 && nvec * 4 <= BW_WIN_CAP && base_s[0] - ws >= 0 && base_s[0] - ws < count &&
+                                         (!seg2 || (base_s[1] - ws >= 0 && base_s[1] - ws < count)) && dd.z >= 0 && dd.z <= nvec * 16, BOUNDS_RECORD, nvec, src_index);
+                wr.wrel = (uint32_t)(base_s[0] - ws) | ((uint32_t)((seg2 ? base_s[1] : base_s[0]) - ws) << 16);
+                wr.cnt = cnt1 | ((cnt1 + cnt2) << 16);
+                wr.ops = ops;
+            }
+        }
+    }
+    return fast;
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // buffered_walk: one thread per slot of the buffered set
 // ---------------------------------------------------------------------------------------------------------------
@@ -274,110 +387,9 @@ __global__ __launch_bounds__(128) void buffered_walk(SceneParams P, const BufSta
                 else fast = false;
                 if (cnt1 + cnt2 < 1u || cnt1 + cnt2 > BW_FRAMES || cnt1 > BW_FRAMES) fast = false;
             }
-            // the chain: interval per level (speed.rs:32-35), Smoothed::set (gain.rs:106-109) -- on copies; committed only if fast
             float sm_prev[MAX_WRAP], sm_next[MAX_WRAP], sm_prog[MAX_WRAP];
-            uint32_t ops = s.n_wrap & 7u;
             double t_new = c.t;
-            if (fast) {
-                const float interval = 1.0f / (float)s.rate;
-                float level_interval[MAX_WRAP];
-                float cur = interval;
-#pragma unroll
-                for (int w = MAX_WRAP - 1; w >= 0; --w) {
-                    level_interval[w] = cur;
-                    if ((uint32_t)w < s.n_wrap && s.wrap_kind[w] == WRAP_SPEED) cur = cur * d.shared[w];
-                }
-                int n_ramp = 0;
-#pragma unroll
-                for (uint32_t w = 0; w < MAX_WRAP; ++w) {
-                    sm_prev[w] = d.sm_prev[w]; sm_next[w] = d.sm_next[w]; sm_prog[w] = d.sm_progress[w];
-                    wr.c[w] = 1.0f;
-                    if (w >= s.n_wrap) continue;
-                    if (s.wrap_kind[w] == WRAP_FIXED_GAIN) wr.c[w] = s.wrap_param[w];                  // gain.rs:32-37
-                    else if (s.wrap_kind[w] == WRAP_GAIN) {
-                        const float shared = d.shared[w];
-                        if (sm_next[w] != shared) {
-                            sm_prev[w] = sm_prev[w] + sm_prog[w] * (sm_next[w] - sm_prev[w]);
-                            sm_next[w] = shared;
-                            sm_prog[w] = 0.0f;
-                        }
-                        if (sm_prog[w] != 1.0f) {                                                       // a running ramp (gain.rs:114-120)
-                            const float step = level_interval[w] / 0.1f;                                 // SMOOTHING_PERIOD, gain.rs:163
-                            if (n_ramp == 0) {   // (no array indexed by n_ramp: that would put the record in scratch memory)
-                                wr.rprev[0] = sm_prev[w]; wr.rnext[0] = sm_next[w]; wr.rp0[0] = sm_prog[w]; wr.rstep[0] = step;
-                                ops |= 1u << (4 + 2 * w);
-                                ops |= w << 12;
-                            } else if (n_ramp == 1) {
-                                wr.rprev[1] = sm_prev[w]; wr.rnext[1] = sm_next[w]; wr.rp0[1] = sm_prog[w]; wr.rstep[1] = step;
-                                ops |= 2u << (4 + 2 * w);
-                                ops |= w << 14;
-                            }
-                            n_ramp++;
-                        } else {
-                            wr.c[w] = sm_prev[w] + sm_prog[w] * (sm_next[w] - sm_prev[w]);               // gain.rs:110-113 (x * 1.0 == x: no need to skip)
-                        }
-                    }
-                }
-                if (n_ramp > 2) fast = false;
-                // leaf: frames.rs:176-181 per inner.sample call
-                const float ds = cur * (float)s.clip_rate;
-                if (!(ds > 0.0f) || !(ds < 64.0f)) fast = false;
-                const bool leaf_fast = fabsf(ds - 1.0f) <= FLT_EPSILON;
-                int lo = 0x7fffffff, hi = (int)0x80000000;
-                int base_s[2] = {0, 0};
-                const uint32_t cnts[2] = {cnt1, cnt2};
-#pragma unroll
-                for (int sg = 0; sg < 2; ++sg) {
-                    if (sg == 1 && !seg2) break;
-                    const double s0 = t_new * (double)s.clip_rate;
-                    const long long base = f64_as_isize(s0);
-                    const float frac0 = (float)(s0 - (double)base);
-                    if (!(fabs(s0) < 1.0e9)) fast = false;
-                    base_s[sg] = (int)base;
-                    wr.frac0[sg] = frac0;
-                    if (cnts[sg] > 0 && fast) {
-                        int i0, i1;
-                        if (leaf_fast) { i0 = (int)base; i1 = (int)base + (int)cnts[sg] - 1; }
-                        else {
-                            const float xb = frac0 + (float)(cnts[sg] - 1u) * ds;
-                            const float xu = xb + fabsf(xb) * 1.0e-4f + 1.0e-2f;
-                            if (!(xu < 8.0e6f)) fast = false;
-                            i0 = (int)base + (int)frac0;
-                            i1 = (int)base + (int)xu;
-                        }
-                        lo = min(lo, i0); hi = max(hi, i1);
-                    }
-                    t_new = t_new + (double)cur * (double)cnts[sg];                                      // frames.rs:198
-                }
-                if (fast) {
-                    const int ws = lo & ~3;
-                    const int count = hi + 2 - ws;
-                    const int nvec = (count + 3) >> 2;
-                    uint32_t fl = 0;
-                    if (leaf_fast) fl |= BWF_LEAF_FAST;
-                    if (seg2) fl |= BWF_SEG2;
-                    if (seg2 || start_idx < RING_MIRROR || cnt1 + cnt2 != BW_FRAMES) fl |= BWF_SPECIAL;
-                    if (fabsf(ds - 1.0f) < PAD_EPS) {
-                        if (nvec * 4 + (nvec * 4 >> 4) + 1 <= BW_WIN_CAP) fl |= BWF_PAD;
-                        else if (leaf_fast) fast = false;         // the constant-fract loop exists for the padded layout only
-                    }
-                    if (count < 2 || nvec * 4 > BW_WIN_CAP) fast = false;
-                    if (fast) {
-                        const int4 dd = window_desc(s.clip, (int)((s.clip_len + 3u) & ~3u), ws, nvec);
-                        const int negvec = (dd.z > 0) ? ((-dd.w) >> 4) : 0;
-                        if (negvec > 255) fast = false;
-                        wr.desc[0] = (uint32_t)dd.x; wr.desc[1] = (uint32_t)dd.y; wr.desc[2] = (uint32_t)dd.z;
-                        wr.info = BW_FAST | fl | ((uint32_t)nvec << 8) | ((uint32_t)negvec << 20);
-                        wr.ring = s.ring; wr.ring_len = rlen; wr.start_idx = (uint32_t)start_idx;
-                        wr.ds = ds;
-                        (void)ODDIO_BOUNDS_CHECK(P.bounds_err, nvec >= 1 && nvec * 4 <= BW_WIN_CAP && base_s[0] - ws >= 0 && base_s[0] - ws < count &&
-                                                 (!seg2 || (base_s[1] - ws >= 0 && base_s[1] - ws < count)) && dd.z >= 0 && dd.z <= nvec * 16, BOUNDS_RECORD, nvec, i);
-                        wr.wrel = (uint32_t)(base_s[0] - ws) | ((uint32_t)((seg2 ? base_s[1] : base_s[0]) - ws) << 16);
-                        wr.cnt = cnt1 | ((cnt1 + cnt2) << 16);
-                        wr.ops = ops;
-                    }
-                }
-            }
+            fast = chain_write_rec(wr, P.bounds_err, s, d, c, 1.0f / (float)s.rate, cnt1, cnt2, seg2, start_idx, s.ring, rlen, i, fast, t_new, sm_prev, sm_next, sm_prog);
             // the ring reads of this callback start from the cursor Ring::write leaves (ring.rs:40)
             if (fast) {
 #pragma unroll

@@ -4,6 +4,7 @@
 #pragma once
 #include "kernels.h"
 #include "buffered_kernels.h"
+#include "buffered_fast.h"
 
 namespace oddio_hip {
 
@@ -355,30 +356,80 @@ __global__ __launch_bounds__(1024) void mixer_reduce(const float* __restrict__ p
 
 // ORDERED mode of the general path above the serial threshold (round 4): the slabs ([slot][frame][channels of the leaf]) re-laid as
 // the rows ordered_sum reads ([group of 16 sources][ear][16-frame column block][source][16 frames]); a mono slab feeds both ears
-// (MonoToStereo, signal.rs:73-80), a stopped source leaves rows of zeros.  One thread per (source, column block).
-__global__ __launch_bounds__(256) void mixer_general_rows(const float* __restrict__ slabs, const uint32_t* __restrict__ skip,
-                                                          const BufStatic* __restrict__ st, uint32_t n_sources, uint32_t n_frames,
-                                                          float* __restrict__ rows, uint32_t rows_ncb) {
-    const uint32_t slot = blockIdx.y, cb = blockIdx.x * blockDim.x + threadIdx.x;
-    if (slot >= n_sources || cb * 16u >= n_frames) return;
-    const uint32_t C = st[slot].channels == 2u ? 2u : 1u;
-    const bool live = skip[slot] == 0u;
-    const float* my = slabs + (size_t)slot * 2 * n_frames + (size_t)cb * 16u * C;
-    float l[16], r[16];
+// (MonoToStereo, signal.rs:73-80), a stopped source leaves rows of zeros.  One wavefront per (group of 16 sources, 8 column blocks):
+// lane (j, q) moves the 16-byte piece q of source j's row -- the 16 rows of a (group, ear, column block) leave as one contiguous KiB
+// (one thread per (source, column block), 64 bytes at a 1-KiB stride each, took 0.41 ms for 65 536 sources; this 0.15).
+__global__ __launch_bounds__(64) void mixer_general_rows(const float* __restrict__ slabs, const uint32_t* __restrict__ skip,
+                                                         const BufStatic* __restrict__ st, uint32_t n_sources, uint32_t n_frames,
+                                                         float* __restrict__ rows, uint32_t rows_ncb) {
+    const uint32_t G = blockIdx.y, lane = threadIdx.x, j = lane >> 2, q = lane & 3u;
+    const uint32_t slot = G * 16u + j;
+    const bool valid = slot < n_sources;
+    const uint32_t C = valid && st[slot].channels == 2u ? 2u : 1u;
+    const bool live = valid && skip[slot] == 0u;
+    const float* my = slabs + (size_t)slot * 2 * n_frames;
+    unsigned char* gbase = reinterpret_cast<unsigned char*>(rows) + (size_t)G * (2u * (size_t)rows_ncb * 1024u) + (size_t)lane * 16u;
+    const uint32_t ncb_used = (n_frames + 15u) / 16u;
+#pragma unroll 2
+    for (uint32_t k = 0; k < 8u; ++k) {
+        const uint32_t cb = blockIdx.x * 8u + k;
+        if (cb >= ncb_used) break;
+        const uint32_t f0 = cb * 16u + 4u * q;                       // this lane's four frames
+        float l[4] = {0.f, 0.f, 0.f, 0.f}, r[4] = {0.f, 0.f, 0.f, 0.f};
+        if (live) {
 #pragma unroll
-    for (int f = 0; f < 16; ++f) {
-        const bool in = live && cb * 16u + (uint32_t)f < n_frames;
-        l[f] = in ? my[(uint32_t)f * C] : 0.0f;
-        r[f] = in ? my[(uint32_t)f * C + (C - 1u)] : 0.0f;
+            for (int t = 0; t < 4; ++t) {
+                const uint32_t f = f0 + (uint32_t)t;
+                if (f < n_frames) { l[t] = my[(size_t)f * C]; r[t] = my[(size_t)f * C + (C - 1u)]; }
+            }
+        }
+        *reinterpret_cast<float4*>(gbase + (size_t)cb * 1024u) = make_float4(l[0], l[1], l[2], l[3]);
+        *reinterpret_cast<float4*>(gbase + ((size_t)rows_ncb + cb) * 1024u) = make_float4(r[0], r[1], r[2], r[3]);
     }
-    unsigned char* p = reinterpret_cast<unsigned char*>(rows) + (size_t)(slot >> 4) * (2u * (size_t)rows_ncb * 1024u) + (size_t)cb * 1024u + (size_t)(slot & 15u) * 64u;
-    float4* d0 = reinterpret_cast<float4*>(p);
-    float4* d1 = reinterpret_cast<float4*>(p + (size_t)rows_ncb * 1024u);
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        d0[q] = make_float4(l[4 * q], l[4 * q + 1], l[4 * q + 2], l[4 * q + 3]);
-        d1[q] = make_float4(r[4 * q], r[4 * q + 1], r[4 * q + 2], r[4 * q + 3]);
+}
+
+// FAST mode of the general path (round 4): the slab sum as a tree of row sums.  A workgroup adds `per` consecutive rows (slabs: a mono
+// slab feeds both channels, a stopped source is skipped; or partial sums of an earlier stage) into one row of `out`; three stages
+// of 64 take 262 144 slabs to one row, in a fixed order, every slab read once with whole-row (4 - 8 KiB) accesses.  (The tiled sum
+// above reads 256-byte pieces of each slab from 16 x n_out / 64 workgroups: 0.94 ms for 65 536 sources.)
+template <bool SLABS>
+__global__ __launch_bounds__(64) void mixer_sum_rows(const float* __restrict__ in, size_t in_stride, const uint32_t* __restrict__ skip,
+                                                     const BufStatic* __restrict__ st, uint32_t n_rows, uint32_t per, uint32_t n_out,
+                                                     float* __restrict__ out, int postfx, int apply_postfx) {
+    // grid = (chunks of `per` rows, quads of 64 output columns): one wavefront, four consecutive outputs per lane
+    const uint32_t lo = blockIdx.x * per;
+    const uint32_t hi = lo + per < n_rows ? lo + per : n_rows;
+    const uint32_t o = 256u * blockIdx.y + 4u * threadIdx.x;
+    if (o >= n_out) return;                                             // n_out is even: a lane's quad is whole or half
+    const bool whole = o + 3u < n_out;
+    auto fetch = [&](uint32_t r) -> float4 {
+        const float* row = in + (size_t)r * in_stride;
+        if (SLABS) {
+            if (skip[r]) return make_float4(0.f, 0.f, 0.f, 0.f);          // (x + 0.0 == x: the running sums are never -0.0)
+            if (st[r].channels != 2u) {                                   // a mono slab feeds both channels (signal.rs:73-80)
+                const float a = row[o >> 1], b = whole ? row[(o >> 1) + 1u] : 0.f;
+                return make_float4(a, a, b, b);
+            }
+        }
+        if (whole) { const f4u t = *reinterpret_cast<const f4u*>(row + o); return make_float4(t.x, t.y, t.z, t.w); }   // (rows of an odd frame count are 8-byte aligned only)
+        return make_float4(row[o], row[o + 1], 0.f, 0.f);
+    };
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    uint32_t r = hi;
+    while (r >= lo + 4u) {                                              // four rows' loads in flight, added in descending row order
+        const float4 v0 = fetch(r - 1u), v1 = fetch(r - 2u), v2 = fetch(r - 3u), v3 = fetch(r - 4u);
+        acc.x = ((((acc.x + v0.x) + v1.x) + v2.x) + v3.x); acc.y = ((((acc.y + v0.y) + v1.y) + v2.y) + v3.y);
+        acc.z = ((((acc.z + v0.z) + v1.z) + v2.z) + v3.z); acc.w = ((((acc.w + v0.w) + v1.w) + v2.w) + v3.w);
+        r -= 4u;
     }
+    while (r > lo) {
+        const float4 v = fetch(--r);
+        acc.x = acc.x + v.x; acc.y = acc.y + v.y; acc.z = acc.z + v.z; acc.w = acc.w + v.w;
+    }
+    float* dst = out + (size_t)blockIdx.x * n_out + o;
+    if (apply_postfx) { acc.x = postfx_apply(acc.x, postfx); acc.y = postfx_apply(acc.y, postfx); acc.z = postfx_apply(acc.z, postfx); acc.w = postfx_apply(acc.w, postfx); }
+    dst[0] = acc.x; dst[1] = acc.y;
+    if (whole) { dst[2] = acc.z; dst[3] = acc.w; }
 }
 
 // ---- general path: any leaf (FramesSignal mono/stereo, Sine, Constant, Cycle, Stream) inside any chain of
@@ -386,15 +437,64 @@ __global__ __launch_bounds__(256) void mixer_general_rows(const float* __restric
 // work (mixer.rs:100-117) through the filter chain into the source's own slab (inner_sample_wave / fader_sample_wave,
 // buffered_kernels.h); mixer_general_reduce then adds the slabs in reverse slot order (bit-identical sum order).
 // One wave per general-path source: every shape the ABI accepts (mono or stereo leaf under any filter chain, Fader).
+// Round 4: the CHAIN sources of the general set -- a mono FramesSignal under FixedGain / Gain / Speed filters, no Fader
+// (BufStatic::flags & BUF_FAST_OK), in callbacks of 1 .. 1024 frames (one Mixer staging chunk, mixer.rs:77,109-117) -- are rendered
+// by buffered_write (buffered_fast.h: 16 sources per wavefront, the exact running sums scanned one stream per lane) instead of one
+// wavefront per source: the source's slab plays the ring, written from index RING_MIRROR of a ring that starts RING_MIRROR floats
+// before the slab (so that no store is a mirror store, and a full chunk leaves as whole kilobytes).  This kernel is the walk for
+// them, one thread per slot: mixer.rs:100-106's stopped / finished scan, then the record (chain_write_rec), the Smoothed::set and
+// clock commits.  Every other source, and a chain source buffered_write cannot take this callback (three Gains ramping at once, a
+// resample ratio out of range), is marked BW_SLOW and left -- stop logic included -- to mixer_general_sources_wave.
+__global__ __launch_bounds__(128) void mixer_chain_walk(uint32_t n_sources, uint32_t n_frames, float interval, const BufStatic* __restrict__ st,
+                                                        BufDyn* __restrict__ dyn, WriteRec* __restrict__ wrecs, float* __restrict__ slabs,
+                                                        uint32_t* __restrict__ skip, uint32_t* __restrict__ stopped_hdr, uint32_t stopped_cap,
+                                                        uint32_t* __restrict__ bounds_err) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_sources) return;
+    const BufStatic s = st[i];
+    WriteRec wr = {};                                   // info == BW_SKIP: nothing to render
+    if (!(s.flags & BUF_FAST_OK) || s.fader || s.kind != KIND_FRAMES || s.channels != 1u) { wr.info = BW_SLOW; wrecs[i] = wr; return; }
+    const BufDyn d = dyn[i];
+    if (d.common.flags & MIXDYN_STOPPED) { skip[i] = 1; wrecs[i] = wr; return; }
+    bool fin = (d.common.flags & MIXDYN_STOP_REQUESTED) != 0;                                                       // mixer.rs:102
+    fin = fin || d.common.t >= (double)(s.clip_len - 1u) / (double)s.clip_rate;                                      // frames.rs:204-206
+    if (fin) {
+        dyn[i].common.flags = d.common.flags | MIXDYN_STOPPED;
+        const uint32_t k = atomicAdd(&stopped_hdr[0], 1u);
+        if (k < stopped_cap) stopped_hdr[1 + k] = d.common.id;
+        skip[i] = 1;
+        wrecs[i] = wr;
+        return;
+    }
+    double t_new;
+    float sm_prev[MAX_WRAP], sm_next[MAX_WRAP], sm_prog[MAX_WRAP];
+    float* ring = slabs + (size_t)i * 2 * n_frames - RING_MIRROR;
+    const bool fast = chain_write_rec(wr, bounds_err, s, d, d.common, interval, n_frames, 0u, false, (size_t)RING_MIRROR, ring, 1u << 24, i, true,
+                                      t_new, sm_prev, sm_next, sm_prog);
+    if (fast) {
+        dyn[i].common.t = t_new;                                                                                     // frames.rs:198
+#pragma unroll
+        for (int w = 0; w < MAX_WRAP; ++w) { dyn[i].sm_prev[w] = sm_prev[w]; dyn[i].sm_next[w] = sm_next[w]; dyn[i].sm_progress[w] = sm_prog[w]; }
+        skip[i] = 0;
+    } else {
+        wr = WriteRec{};
+        wr.info = BW_SLOW;
+    }
+    wrecs[i] = wr;
+}
+
+// `wrecs` (null: every source): only the sources mixer_chain_walk left to this kernel (BW_SLOW).
 __global__ __launch_bounds__(64) void mixer_general_sources_wave(uint32_t n_sources, uint32_t n_frames, float interval,
                                                                  BufStatic* __restrict__ st, BufDyn* __restrict__ dyn,
                                                                  float* __restrict__ slabs, uint32_t* __restrict__ skip,
                                                                  uint32_t* __restrict__ stopped_hdr, uint32_t stopped_cap,
-                                                                 FaderRec* __restrict__ faders, float* __restrict__ fader_scratch) {
+                                                                 FaderRec* __restrict__ faders, float* __restrict__ fader_scratch,
+                                                                 const WriteRec* __restrict__ wrecs) {
     __shared__ float ck[8][64];
     const uint32_t i = blockIdx.x;
     const int lane = threadIdx.x;
     if (i >= n_sources) return;
+    if (wrecs && (wrecs[i].info & 7u) != BW_SLOW) return;
     BufStatic s = st[i];
     BufDyn d = dyn[i];
     if (d.common.flags & MIXDYN_STOPPED) { if (lane == 0) skip[i] = 1; return; }
@@ -499,6 +599,7 @@ __global__ void mixer_convert_to_general(uint32_t n, const MixStatic* __restrict
     BufStatic s = {};
     s.clip = ms[i].clip; s.clip_len = ms[i].clip_len; s.clip_rate = ms[i].clip_rate; s.freq_or_value = ms[i].freq_or_value;
     s.kind = ms[i].kind; s.channels = 1;
+    s.flags = ms[i].kind == KIND_FRAMES ? BUF_FAST_OK : 0u;      // (a chain source from now on: mixer_chain_walk)
     if (ms[i].fixed_gain != 1.0f) { s.n_wrap = 1; s.wrap_kind[0] = WRAP_FIXED_GAIN; s.wrap_param[0] = ms[i].fixed_gain; }
     BufDyn d = {};
     d.common.t = md[i].t; d.common.phase = md[i].phase; d.common.flags = md[i].flags; d.common.id = md[i].id;
