@@ -455,6 +455,20 @@ def bench_mixer(device: int, frames_bank) -> dict:
     mixer.close()
     out.update({"sources": S, "fast_ms_per_callback": fast, "ordered_ms_per_callback": ordered,
                 "fast_source_frames_per_s": float(S) * N_FRAMES / (fast * 1e-3), "ordered_source_frames_per_s": float(S) * N_FRAMES / (ordered * 1e-3)})
+    # the same with a GainControl on every source (Gain<MonoToStereo<FramesSignal>>: the mixer's chain path, gain.rs + smooth.rs)
+    control, mixer = oa.Mixer(device=device, max_sources=S, max_frames=N_FRAMES)
+    gains = []
+    for i in range(S):
+        gc, gsig = oa.Gain.new(oa.MonoToStereo(oa.FramesSignal(frames_bank[(i * 2654435761) % len(frames_bank)], 0.25)))
+        control.play(gsig)
+        if i % 64 == 0:
+            gains.append(gc)
+    for k, gc in enumerate(gains):          # (a ramp is running on a 64th of the sources while the callbacks are timed)
+        gc.set_amplitude_ratio(0.5 + 0.001 * (k % 100))
+    out["gain_sources_fast_ms_per_callback"] = timed(mixer, 16, 2)
+    mixer.set_mode(oa.MODE_ORDERED)
+    out["gain_sources_ordered_ms_per_callback"] = timed(mixer, 8, 3)
+    mixer.close()
     return out
 
 
