@@ -298,6 +298,22 @@ __global__ __launch_bounds__(1024) void publish_out(const float* __restrict__ ou
     if (threadIdx.x == 0) __hip_atomic_store(flag, ticket, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
+// The Mixer's host-output call: the frames and the head of the stopped-id list ([0] = count, then ids) into pinned host memory, then
+// the ticket.  One block.
+__global__ __launch_bounds__(1024) void mixer_publish(const float* __restrict__ out_dev, float* host_out, uint32_t n, uint32_t* __restrict__ stopped,
+                                                      uint32_t* host_stopped, uint32_t stopped_words, uint32_t* flag, uint32_t ticket) {
+    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) __hip_atomic_store(host_out + i, out_dev[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    const uint32_t cnt = stopped[0];
+    const uint32_t words = 1u + (cnt < stopped_words - 1u ? cnt : stopped_words - 1u);
+    for (uint32_t i = threadIdx.x; i < words; i += blockDim.x) __hip_atomic_store(host_stopped + i, stopped[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        stopped[0] = 0u;          // the next callback's walk counts from zero (no memset on the stream)
+        __hip_atomic_store(flag, ticket, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
 // (bench) FramesSignal::t = seconds for the FramesSignal leaves of the buffered set
 __global__ void reset_buffered_clock(BufDyn* __restrict__ dyn, const BufStatic* __restrict__ st, const uint32_t* __restrict__ d_len, double seconds) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
