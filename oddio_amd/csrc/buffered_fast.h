@@ -476,8 +476,18 @@ __global__ __launch_bounds__(64) void buffered_write(const WriteRec* __restrict_
     const int lane16 = 16 * lane;
     const uint32_t n_sources = *len_snap;
     const uint32_t n_groups = (n_sources + BW_GROUP - 1) / BW_GROUP;
-    const uint32_t g_lo = blockIdx.x * groups_per_wave;
-    uint32_t g_hi = g_lo + groups_per_wave;
+    // `groups_per_wave`: groups of 16 sources per wave; with 2^k in its top byte instead, 2^k waves share ONE group and each renders
+    // 16 >> k of its sources (small sets: a wave renders its sources one after the other, ~3 us each)
+    const uint32_t split_log2 = groups_per_wave >> 24;
+    uint32_t g_lo = blockIdx.x * (groups_per_wave & 0xffffffu);
+    uint32_t g_hi = g_lo + (groups_per_wave & 0xffffffu);
+    unsigned long long part_mask = 0xffffull;
+    if (split_log2) {
+        g_lo = blockIdx.x >> split_log2;
+        g_hi = g_lo + 1u;
+        const uint32_t per = (uint32_t)BW_GROUP >> split_log2;
+        part_mask = ((1ull << per) - 1ull) << ((blockIdx.x & ((1u << split_log2) - 1u)) * per);
+    }
     if (g_hi > n_groups) g_hi = n_groups;
     const uint32_t lds_base = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uintptr_t)smem);
     float* ck = reinterpret_cast<float*>(smem + BW_LDS_CK);
@@ -509,7 +519,7 @@ __global__ __launch_bounds__(64) void buffered_write(const WriteRec* __restrict_
                 }
             }
         }
-        const unsigned long long fast_mask = __ballot(slot == 0 && (infoA & 7u) == BW_FAST);   // bit j: source j of the group is rendered here
+        const unsigned long long fast_mask = __ballot(slot == 0 && (infoA & 7u) == BW_FAST) & part_mask;   // bit j: source j of the group is rendered here
         if (fast_mask == 0ull) continue;
         // lanes 0-15 keep the record of source `lane` in registers for the whole group: phase B takes a source's (wave-uniform)
         // words from there with v_readlane -- fetched from memory at the point of use, every source paid a scalar-load latency
