@@ -2,7 +2,8 @@
 
 TEST INFRASTRUCTURE ONLY.  Written from the operation-order specification (SURVEY.md Appendix A,
 which cites src/spatial.rs:376-471, src/frames.rs:176-213, src/sine.rs:18-47, src/mixer.rs:92-119,
-src/math/mod.rs:33-94), deliberately NOT from oracle/oddio_oracle.c: different structure
+src/math/mod.rs:33-94; round 4: src/ring.rs:4-80, src/gain.rs:18-37,58-127, src/smooth.rs:26-91, src/speed.rs:10-40,
+src/spatial.rs:18-57,314-340,395-433 -- the buffered path and the filters), deliberately NOT from oracle/oddio_oracle.c: different structure
 (array-at-a-time, functional state), so that bit-equality between the two on seeded scenes is
 evidence that both follow the specification (tests/test_oracle_cross.py).
 
@@ -161,6 +162,46 @@ def cycle_source(rate, samples, fixed_gain_db=None):
     return s
 
 
+# ---- filters around a source (round 4): FixedGain / Gain (with its Smoothed ramp) / Speed ----------------------------
+
+SMOOTHING_PERIOD = f32(0.1)       # src/gain.rs:163
+
+
+def fixed_gain_filter(inner, db):
+    """FixedGain::new(inner, db) (src/gain.rs:18-23): gain = 10^(db / 20)."""
+    return {"kind": "fixed", "inner": inner, "gain": powf(10.0, f32(db) / f32(20.0))}
+
+
+def gain_filter(inner, initial_ratio=None):
+    """Gain::new(inner) (src/gain.rs:66-76): shared = 1.0, Smoothed::new(1.0) (src/smooth.rs:34-44).  `initial_ratio`:
+    Gain::set_amplitude_ratio before playing (gain.rs:90-93): the store AND a fresh Smoothed."""
+    g = {"kind": "gain", "inner": inner, "shared": ONE, "prev": ONE, "next": ONE, "progress": ONE}
+    if initial_ratio is not None:
+        g["shared"] = f32(initial_ratio)
+        g["prev"] = g["next"] = f32(initial_ratio)
+    return g
+
+
+def gain_control_set(g, ratio):
+    """GainControl::set_amplitude_ratio (src/gain.rs:157-160): a relaxed store; the filter notices at its next sample call."""
+    g["shared"] = f32(ratio)
+
+
+def speed_filter(inner, speed=1.0):
+    """Speed::new(inner) (src/speed.rs:16-24) + SpeedControl::set_speed (:52-54)."""
+    return {"kind": "speed", "inner": inner, "speed": f32(speed)}
+
+
+def speed_control_set(sp, factor):
+    sp["speed"] = f32(factor)
+
+
+def _smoothed_get(g):
+    """Smoothed::get (src/smooth.rs:67-72) with f32::interpolate (:84-89): prev + progress * (next - prev)."""
+    diff = g["next"] - g["prev"]
+    return f32(g["prev"] + g["progress"] * diff)
+
+
 def _gather_pair(samples, idx):
     """pair(i) = (S(i), S(i+1)) with S(i) = samples[i] inside the clip, 0 outside."""
     n = samples.shape[0]
@@ -173,6 +214,30 @@ def _gather_pair(samples, idx):
 def src_sample(src, interval, n):
     interval = f32(interval)
     kind = src["kind"]
+    if kind == "fixed":                                   # FixedGain::sample, src/gain.rs:30-37
+        return (src_sample(src["inner"], interval, n) * src["gain"]).astype(f32)
+    if kind == "speed":                                   # Speed::sample, src/speed.rs:32-35
+        return src_sample(src["inner"], interval * src["speed"], n)
+    if kind == "gain":                                    # Gain::sample, src/gain.rs:103-122
+        out = src_sample(src["inner"], interval, n)
+        if src["next"] != src["shared"]:                  # :106-108 -> Smoothed::set, src/smooth.rs:57-64
+            src["prev"] = _smoothed_get(src)
+            src["next"] = src["shared"]
+            src["progress"] = ZERO
+        if src["progress"] == ONE:                        # :109-117
+            g = _smoothed_get(src)
+            return (out * g).astype(f32) if g != ONE else out
+        # :118-121: per frame `x * gain.get()` then `advance(interval / SMOOTHING_PERIOD)` = min(progress + step, 1)
+        # (src/smooth.rs:47-49).  The running progress is a strictly sequential f32 sum; once it is clamped it stays 1.
+        step = interval / SMOOTHING_PERIOD
+        assert step > ZERO
+        seq = np.full(n + 1, step, dtype=f32)
+        seq[0] = src["progress"]
+        prog = np.minimum(np.cumsum(seq, dtype=f32), ONE)  # prog[k] = progress before frame k, prog[n] after the call
+        diff = src["next"] - src["prev"]
+        gains = (src["prev"] + prog[:n] * diff).astype(f32)
+        src["progress"] = f32(prog[n])
+        return (out * gains).astype(f32)
     if kind == "frames":
         rate64 = f64(src["rate"])
         s0 = src["t"] * rate64
@@ -259,6 +324,8 @@ def src_seek(src, seconds):
 
 
 def src_is_finished(src):
+    if src["kind"] in ("fixed", "gain", "speed"):         # is_finished passes through the filters (gain.rs:39-41,124-126, speed.rs:37-39)
+        return src_is_finished(src["inner"])
     if src["kind"] in ("frames", "downmix"):
         return bool(src["t"] >= f64(len(src["samples"]) - 1) / f64(src["rate"]))
     return False
@@ -268,10 +335,63 @@ def src_is_finished(src):
 # SpatialScene (seekable sources)
 # ---------------------------------------------------------------------------------------------
 
+def _rem_euclid_f32(a, b):
+    """f32::rem_euclid: r = a % b (fmod); r < 0 -> r + |b|."""
+    r = fmodf(f32(a), f32(b))
+    return f32(r + abs(f32(b))) if r < ZERO else f32(r)
+
+
+class Ring:
+    """src/ring.rs:4-80 -- the delay queue of a buffered spatial source."""
+
+    def __init__(self, capacity):
+        self.buffer = np.zeros(int(capacity), dtype=f32)
+        self.write_pos = ZERO
+
+    def delay(self, rate, dt):                            # :45-47
+        self.write_pos = fmodf(self.write_pos + f32(rate) * f32(dt), f32(len(self.buffer)))
+
+    def write(self, src, rate, dt):                       # :18-41
+        n = len(self.buffer)
+        end = fmodf(self.write_pos + f32(dt) * f32(rate), f32(n))
+        start_idx = int(np.ceil(self.write_pos))
+        end_idx = int(np.ceil(end))
+        interval = ONE / f32(rate)
+        if end_idx > start_idx:
+            self.buffer[start_idx:end_idx] = src_sample(src, interval, end_idx - start_idx)
+        else:
+            self.buffer[start_idx:] = src_sample(src, interval, n - start_idx)
+            self.buffer[:end_idx] = src_sample(src, interval, end_idx)
+        self.write_pos = end
+
+    def sample(self, rate, t, interval, n_out):           # :51-79
+        buf, n = self.buffer, len(self.buffer)
+        offset = _rem_euclid_f32(self.write_pos + f32(t) * f32(rate), f32(n))
+        ds = f32(interval) * f32(rate)
+        out = np.zeros(n_out, dtype=f32)
+        for i in range(n_out):
+            trunc = int(offset)                           # to_int_unchecked: offset >= 0 here
+            fract = f32(offset - f32(trunc))
+            x = trunc
+            if x < n - 1:
+                a, b = buf[x], buf[x + 1]
+            elif x < n:
+                a, b = buf[x], buf[0]
+            else:
+                x = x % n
+                offset = f32(f32(x) + fract)
+                a, b = (buf[x], buf[x + 1]) if x < n - 1 else (buf[x], buf[0])
+            out[i] = f32(a + fract * f32(b - a))          # frame::lerp
+            offset = f32(offset + ds)
+        return out
+
+
 class Scene:
     def __init__(self):
         self.set = []
         self.pending = []
+        self.bset = []                                    # the buffered set (play_buffered): walked first (spatial.rs:395-433)
+        self.bpending = []
         self.all = []
         self.rot = np.array([1, 0, 0, 0], dtype=f32)
         self.rot_pending = None
@@ -284,6 +404,21 @@ class Scene:
             "finished_for": None, "stopped": False,
         }
         self.pending.append(e)
+        self.all.append(e)
+        return len(self.all) - 1
+
+    def play_buffered(self, src, position, velocity=(0, 0, 0), radius=0.1, max_distance=100.0, rate=48000, buffer_duration=0.1):
+        """SpatialSceneControl::play_buffered (src/spatial.rs:314-340) -> SpatialSignalBuffered::new (:31-56)."""
+        max_delay = f32(max_distance) / C_SOUND + f32(buffer_duration)
+        queue = Ring(int(np.ceil(max_delay * f32(rate))) + 1)
+        pos = np.asarray(position, dtype=f32).copy()
+        queue.delay(rate, min(norm(pos) / C_SOUND, max_delay))
+        e = {
+            "src": src, "radius": f32(radius), "pos": pos, "vel": np.asarray(velocity, dtype=f32).copy(),
+            "pending": None, "prev_position": pos.copy(), "dt": f32(0.0), "finished_for": None, "stopped": False,
+            "rate": int(rate), "max_delay": max_delay, "queue": queue,
+        }
+        self.bpending.append(e)
         self.all.append(e)
         return len(self.all) - 1
 
@@ -306,21 +441,12 @@ class Scene:
         ir = ONE - r
         return (ir * naive + r * intended).astype(f32)
 
-    def sample(self, interval, n, acc_dtype=np.float32):
-        interval = f32(interval)
-        prev_rot = self.rot
-        if self.rot_pending is not None:
-            self.rot = self.rot_pending
-            self.rot_pending = None
-        rot = self.rot
-        out = np.zeros((n, 2), dtype=acc_dtype)
-        elapsed = interval * f32(n)
-        nf = f32(n)
-        self.set.extend(self.pending)
-        self.pending = []
-        i = len(self.set) - 1
+    def _walk(self, the_set, prev_rot, rot, elapsed, render):
+        """walk_set (src/spatial.rs:191-265): reverse index order, motion hand-off, the finished / propagation-delay rule,
+        swap_remove; `render(e, p0, p1)` for every source that stays."""
+        i = len(the_set) - 1
         while i >= 0:
-            e = self.set[i]
+            e = the_set[i]
             if e["pending"] is not None:
                 old_pos, old_vel = e["pos"], e["vel"]
                 npos, nvel, disc = e["pending"]
@@ -340,10 +466,42 @@ class Scene:
             elif src_is_finished(e["src"]):
                 e["finished_for"] = elapsed
             if e["stopped"]:
-                self.set[i] = self.set[-1]
-                self.set.pop()
+                the_set[i] = the_set[-1]
+                the_set.pop()
                 i -= 1
                 continue
+            render(e, p0, p1)
+            i -= 1
+
+    def sample(self, interval, n, acc_dtype=np.float32):
+        interval = f32(interval)
+        prev_rot = self.rot
+        if self.rot_pending is not None:
+            self.rot = self.rot_pending
+            self.rot_pending = None
+        rot = self.rot
+        out = np.zeros((n, 2), dtype=acc_dtype)
+        elapsed = interval * f32(n)
+        nf = f32(n)
+
+        def render_buffered(e, p0, p1):                   # src/spatial.rs:403-432
+            e["queue"].write(e["src"], e["rate"], elapsed)
+            for ear in (0, 1):
+                off0, g0 = ear_state(p0, ear, e["radius"])
+                off1, g1 = ear_state(p1, ear, e["radius"])
+                prev_offset = max(f32(off0 - elapsed), f32(-e["max_delay"]))
+                next_offset = max(off1, f32(-e["max_delay"]))
+                dt = f32(next_offset - prev_offset) / nf
+                d_gain = f32(g1 - g0) / nf
+                for c0 in range(0, n, 256):
+                    ln = min(256, n - c0)
+                    t = f32(prev_offset + f32(c0) * dt)
+                    buf = e["queue"].sample(e["rate"], t, dt, ln)
+                    gain = g0 + np.arange(c0, c0 + ln, dtype=f32) * d_gain
+                    contrib = (buf * gain).astype(f32)
+                    out[c0:c0 + ln, ear] = out[c0:c0 + ln, ear] + contrib.astype(acc_dtype)
+
+        def render_seek(e, p0, p1):                       # src/spatial.rs:446-468
             src = e["src"]
             for ear in (0, 1):
                 off0, g0 = ear_state(p0, ear, e["radius"])
@@ -360,7 +518,13 @@ class Scene:
                     out[c0:c0 + ln, ear] = out[c0:c0 + ln, ear] + contrib.astype(acc_dtype)
                 src_seek(src, (-eff) - off0)
             src_seek(src, elapsed)
-            i -= 1
+
+        self.bset.extend(self.bpending)                   # set.update() then the walk, buffered set first (:395-433)
+        self.bpending = []
+        self._walk(self.bset, prev_rot, rot, elapsed, render_buffered)
+        self.set.extend(self.pending)
+        self.pending = []
+        self._walk(self.set, prev_rot, rot, elapsed, render_seek)
         return out
 
 

@@ -162,3 +162,122 @@ def test_postfx_bit_equal():
     sc, cs, ns, hc, hn = build_pair(32, 4, ["frames"])
     t = oc.Tanh(cs)
     np.testing.assert_array_equal(t.sample_n(interval, 512), on.tanh_clip(ns.sample(interval, 512)))
+
+
+# ---- round 4: the filters and the buffered path (gain.rs, smooth.rs, speed.rs, ring.rs, spatial.rs:18-57,314-340,395-433) -----------
+# The C restatement of these is pinned by the reference's KATs (tests/test_oracle_kats.py: ring.rs:105-134, gain.rs:171-179,
+# smooth.rs:6-24); here it also has to agree, bit for bit, with the numpy restatement written independently from the same lines.
+
+def test_ring_kats_through_the_numpy_ring():
+    # src/ring.rs:105-134 (`fill`, `wrap`) on oracle_np.Ring, the buffer contents given
+    r = on.Ring(4)
+    r.buffer[:] = [1.0, 2.0, 3.0, 0.0]
+    r.write_pos = np.float32(3.0)
+    np.testing.assert_array_equal(r.sample(1, -1.5, 1.0, 2), np.array([2.5, 1.5], np.float32))
+    np.testing.assert_array_equal(r.sample(1, -1.5, 0.25, 4), np.array([2.5, 2.75, 3.0, 2.25], np.float32))
+    r.buffer[:] = [5.0, 6.0, 3.0, 4.0]
+    r.write_pos = np.float32(2.0)
+    np.testing.assert_array_equal(r.sample(1, -2.75, 0.5, 6), np.array([4.25, 4.75, 5.25, 5.75, 5.25, 3.75], np.float32))
+
+
+def _chain_pair(i, clip, rate, start):
+    """The same filter nest around a FramesSignal in both restatements; returns (c_signal_mono, np_source, controls)."""
+    cleaf, nleaf = oc.FramesSignal(oc.Frames(rate, clip), start), on.frames_source(rate, clip, start)
+    shape = i % 5
+    ctl = {}
+    if shape == 0:                                     # Gain<FramesSignal>
+        cg, ng = oc.Gain(cleaf), on.gain_filter(nleaf)
+        ctl["gain"] = (cg, ng)
+        return cg, ng, ctl
+    if shape == 1:                                     # Gain<Speed<FramesSignal>>, an initial amplitude ratio
+        cs_, ns_ = oc.Speed(cleaf), on.speed_filter(nleaf)
+        cs_.set_speed(0.93 + 0.01 * i)
+        on.speed_control_set(ns_, 0.93 + 0.01 * i)
+        cg, ng = oc.Gain(cs_), on.gain_filter(ns_, initial_ratio=0.5)
+        cg.init_amplitude_ratio(0.5)
+        ctl["gain"], ctl["speed"] = (cg, ng), (cs_, ns_)
+        return cg, ng, ctl
+    if shape == 2:                                     # FixedGain<Speed<FramesSignal>>
+        cs_, ns_ = oc.Speed(cleaf), on.speed_filter(nleaf)
+        ctl["speed"] = (cs_, ns_)
+        return oc.FixedGain(cs_, -4.5), on.fixed_gain_filter(ns_, -4.5), ctl
+    if shape == 3:                                     # Gain<Gain<FixedGain<FramesSignal>>>: two ramps at once
+        cg1, ng1 = oc.Gain(oc.FixedGain(cleaf, 2.0)), on.gain_filter(on.fixed_gain_filter(nleaf, 2.0))
+        cg2, ng2 = oc.Gain(cg1), on.gain_filter(ng1)
+        ctl["gain"], ctl["gain2"] = (cg2, ng2), (cg1, ng1)
+        return cg2, ng2, ctl
+    return cleaf, nleaf, ctl                            # plain
+
+
+def _poke(ctl, cb, i):
+    if "gain" in ctl and cb in (1, 2):                 # a second store while the first ramp is still running (0.1 s = 4.7 callbacks)
+        v = 0.2 + 0.13 * ((i + cb) % 6)
+        ctl["gain"][0].set_amplitude_ratio(v)
+        on.gain_control_set(ctl["gain"][1], v)
+    if "gain2" in ctl and cb == 2:
+        ctl["gain2"][0].set_amplitude_ratio(1.7)
+        on.gain_control_set(ctl["gain2"][1], 1.7)
+    if "speed" in ctl and cb == 3:
+        v = 1.04 + 0.005 * (i % 7)
+        ctl["speed"][0].set_speed(v)
+        on.speed_control_set(ctl["speed"][1], v)
+
+
+@pytest.mark.parametrize("n_frames", [1024, 700, 2300])
+def test_mixer_filter_chains_bit_equal(n_frames):
+    cm, nm = oc.Mixer(2), on.Mixer(2)
+    ctls = []
+    for i in range(15):
+        clip = synth.noise_clip(91, i, 9000 + 531 * i)
+        c, n, ctl = _chain_pair(i, clip, (48000, 44100, 96000)[i % 3], 0.002 * (i % 4))
+        cm.play(oc.MonoToStereo(c))
+        nm.play(n)
+        ctls.append(ctl)
+    interval = np.float32(1.0) / np.float32(48000)
+    for cb in range(6):
+        for i, ctl in enumerate(ctls):
+            _poke(ctl, cb, i)
+        a = cm.sample_n(interval, n_frames)
+        b = nm.sample(interval, n_frames)
+        np.testing.assert_array_equal(a, b)
+    assert np.abs(a).max() > 0
+
+
+@pytest.mark.parametrize("n_frames", [1024, 300, 1536])
+def test_buffered_scene_bit_equal(n_frames):
+    """play_buffered sources (rings: Ring::write through the filter chain, Ring::sample per ear and chunk) beside seekable ones,
+    motion updates incl. a jump, a listener rotation, control stores."""
+    sc = synth.make_scene(77, 14, cube=30.0)
+    cs, ns = oc.SpatialScene(), on.Scene()
+    hc, hn, ctls = [], [], []
+    for i in range(14):
+        pos, vel, rad = sc["position"][i], sc["velocity"][i], sc["radius"][i]
+        clip = synth.noise_clip(77, i, 12000 + 777 * i)
+        if i % 4 == 3:                                  # a seekable source in between
+            hc.append(cs.play(oc.FramesSignal(oc.Frames(48000, clip), 0.1), oc.SpatialOptions(pos, vel, rad)))
+            hn.append(ns.play(on.frames_source(48000, clip, 0.1), pos, vel, rad))
+            ctls.append({})
+            continue
+        c, n, ctl = _chain_pair(i, clip, (48000, 44100)[i % 2], 0.0)
+        rate, maxd, dur = (48000, 44100, 32000)[i % 3], (100.0, 40.0)[i % 2], (0.1, 0.06)[i % 2]
+        hc.append(cs.play_buffered(c, oc.SpatialOptions(pos, vel, rad), maxd, rate, dur))
+        hn.append(ns.play_buffered(n, pos, vel, rad, maxd, rate, dur))
+        ctls.append(ctl)
+    interval = np.float32(1.0) / np.float32(48000)
+    rng = np.random.default_rng(3)
+    for cb in range(7):
+        for i, ctl in enumerate(ctls):
+            _poke(ctl, cb, i)
+        if cb in (2, 4):
+            for j in (0, 5, 9):
+                p = (sc["position"][j] + rng.normal(size=3).astype(np.float32) * (25.0 if cb == 4 else 1.0)).astype(np.float32)
+                hc[j].set_motion(p, sc["velocity"][j], cb == 4)
+                ns.set_motion(hn[j], p, sc["velocity"][j], cb == 4)
+        if cb == 3:
+            q = np.array([np.cos(0.3), 0.0, np.sin(0.3), 0.0], np.float32)
+            cs.set_listener_rotation(q)
+            ns.set_listener_rotation(q)
+        a = cs.sample_n(interval, n_frames)
+        b = ns.sample(interval, n_frames)
+        np.testing.assert_array_equal(a, b)
+    assert np.abs(a).max() > 0
