@@ -10,7 +10,8 @@ import pytest
 
 import scenario
 
-GOLDEN = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "*.npz")))
+GOLDEN = sorted(p for p in glob.glob(os.path.join(os.path.dirname(__file__), "golden", "*.npz"))
+                if not os.path.basename(p).startswith("chains_"))      # (chains_*.npz: tests/test_golden_chains.py)
 KINDS = {0: "frames", 1: "sine", 2: "constant", 3: "cycle", 4: "downmix"}
 
 
