@@ -469,10 +469,19 @@ __device__ __forceinline__ void leaf_repack_padded(unsigned char* win_bytes, int
 
 // grid = waves (one 64-thread workgroup each); wave w renders groups [w * groups_per_wave, ...) of 16 slots.
 // (bounds_err: the bounds-checked build's violation record -- device_types.h; null otherwise)
+// ACC (the Mixer's chain sources in FAST mode, mixer_kernels.h): nothing is stored per source -- the wave adds what it renders to 16
+// running sums per lane and leaves ONE row, frames duplicated into both channels (MonoToStereo, signal.rs:73-80), at
+// acc_rows[blockIdx.x * acc_stride ..]: the sum is a tree over waves anyway, and a slab per source that a sum kernel re-reads is
+// twice the chain's traffic.
+template <bool ACC = false>
 __global__ __launch_bounds__(64) void buffered_write(const WriteRec* __restrict__ wrecs, const uint32_t* __restrict__ len_snap,
-                                                     BufDyn* __restrict__ dyn, uint32_t groups_per_wave, uint32_t* __restrict__ bounds_err) {
+                                                     BufDyn* __restrict__ dyn, uint32_t groups_per_wave, uint32_t* __restrict__ bounds_err,
+                                                     float* __restrict__ acc_rows, uint32_t acc_stride, uint32_t acc_frames) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[BW_LDS_TOTAL];
     const int lane = threadIdx.x;
+    float acc[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) acc[k] = 0.0f;
     const int lane16 = 16 * lane;
     const uint32_t n_sources = *len_snap;
     const uint32_t n_groups = (n_sources + BW_GROUP - 1) / BW_GROUP;
@@ -704,6 +713,14 @@ __global__ __launch_bounds__(64) void buffered_write(const WriteRec* __restrict_
                     if ((uint32_t)lane == last_lane) dyn[src].sm_progress[(ops >> (12 + 2 * ri)) & 3u] = pfin;
                 }
             }
+            if (ACC) {
+#pragma unroll
+                for (int k = 0; k < 16; ++k) if (f0 + (uint32_t)k < cnt) acc[k] = acc[k] + out[k];
+                light = 0;        // (only the progress stores above were issued after the next window: wait for everything)
+                wave_sync();
+                buf ^= 1;
+                continue;
+            }
             // ---- Ring::write's stores (ring.rs:33-38) ----
             // A lane holds 16 consecutive frames; stored from there, every instruction would touch 64 lines with 16 bytes each
             // (8 partial writes per 128-byte line: the kernel was bound by the L2's request rate, 104 M requests per launch).
@@ -743,6 +760,14 @@ __global__ __launch_bounds__(64) void buffered_write(const WriteRec* __restrict_
 #undef ODDIO_BW_ISSUE
 #undef ODDIO_RW
 #undef ODDIO_RF
+    }
+    if (ACC) {
+        float* dst = acc_rows + (size_t)blockIdx.x * acc_stride;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const uint32_t f = 16u * (uint32_t)lane + (uint32_t)k;
+            if (f < acc_frames) { dst[2u * f] = acc[k]; dst[2u * f + 1u] = acc[k]; }
+        }
     }
 }
 

@@ -492,7 +492,8 @@ __global__ __launch_bounds__(64) void mixer_sum_slabs(const float* __restrict__ 
 __global__ __launch_bounds__(128) void mixer_chain_walk(uint32_t n_sources, uint32_t n_frames, float interval, const BufStatic* __restrict__ st,
                                                         BufDyn* __restrict__ dyn, WriteRec* __restrict__ wrecs, float* __restrict__ slabs,
                                                         uint32_t* __restrict__ skip, uint32_t* __restrict__ stopped_hdr, uint32_t stopped_cap,
-                                                        uint32_t* __restrict__ bounds_err) {
+                                                        uint32_t* __restrict__ bounds_err, int acc_mode) {
+    // acc_mode: buffered_write<ACC> adds the chain sources up itself: they have no slab, the slab sums skip them
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_sources) return;
     const BufStatic s = st[i];
@@ -519,7 +520,7 @@ __global__ __launch_bounds__(128) void mixer_chain_walk(uint32_t n_sources, uint
         dyn[i].common.t = t_new;                                                                                     // frames.rs:198
 #pragma unroll
         for (int w = 0; w < MAX_WRAP; ++w) { dyn[i].sm_prev[w] = sm_prev[w]; dyn[i].sm_next[w] = sm_next[w]; dyn[i].sm_progress[w] = sm_prog[w]; }
-        skip[i] = 0;
+        skip[i] = acc_mode ? 1u : 0u;
     } else {
         wr = WriteRec{};
         wr.info = BW_SLOW;
