@@ -247,6 +247,54 @@ def test_general_path_beyond_1024_sources_bit_exact():
         mixer.close()
 
 
+@pytest.mark.parametrize("mode,n_frames", [(0, 1024), (0, 700), (1, 700)])
+def test_general_path_chain_and_other_shapes_together(mode, n_frames):
+    """600 sources of three kinds in one mixer: chains over a mono clip (buffered_write; in FAST mode added up by the kernel itself),
+    Gain over a STEREO clip and Gain<MonoToStereo<Cycle>> (one wavefront per source, a slab each) -- the row-sum tree takes both kinds
+    of rows; sources stop on the way."""
+    import oddio_amd as oa
+    control, mixer = oa.Mixer(max_sources=640, max_frames=1024)
+    cm = oc.Mixer(2)
+    mixer.set_mode(mode)
+    mono = [synth.noise_clip(12, k, 6000 + 400 * k) for k in range(5)]
+    st2 = [np.stack([synth.noise_clip(13, k, 5000), synth.noise_clip(14, k, 5000)], axis=1) for k in range(3)]
+    fm = [(oa.Frames.from_slice(48000, c), oc.Frames(48000, c)) for c in mono]
+    fs = [(oa.Frames.from_slice(44100, c), oc.Frames(44100, c)) for c in st2]
+    fc = [(oa.Frames.from_slice(48000, c[:700]), oc.Frames(48000, c[:700])) for c in mono[:2]]
+    hs, hc, gh, gc = [], [], [], []
+    for i in range(600):
+        if i % 3 == 0:
+            h_, c_ = oa.MonoToStereo(oa.FramesSignal(fm[i % 5][0], 0.001 * (i % 9))), oc.MonoToStereo(oc.FramesSignal(fm[i % 5][1], 0.001 * (i % 9)))
+        elif i % 3 == 1:
+            h_, c_ = oa.FramesSignal(fs[i % 3][0], 0.0), oc.FramesSignal(fs[i % 3][1], 0.0)
+        else:
+            h_, c_ = oa.MonoToStereo(oa.Cycle(fc[i % 2][0])), oc.MonoToStereo(oc.Cycle(fc[i % 2][1]))
+        hgc, hg = oa.Gain.new(h_)
+        cg = oc.Gain(c_)
+        hs.append(control.play(hg))
+        hc.append(cm.play(cg))
+        gh.append(hgc)
+        gc.append(cg)
+    iv = np.float32(1.0) / np.float32(48000)
+    for cb in range(6):
+        if cb == 1:
+            for k in range(0, 600, 4):
+                gh[k].set_amplitude_ratio(0.3 + 0.002 * (k % 200))
+                gc[k].set_amplitude_ratio(0.3 + 0.002 * (k % 200))
+        if cb == 3:
+            for k in range(5, 600, 31):
+                hs[k].stop()
+                hc[k].stop()
+        got = mixer.sample_n(iv, n_frames)
+        ref = cm.sample_n(iv, n_frames)
+        if mode == 1:
+            np.testing.assert_array_equal(got, ref)
+        else:
+            assert np.abs(got - ref).max() <= 1e-5 * np.abs(ref).max()
+        assert len(mixer) == len(cm)
+    mixer.close()
+
+
 @pytest.mark.parametrize("n_src", [5, 40, 64, 100, 700, 3000])
 def test_mixer_fast_mode_wave_split_tolerance(n_src):
     """FAST mode at sizes where 2 .. 16 waves share a group of 64 sources (round 4) and beyond: within 1e-5 of the reference."""
