@@ -40,7 +40,7 @@ pub struct RawMixer {
 #[repr(C)]
 #[derive(Clone, Copy)]
 pub struct RawFilter {
-    pub kind: c_int, // 1 FixedGain(dB), 2 Gain(initial amplitude ratio), 3 Speed(initial factor)
+    pub kind: c_int, // 1 FixedGain(dB), 2 Gain(initial amplitude ratio), 3 Speed(initial factor), 4 Reinhard, 5 Tanh (per-source soft clips)
     pub param: f32,
 }
 pub const LEAF_FRAMES: c_int = 0;
@@ -63,6 +63,7 @@ extern "C" {
     fn oddio_hip_scene_play_constant(s: *mut RawScene, value: f32, position: *const f32, velocity: *const f32, radius: f32, id: *mut u32) -> c_int;
     fn oddio_hip_scene_play_cycle(s: *mut RawScene, f: *mut RawFrames, fixed_gain_db: f32, position: *const f32, velocity: *const f32, radius: f32, id: *mut u32) -> c_int;
     fn oddio_hip_scene_play_buffered(s: *mut RawScene, leaf_kind: c_int, f: *mut RawFrames, start_seconds: f64, phase: f32, frequency_hz_or_value: f32, filters: *const RawFilter, n_filters: c_int, position: *const f32, velocity: *const f32, radius: f32, max_distance: f32, rate: u32, buffer_duration: f32, id: *mut u32) -> c_int;
+    fn oddio_hip_scene_play_filtered(s: *mut RawScene, leaf_kind: c_int, f: *mut RawFrames, start_seconds: f64, phase: f32, frequency_hz_or_value: f32, filters: *const RawFilter, n_filters: c_int, position: *const f32, velocity: *const f32, radius: f32, id: *mut u32) -> c_int;
     fn oddio_hip_source_set_gain(s: *mut RawScene, id: u32, filter_index: c_int, amplitude_ratio: f32) -> c_int;
     fn oddio_hip_source_set_gain_db(s: *mut RawScene, id: u32, filter_index: c_int, db: f32) -> c_int;
     fn oddio_hip_source_set_speed(s: *mut RawScene, id: u32, filter_index: c_int, factor: f32) -> c_int;
@@ -238,6 +239,17 @@ impl HipSpatialSceneControl {
         let (p, v) = pv(&options);
         let mut id = 0u32;
         check(unsafe { oddio_hip_scene_play_cycle((self.0).0, frames.0, f32::NAN, p.as_ptr(), v.as_ptr(), options.radius, &mut id) });
+        self.spatial(id)
+    }
+    /// play(Reinhard::new(FramesSignal::new(frames, start_seconds)), options) and the other Seek chains around a clip: `filters`
+    /// innermost first, at most one FixedGain and one soft clip (`RawFilter { kind: 4 /* Reinhard */ | 5 /* Tanh */, .. }`) in
+    /// either order (src/reinhard.rs:42-50, src/tanh.rs:36-44, src/gain.rs:39-51 are the Seek impls that make such a signal playable).
+    pub fn play_frames_filtered(&mut self, frames: &Arc<HipFrames>, start_seconds: f64, filters: &[RawFilter], options: SpatialOptions) -> HipSpatial {
+        let (p, v) = pv(&options);
+        let mut id = 0u32;
+        check(unsafe {
+            oddio_hip_scene_play_filtered((self.0).0, LEAF_FRAMES, frames.0, start_seconds, 0.0, 0.0, filters.as_ptr(), filters.len() as c_int, p.as_ptr(), v.as_ptr(), options.radius, &mut id)
+        });
         self.spatial(id)
     }
     /// play_buffered(filters(FramesSignal), options, max_distance, rate, buffer_duration)   (src/spatial.rs:314-340);

@@ -151,8 +151,24 @@ int oddio_hip_scene_play_frames_batch(oddio_hip_scene* scene, size_t n,
  * in HBM, allocated here (control thread) and sampled at `rate`. */
 enum { ODDIO_HIP_LEAF_FRAMES = 0, ODDIO_HIP_LEAF_SINE = 1, ODDIO_HIP_LEAF_CONSTANT = 2,
        ODDIO_HIP_LEAF_CYCLE = 3 /* Cycle::new(frames), src/cycle.rs (buffered sources and Mixer chains) */ };
-enum { ODDIO_HIP_FILTER_FIXED_GAIN = 1, ODDIO_HIP_FILTER_GAIN = 2, ODDIO_HIP_FILTER_SPEED = 3 };
+enum { ODDIO_HIP_FILTER_FIXED_GAIN = 1, ODDIO_HIP_FILTER_GAIN = 2, ODDIO_HIP_FILTER_SPEED = 3,
+       /* per-source soft clips, `Reinhard<T>` (src/reinhard.rs:22-50) and `Tanh<T>` (src/tanh.rs:16-44): Signal + Seek
+        * wrappers over any signal, param unused.  In buffered and Mixer chains anywhere among the filters; in
+        * oddio_hip_scene_play_filtered see there. */
+       ODDIO_HIP_FILTER_REINHARD = 4, ODDIO_HIP_FILTER_TANH = 5 };
 typedef struct oddio_hip_filter { int kind; float param; } oddio_hip_filter;
+/* play(filters(leaf), options) for the filters that keep a signal `Seek` -- FixedGain(db) (src/gain.rs:9-51,
+ * :39-51 Seek), Reinhard (src/reinhard.rs:42-50) and Tanh (src/tanh.rs:36-44) -- innermost first: at most one
+ * FixedGain and one soft clip, in either order (`Reinhard::new(FixedGain::new(x, db))` or
+ * `FixedGain::new(Reinhard::new(x), db)`; ODDIO_HIP_EINVAL for other chains: play_buffered takes those).  The clip
+ * is applied to every sample of the source before the distance gain and the sum (src/spatial.rs:457-462 samples
+ * the wrapped signal).  leaf_kind: ODDIO_HIP_LEAF_FRAMES (mono clip) / _SINE / _CONSTANT / _CYCLE, arguments as in
+ * the play_* calls above. */
+int oddio_hip_scene_play_filtered(oddio_hip_scene* scene, int leaf_kind, oddio_hip_frames* frames,
+                                  double start_seconds, float phase, float frequency_hz_or_value,
+                                  const oddio_hip_filter* filters, int n_filters,
+                                  const float position[3], const float velocity[3], float radius,
+                                  uint32_t* source_id);
 int oddio_hip_scene_reserve_buffered(oddio_hip_scene* scene, uint32_t max_buffered);
 int oddio_hip_scene_play_buffered(oddio_hip_scene* scene, int leaf_kind, oddio_hip_frames* frames,
                                   double start_seconds, float phase, float frequency_hz_or_value,

@@ -278,7 +278,7 @@ class Speed(Signal):
         return sp.control, sp
 
 
-FILTER_FIXED_GAIN, FILTER_GAIN, FILTER_SPEED = 1, 2, 3
+FILTER_FIXED_GAIN, FILTER_GAIN, FILTER_SPEED, FILTER_REINHARD, FILTER_TANH = 1, 2, 3, 4, 5
 
 
 def _leaf_args(leaf, keep):
@@ -301,9 +301,11 @@ class _Filter(C.Structure):
 def _unwrap_chain(signal):
     """-> (leaf, [(kind, param, control or None)] innermost first)"""
     chain = []
-    while isinstance(signal, (FixedGain, Gain, Speed)):
+    while isinstance(signal, (FixedGain, Gain, Speed, Reinhard)) and not _is_postfx(signal):
         if isinstance(signal, FixedGain):
             chain.append((FILTER_FIXED_GAIN, float(signal.db), None))
+        elif isinstance(signal, Reinhard):       # (Tanh is a subclass)
+            chain.append((signal._FILTER, 0.0, None))
         elif isinstance(signal, Gain):
             chain.append((FILTER_GAIN, float(signal.control._ratio), signal.control))
         else:
@@ -337,19 +339,40 @@ class MonoToStereo(Signal):
         self.inner = inner
 
 
+def _is_postfx(signal):
+    """Reinhard / Tanh around a whole SpatialScene / Mixer (the reduce kernel's epilogue), as opposed to around a source."""
+    return isinstance(signal, Reinhard) and signal._postfx
+
+
 def _unwrap(signal):
-    """-> (leaf, fixed_gain_db or NaN)"""
+    """-> (leaf, fixed_gain_db or NaN, [(filter kind, param)] innermost first when the chain has a per-source soft clip, else None)
+
+    A Seek chain: at most one FixedGain and one Reinhard / Tanh, in either order (src/gain.rs:39-51, src/reinhard.rs:42-50,
+    src/tanh.rs:36-44 are the Seek impls of the wrappers)."""
     db = math.nan
-    if isinstance(signal, FixedGain):
-        db = float(signal.db)
+    chain = []
+    while isinstance(signal, (FixedGain, Reinhard)) and not _is_postfx(signal):
+        if isinstance(signal, FixedGain):
+            chain.append((FILTER_FIXED_GAIN, float(signal.db)))
+        else:
+            chain.append((signal._FILTER, 0.0))
         signal = signal.inner
-    if isinstance(signal, (Gain, Speed)) or (isinstance(signal, FixedGain)):
+    chain = chain[::-1]
+    kinds = [k for k, _ in chain]
+    if isinstance(signal, (Gain, Speed)) or kinds.count(FILTER_FIXED_GAIN) > 1 or len(kinds) - kinds.count(FILTER_FIXED_GAIN) > 1:
         raise TypeError("Gain / Speed are not Seek (src/gain.rs:53-57, src/speed.rs): use play_buffered; "
-                        "nested FixedGain needs play_buffered too")
+                        "chains with more than one FixedGain or soft clip need play_buffered too")
     if not isinstance(signal, (FramesSignal, Sine, Constant, Cycle, Downmix)):
         raise TypeError(f"{type(signal).__name__} is not implemented on the device path "
-                        "(supported: FramesSignal, Downmix of a stereo FramesSignal, Cycle, Sine, Constant, FixedGain around them)")
-    return signal, db
+                        "(supported: FramesSignal, Downmix of a stereo FramesSignal, Cycle, Sine, Constant; FixedGain, Reinhard, Tanh around them)")
+    if kinds in ([], [FILTER_FIXED_GAIN]) and not (kinds and isinstance(signal, Constant)):
+        if kinds:
+            db = chain[0][1]
+        return signal, db, None
+    # (FixedGain around a Constant goes through play_filtered as well: oddio_hip_scene_play_constant has no gain argument)
+    if isinstance(signal, Downmix):
+        raise TypeError("a soft clip around a Downmix needs play_buffered")
+    return signal, db, chain
 
 
 class SpatialOptions:
@@ -537,11 +560,20 @@ class SpatialSceneControl:
     def play(self, signal: Signal, options: SpatialOptions) -> Spatial:
         if signal.channels != 1:
             raise TypeError("signals in a spatial scene must be single-channel (src/spatial.rs:278-279)")
-        leaf, db = _unwrap(signal)
+        leaf, db, chain = _unwrap(signal)
         L, s = _lib.lib(), self._scene
         sid = C.c_uint32()
         pos, vel = _vec3(options.position), _vec3(options.velocity)
-        if isinstance(leaf, Downmix):
+        if chain is not None:      # a per-source Reinhard / Tanh (with or without a FixedGain on either side of it)
+            if isinstance(leaf, Cycle) and leaf.frames.channels != 1:
+                raise TypeError("signals in a spatial scene must be single-channel (src/spatial.rs:278-279)")
+            filt = (_Filter * len(chain))()
+            for i, (kind, param) in enumerate(chain):
+                filt[i].kind, filt[i].param = kind, param
+            args = _leaf_args(leaf, s._keep)
+            _lib.check(L.oddio_hip_scene_play_filtered(s._h, args[0], args[1], args[2], args[3], args[4], C.cast(filt, C.c_void_p), len(chain),
+                                                       _fp(pos), _fp(vel), np.float32(options.radius), C.byref(sid)))
+        elif isinstance(leaf, Downmix):
             s._keep.append(leaf.inner.frames)
             _lib.check(L.oddio_hip_scene_play_frames_downmix(s._h, leaf.inner.frames._h, leaf.inner.start_seconds, db, _fp(pos), _fp(vel),
                                                              np.float32(options.radius), C.byref(sid)))
@@ -722,18 +754,26 @@ class Adapt(Signal):
 
 
 class Reinhard(Signal):
-    """Reinhard::new(scene_or_mixer) (src/reinhard.rs): fused into the reduce kernel's epilogue
-    (or into the Adapt epilogue for Reinhard::new(Adapt::new(..)))."""
+    """Reinhard::new(signal) (src/reinhard.rs:22-50).  Around a SpatialScene, a Mixer or an Adapt of one: fused into
+    the reduce kernel's epilogue (or into the Adapt epilogue).  Around a source signal: a per-source soft clip --
+    `x / (1 + |x|)` on every sample of that source before it is mixed -- playable wherever the wrapped signal is (it is
+    Seek when the inner signal is, src/reinhard.rs:42-50): `play` for [FixedGain] [Reinhard] chains over a leaf,
+    `play_buffered` and Mixer chains anywhere among the filters."""
     channels = 2
     seekable = False
     _KIND = POSTFX_REINHARD
+    _FILTER = FILTER_REINHARD
 
     def __init__(self, inner):
         target = inner.inner if isinstance(inner, Adapt) else inner
-        if not isinstance(target, (_SceneSignal, _MixerSignal)):
-            raise TypeError("device post-filters wrap a SpatialScene, a Mixer, or an Adapt around one")
+        self._postfx = isinstance(target, (_SceneSignal, _MixerSignal))
         self.inner = inner
-        target.set_postfx(self._KIND)
+        if self._postfx:
+            target.set_postfx(self._KIND)
+        elif isinstance(inner, Signal):
+            self.channels, self.seekable = inner.channels, inner.seekable
+        else:
+            raise TypeError("Reinhard / Tanh wrap a SpatialScene, a Mixer, an Adapt around one, or a source signal")
 
     def sample(self, interval, out):
         return self.inner.sample(interval, out)
@@ -746,8 +786,9 @@ class Reinhard(Signal):
 
 
 class Tanh(Reinhard):
-    """Tanh::new(scene_or_mixer) (src/tanh.rs)."""
+    """Tanh::new(signal) (src/tanh.rs:16-44): like Reinhard, for a whole scene / mixer or per source."""
     _KIND = POSTFX_TANH
+    _FILTER = FILTER_TANH
 
 
 class Mixed:
@@ -830,13 +871,15 @@ class MixerControl:
     def _parse(self, signal):
         """-> (leaf, [(kind, param, control)] innermost first) for a nest whose output is the mixer's frame type"""
         chain, stereo_seen, sig = [], False, signal
-        while isinstance(sig, (FixedGain, Gain, Speed, MonoToStereo)):
+        while isinstance(sig, (FixedGain, Gain, Speed, MonoToStereo, Reinhard)) and not _is_postfx(sig):
             if isinstance(sig, MonoToStereo):
                 if stereo_seen:
                     raise TypeError("MonoToStereo appears twice")
                 stereo_seen = True
             elif isinstance(sig, FixedGain):
                 chain.append((FILTER_FIXED_GAIN, float(sig.db), None))
+            elif isinstance(sig, Reinhard):      # per-source soft clip (per channel: reinhard.rs:28-35, tanh.rs:22-29)
+                chain.append((sig._FILTER, 0.0, None))
             elif isinstance(sig, Gain):
                 chain.append((FILTER_GAIN, float(sig.control._ratio), sig.control))
             else:

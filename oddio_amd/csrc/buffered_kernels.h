@@ -13,7 +13,7 @@
 
 namespace oddio_hip {
 
-enum : uint32_t { WRAP_FIXED_GAIN = 1, WRAP_GAIN = 2, WRAP_SPEED = 3 };
+enum : uint32_t { WRAP_FIXED_GAIN = 1, WRAP_GAIN = 2, WRAP_SPEED = 3, WRAP_REINHARD = 4, WRAP_TANH = 5 };   // == ODDIO_HIP_FILTER_*
 constexpr int MAX_WRAP = 4;
 
 struct alignas(16) BufStatic {
@@ -252,6 +252,8 @@ __device__ __forceinline__ void inner_sample_wave(const BufStatic& s, BufDyn& d,
                 for (uint32_t w = 0; w < MAX_WRAP; ++w) {
                     if (w >= s.n_wrap) continue;
                     if (s.wrap_kind[w] == WRAP_FIXED_GAIN) { v0 = v0 * s.wrap_param[w]; v1 = v1 * s.wrap_param[w]; }   // gain.rs:32-37
+                    else if (s.wrap_kind[w] == WRAP_REINHARD) { v0 = v0 / (1.0f + fabsf(v0)); v1 = v1 / (1.0f + fabsf(v1)); }   // reinhard.rs:28-35 (per channel)
+                    else if (s.wrap_kind[w] == WRAP_TANH) { v0 = tanhf(v0); v1 = tanhf(v1); }                                // tanh.rs:22-29
                     else if (s.wrap_kind[w] == WRAP_GAIN) {                                       // gain.rs:110-121
                         if (ramp[w]) {
                             const float g = d.sm_prev[w] + pr[w] * (d.sm_next[w] - d.sm_prev[w]);

@@ -34,9 +34,13 @@ struct alignas(16) SrcStatic {
     float fixed_gain;       // FixedGain linear factor (gain.rs:20); 1.0 when there is no wrapper
     float radius;           // SpatialOptions::radius
     float freq_or_value;    // Sine: rad/s (sine.rs:21); Constant: the value
-    uint32_t kind;
+    uint16_t kind;          // KIND_*
+    uint16_t fx;            // FX_*: a per-source soft clip around the signal (reinhard.rs:22-50, tanh.rs:16-44 are Signal + Seek wrappers)
 };
 static_assert(sizeof(SrcStatic) == 32, "SrcStatic layout");
+// `Reinhard<T>` / `Tanh<T>` wrapped around a Seek-set source, with the source's optional FixedGain inside the clip
+// (Reinhard(FixedGain(x)), the default) or outside it (FX_CLIP_FIRST: FixedGain(Reinhard(x)))
+enum : uint16_t { FX_REINHARD = 1, FX_TANH = 2, FX_CLIP_FIRST = 4 };
 
 struct alignas(16) SrcDyn {
     double t;               // FramesSignal::t seconds (frames.rs:145)
@@ -90,6 +94,26 @@ struct alignas(16) TileRec {
 static_assert(sizeof(TileRec) == 64, "TileRec layout");
 constexpr int REC_TILES = 2;   // tiles whose records the walk kernel writes itself; longer callbacks run in passes of this many tiles
 
+// The same for spatial_mix_pair (pair_kernels.h): ONE record per source for a callback of up to 1024 frames (four 256-frame
+// chunks), whose window -- every sample both ears touch in the whole callback -- is staged once per source by a workgroup
+// of two wavefronts, one per ear.
+//   desc     buffer descriptor words 0-2 of the window (kernels.h window_desc)
+//   info     path (bits 0-2) | SFLAG_* (bits 3-7) | nvec (bits 8-16: 16-byte vectors of the window) | negvec (bits 17-25)
+//   ear[e]   {ds, g0, dg}, the four chunks' start offsets (frames.rs:181/189) and their base indices relative to the window start
+struct alignas(8) PairEar {
+    float ds, g0, dg;
+    uint32_t pad;
+    float frac0[4];
+    uint16_t wrel[4];
+};
+struct alignas(16) PairRec {
+    uint32_t desc[3];
+    uint32_t info;
+    PairEar ear[2];
+};
+static_assert(sizeof(PairEar) == 40 && sizeof(PairRec) == 96, "PairRec layout");
+static_assert(sizeof(PairRec) <= REC_TILES * sizeof(TileRec), "a PairRec fits the room of a source's tile records");
+
 struct SceneParams {
     float prev_rot[4];      // (s,x,y,z) listener rotation used for the callback's start
     float rot[4];           //           ... and for its end (spatial.rs:382-386)
@@ -100,6 +124,7 @@ struct SceneParams {
     float* cycle_rows;      // Seek-set Cycle contribution rows: [row][ear][cycle_plane] (null: none played)
     uint32_t cycle_plane;   // floats per ear plane (= max_frames)
     uint32_t dmx;           // the callback's mix kernels are the Downmix-capable ones (spatial_mix<.., DMX>): the walk may stage stereo windows
+    uint32_t pair;          // the callback's mix kernel is spatial_mix_pair: the walk writes PairRecs instead of tile records
     uint32_t* bounds_err;   // debug build (-DODDIO_HIP_BOUNDS): {count, first code, first value, first source}; null otherwise
 };
 

@@ -135,6 +135,17 @@ __device__ __forceinline__ long long f64_as_isize(double x) {
     return (long long)x;
 }
 
+// A per-source soft clip around the signal (SrcStatic::fx): Reinhard<T>::sample `x / (1 + |x|)` (reinhard.rs:28-35) or
+// Tanh<T>::sample `tanh(x)` (tanh.rs:22-29) applied to every sample the inner signal produced, with the source's FixedGain
+// (gain.rs:32-37) inside the clip or, FX_CLIP_FIRST, outside it.  (x * 1.0 == x: a source without FixedGain carries 1.0.)
+__device__ __forceinline__ float apply_fx(float v, float fixed_gain, int fx) {
+    if (!(fx & FX_CLIP_FIRST)) v = v * fixed_gain;
+    if (fx & FX_REINHARD) v = v / (1.0f + fabsf(v));
+    else if (fx & FX_TANH) v = tanhf(v);
+    if (fx & FX_CLIP_FIRST) v = v * fixed_gain;
+    return v;
+}
+
 // ---------------------------------------------------------------------------------------------
 // prepass: one thread per live slot
 // ---------------------------------------------------------------------------------------------
@@ -282,11 +293,14 @@ constexpr int MIX_WAVES_PER_CU = 16;                   // default grid size (wav
 constexpr int MIX_GROUP = 16;                // sources per phase-A step (16 x 2 ears x 2 chunks = 64 lanes)
 constexpr int TILE_FRAMES = 512;             // frames per (wave, tile) pass
 constexpr int TILE_CHUNKS = TILE_FRAMES / 256;
-#ifndef ODDIO_PART_PAD
-#define ODDIO_PART_PAD 64
-#endif
-constexpr int PART_STRIDE = 2 * TILE_FRAMES + ODDIO_PART_PAD;   // floats between workgroup partial tiles: not a power of two, so that the reduce's
-                                                                 // column reads (one float per tile) spread over the memory channels
+// Workgroup partial sums: the callback's frames in blocks of PART_FRAMES; block fb holds every workgroup's [ear][PART_FRAMES] values
+// next to each other -- partials[(fb * n_wgs + wg) * PART_BLOCK + ear * PART_FRAMES + k] -- so that the reduce block of those
+// frames reads one contiguous stretch of n_wgs * 64 bytes.  (Rounds 1-4 kept one planar [ear][512] tile per workgroup: the
+// reduce then took 32 bytes from each of n_wgs rows 4 KB apart, a quarter of every line it touched -- 9.4 us for 1024 tiles,
+// 14 us for the 2048 of spatial_mix_pair.)
+constexpr int PART_FRAMES = 8;
+constexpr int PART_BLOCK = 2 * PART_FRAMES;
+constexpr int PART_STRIDE = 2 * TILE_FRAMES;   // floats of partial sums per workgroup and tile (allocation sizes)
 constexpr int WIN_CAP = 608;                 // samples staged per source and tile (ds <= ~1.11)
 constexpr int WIN_PIECES = (WIN_CAP * 4 + 1023) / 1024;   // 1 KiB DMA pieces covering a window buffer
 #ifndef ODDIO_PAD_EPS
@@ -523,7 +537,8 @@ __global__ __launch_bounds__(64) void cycle_scan(SceneParams P, const SrcStatic*
             const EarParams& ep = e ? e1 : e0;
             r.ear[e].ds = ds_e[e]; r.ear[e].g0 = ep.g0; r.ear[e].dg = ep.dg;
         }
-        bool staged = any && lin && lo <= hi;      // (hi may lie past the clip: reads of discarded frames, zero-filled by the descriptor)
+        bool staged = any && lin && lo <= hi && !s.fx;   // (hi may lie past the clip: reads of discarded frames, zero-filled by the descriptor;
+                                                         //  a soft-clipped Cycle keeps the row path: cycle_render applies the clip)
         if (staged) {
             const int ws = (int)(lo & ~3u);
             const int count = (int)hi + 2 - ws;
@@ -658,7 +673,7 @@ __global__ __launch_bounds__(64 * CYCLE_WAVES) void cycle_render(SceneParams P, 
 #pragma unroll
                 for (int k = 0; k < 16; ++k) {
                     float vv = a[k] + fract[k] * (b[k] - a[k]);                   // frame::lerp
-                    vv = vv * s.fixed_gain;                                       // FixedGain, gain.rs:32-37
+                    vv = apply_fx(vv, s.fixed_gain, s.fx);                        // FixedGain, gain.rs:32-37 (and the source's soft clip)
                     o[k] = vv * (ep.g0 + (float)(f0 + (uint32_t)k) * ep.dg);      // spatial.rs:459-460
                 }
                 if (cnt == 16u) {
@@ -806,12 +821,15 @@ __device__ __forceinline__ TileRec make_tile_rec(const SceneParams& P, const Src
             }
             if (!(fabsf((ep.dt * 255.0f) * s.freq_or_value) < 12000.0f)) small = false;     // (also false for NaN)
         }
-        if (small) r.info = PATH_SINE_INLINE;
+        if (small && !s.fx) r.info = PATH_SINE_INLINE;      // (a soft-clipped Sine: out of line, apply_fx)
         return r;
     }
     if (s.kind == KIND_CONSTANT) { r.info = PATH_CONST; return r; }
     if (s.kind == KIND_CYCLE) { r.info = PATH_ROW; return r; }
     if (s.kind != KIND_FRAMES && s.kind != KIND_DOWNMIX) { r.info = PATH_GENERIC; return r; }
+    // a per-source soft clip: Reinhard is rendered inline by the staged loops of the kernels that compile it in (P.dmx: the
+    // Downmix-capable instantiations; info bits 28-30 = SrcStatic::fx), Tanh by the exact per-lane path
+    if (s.fx && (!P.dmx || (s.fx & FX_TANH))) { r.info = PATH_GENERIC; return r; }
     // Downmix<FramesSignal<[f32;2]>> (downmix.rs:24-29 over frames.rs:176-201): the same cursor, the window holds interleaved
     // stereo frames -- `mul` floats per frame; always variant 2 of spatial_mix (sub-windows when the window is larger than the stage)
     const bool stereo = s.kind == KIND_DOWNMIX;
@@ -889,7 +907,7 @@ __device__ __forceinline__ TileRec make_tile_rec(const SceneParams& P, const Src
         fl &= ~SFLAG_PAD;
     }
     if (path != PATH_LDS) { r.info = (uint32_t)path; return r; }
-    if (s.fixed_gain != 1.0f) fl |= SFLAG_FG;
+    if (s.fixed_gain != 1.0f || s.fx) fl |= SFLAG_FG;
     const int nvec_all = (count + 3) >> 2;
     const int nvec = npass > 1 ? WIN_CAP / 4 : nvec_all;      // per DMA: a whole sub-window (the descriptor clips the last one)
     const int4 d = window_desc(s.clip, (int)((s.clip_len * (uint32_t)mul + 3u) & ~3u), ws * mul, nvec_all);
@@ -901,12 +919,115 @@ __device__ __forceinline__ TileRec make_tile_rec(const SceneParams& P, const Src
     (void)ODDIO_BOUNDS_CHECK(P.bounds_err, nvec >= 1 && nvec * 4 <= WIN_CAP && negvec >= 0 && negvec <= 255 && d.z >= 0 && d.z <= nvec_all * 16 &&
                              wbase[0][0] - ws >= 0 && (wbase[1][1] - ws) * mul <= 65535, BOUNDS_RECORD, nvec, tile);
     r.info = (uint32_t)path | ((uint32_t)fl << 3) | ((uint32_t)nvec << 8) | ((uint32_t)negvec << 16) | ((uint32_t)(npass > 1 ? npass : 0) << 24) |
-             ((uint32_t)(stereo ? 1 : 0) << 27);
+             ((uint32_t)(stereo ? 1 : 0) << 27) | ((uint32_t)s.fx << 28);
 #pragma unroll
     for (int e = 0; e < 2; ++e) {      // a chunk's base in floats from the window start
         const int w0 = min(max((wbase[e][0] - ws) * mul, 0), 65535), w1 = min(max((wbase[e][1] - ws) * mul, 0), 65535);
         r.ear[e].wrel = (uint32_t)w0 | ((uint32_t)w1 << 16);
     }
+    return r;
+}
+
+// The record of spatial_mix_pair (pair_kernels.h): make_tile_rec's set-up for the four chunks of a callback of up to 1024
+// frames at once, with ONE window -- every sample index the eight streams (2 ears x 4 chunks) can touch.  Sources the pair
+// kernel has no staged variant for (windows larger than its stage, stereo clips, absurd cursors) take its exact per-lane path.
+constexpr int PAIR_WIN_CAP = 1184;               // samples staged per source (ds <= ~1.11 over 1024 frames)
+constexpr int PAIR_CHUNKS = 4;
+__device__ __forceinline__ PairRec make_pair_rec(const SceneParams& P, const SrcStatic& s, const EarParams& e0, const EarParams& e1) {
+    PairRec r = {};                                  // info == 0: PATH_SKIP
+    if (e0.flags & EAR_SKIP) return r;
+    if (s.kind == KIND_SINE) {                       // (see make_tile_rec: the record carries what the inline Sine needs)
+        r.info = PATH_SINE;
+        r.desc[0] = __float_as_uint(s.freq_or_value); r.desc[1] = __float_as_uint(s.fixed_gain);
+        bool small = true;
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const EarParams& ep = e ? e1 : e0;
+            r.ear[e].ds = ep.dt; r.ear[e].g0 = ep.g0; r.ear[e].dg = ep.dg;
+            float ph = ep.phase_ear;
+#pragma unroll
+            for (int c = 0; c < PAIR_CHUNKS; ++c) {
+                r.ear[e].frac0[c] = ph;
+                ph = fmodf(ph + (ep.dt * 256.0f) * s.freq_or_value, ODDIO_TAU);      // sine.rs:39 per chunk
+            }
+            if (!(fabsf((ep.dt * 255.0f) * s.freq_or_value) < 12000.0f)) small = false;
+        }
+        if (small && !s.fx) r.info = PATH_SINE_INLINE;
+        return r;
+    }
+    if (s.kind == KIND_CONSTANT) { r.info = PATH_CONST; return r; }
+    if (s.kind == KIND_CYCLE) { r.info = PATH_ROW; return r; }
+    if (s.kind != KIND_FRAMES) { r.info = PATH_GENERIC; return r; }     // (Downmix: the exact per-lane path)
+    if (s.fx & FX_TANH) { r.info = PATH_GENERIC; return r; }            // (Reinhard is rendered inline: info bits 28-30 = SrcStatic::fx)
+    int lo = 0x7fffffff, hi = (int)0x80000000, generic = 0, fl = 0;
+    int wbase[2][PAIR_CHUNKS];
+    const double rate = (double)s.clip_rate;
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+        const EarParams& ep = e ? e1 : e0;
+        const float ds = ep.dt * (float)s.clip_rate;                                      // frames.rs:178
+        const float dev = fabsf(ds - 1.0f);
+        const bool fast = dev <= FLT_EPSILON;                                            // :180
+        if (fast) fl |= e ? SFLAG_FAST_R : SFLAG_FAST_L;
+        if (dev < PAD_EPS) fl |= SFLAG_PAD;
+        if (!(ds > 0.0f) || !(ds < 4096.0f)) generic = 1;
+        double t_c = ep.t_ear;
+#pragma unroll
+        for (int c = 0; c < PAIR_CHUNKS; ++c) {
+            const int rem = (int)P.n_frames - 256 * c;
+            const int len = rem < 0 ? 0 : (rem > 256 ? 256 : rem);
+            const double s0 = t_c * rate;                                                 // :177
+            const long long base = f64_as_isize(s0);                                      // :179
+            const float frac0 = (float)(s0 - (double)base);                               // :181 / :189
+            if (!(fabs(s0) < 1.0e9)) generic = 1;
+            if (frac0 < 0.0f) fl |= SFLAG_NEG;
+            wbase[e][c] = (int)base;
+            r.ear[e].frac0[c] = frac0;
+            if (len > 0 && !generic) {
+                int i0, i1;
+                if (fast) { i0 = (int)base; i1 = (int)base + 255; }
+                else {
+                    const float xb = frac0 + 255.0f * ds;
+                    const float xu = xb + fabsf(xb) * 1.0e-4f + 1.0e-2f;                  // >= the exactly rounded running sum
+                    if (!(xu < 8.0e6f)) generic = 1;
+                    i0 = (int)base + (int)frac0;
+                    i1 = (int)base + (int)xu;
+                }
+                lo = min(lo, min(i0, i1));
+                hi = max(hi, max(i0, i1));
+            }
+            t_c = t_c + (double)ep.dt * 256.0;                                            // frames.rs:198 per chunk
+        }
+        r.ear[e].ds = ds; r.ear[e].g0 = ep.g0; r.ear[e].dg = ep.dg;
+    }
+    const int ws = lo & ~3;
+    const int count = hi + 2 - ws;                   // floats
+    {   // the padded layout must fit the window buffer too (see make_tile_rec)
+        const int vec_samples = ((count + 3) >> 2) << 2;
+        if ((fl & SFLAG_PAD) && vec_samples + (vec_samples >> 4) + 1 > PAIR_WIN_CAP) {
+            if (fl & (SFLAG_FAST_L | SFLAG_FAST_R)) generic = 1;
+            else fl &= ~SFLAG_PAD;
+        }
+    }
+    int path;
+    if (generic) path = PATH_GENERIC;
+    else if (lo > hi) path = PATH_SKIP;
+    else if (count <= PAIR_WIN_CAP) path = PATH_LDS;
+    else path = PATH_GENERIC;                        // larger than the stage (resample ratios above ~1.11)
+    if (path != PATH_LDS) { r.info = (uint32_t)path; return r; }
+    if (s.fixed_gain != 1.0f || s.fx) fl |= SFLAG_FG;
+    const int nvec = (count + 3) >> 2;
+    const int4 d = window_desc(s.clip, (int)((s.clip_len + 3u) & ~3u), ws, nvec);
+    r.desc[0] = (uint32_t)d.x; r.desc[1] = (uint32_t)d.y; r.desc[2] = (uint32_t)d.z;
+    const int negvec = (d.z > 0) ? ((-d.w) >> 4) : 0;
+    if (negvec > 511) { r.info = (uint32_t)PATH_GENERIC; return r; }
+    (void)ODDIO_BOUNDS_CHECK(P.bounds_err, nvec >= 1 && nvec * 4 <= PAIR_WIN_CAP && negvec >= 0 && d.z >= 0 && d.z <= nvec * 16 &&
+                             wbase[0][0] - ws >= 0 && wbase[1][PAIR_CHUNKS - 1] - ws <= 65535, BOUNDS_RECORD, nvec, 0);
+    r.info = (uint32_t)path | ((uint32_t)fl << 3) | ((uint32_t)nvec << 8) | ((uint32_t)negvec << 17) | ((uint32_t)s.fx << 28);
+#pragma unroll
+    for (int e = 0; e < 2; ++e)
+#pragma unroll
+        for (int c = 0; c < PAIR_CHUNKS; ++c) r.ear[e].wrel[c] = (uint16_t)min(max(wbase[e][c] - ws, 0), 65535);
     return r;
 }
 
@@ -922,7 +1043,7 @@ __global__ __launch_bounds__(256) void spatial_prepass(SceneParams P, const SrcS
                                                        uint32_t* __restrict__ len_snap, TileRec* __restrict__ recs, uint32_t rec_stride,
                                                        uint32_t n_rec_tiles, int ear_always, uint32_t* __restrict__ cycle_list,
                                                        uint32_t* __restrict__ cycle_rlist, uint32_t cycle_par) {
-    __shared__ uint32_t stage[4][64 * 17];
+    __shared__ uint32_t stage[4][64 * (sizeof(PairRec) / 4 + 1)];
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     const int lane = threadIdx.x & 63;
     uint32_t* lds = stage[threadIdx.x >> 6];
@@ -942,6 +1063,12 @@ __global__ __launch_bounds__(256) void spatial_prepass(SceneParams P, const SrcS
         cycle_list[2u + k] = i;
     }
     bool needs_ear = false;
+    if (P.pair) {   // spatial_mix_pair's record: one per source for the whole callback
+        const PairRec r = make_pair_rec(P, s, ep.e[0], ep.e[1]);
+        const uint32_t path = r.info & 7u;
+        needs_ear = path != PATH_LDS && path != PATH_SKIP;
+        wave_aos_store(r, reinterpret_cast<PairRec*>(recs), first, n_valid, lane, lds);
+    } else
     for (uint32_t t = 0; t < n_rec_tiles; ++t) {
         const TileRec r = make_tile_rec(P, s, ep.e[0], ep.e[1], t);
         const uint32_t path = r.info & 7u;
@@ -1039,6 +1166,20 @@ __device__ __forceinline__ void window_repack_padded(unsigned char* win_bytes, i
     wave_sync();
 }
 
+// A per-source soft clip (apply_fx) in the staged-window loops: FX instantiations (the Downmix-capable spatial_mix kernels, spatial_mix_pair) render Reinhard
+// sources inline -- `fxk` is wave-uniform -- (Tanh sources take the exact per-lane path: the library's tanhf does not fit the loop)
+template <bool HAS_FG, bool FX>
+__device__ __forceinline__ float gain_or_fx(float v, float fixed_gain, int fxk) {
+    if (FX && fxk) {
+        if (!(fxk & FX_CLIP_FIRST)) v = v * fixed_gain;
+        v = v / (1.0f + fabsf(v));                            // reinhard.rs:32
+        if (fxk & FX_CLIP_FIRST) v = v * fixed_gain;
+        return v;
+    }
+    if (HAS_FG) v = v * fixed_gain;                           // gain.rs:32-37
+    return v;
+}
+
 // One source, staged-window path.  acc[i] += lerp * gain for this lane's ear (spatial.rs:458-462).
 // NONNEG: every cursor value of the source is >= 0, so fract(x) == x - trunc(x) (one v_fract_f32).
 // PAD: padded window layout (see above); also serves frames.rs:180-187's constant-fract path.
@@ -1064,12 +1205,17 @@ __device__ __forceinline__ void acc_add(float& acc, float v, float g, bool on) {
 }
 // ST (variant 2 only): `stereo` (wave-uniform) marks a window of interleaved stereo frames -- Downmix<FramesSignal<[f32;2]>>,
 // downmix.rs:24-29: each channel interpolated (frames.rs:180-196, incl. the constant-fract branch `fast`), then channels().sum().
-template <bool FULL, bool HAS_FG, bool NONNEG, bool PAD, bool FUSED, bool WRAP = false, bool ST = false>
+// RAMP1 (spatial_mix_pair's fused instantiations): the gain of frame i is fma(i, dg, fma(fi[0], dg, g0)) -- `i` a literal of the
+// unrolled loop -- instead of fma(fi[i], dg, g0): within an ulp of it, and the kernel keeps one `frame as f32` register, not 16.
+template <bool FULL, bool HAS_FG, bool NONNEG, bool PAD, bool FUSED, bool WRAP = false, bool ST = false, int CAP = WIN_CAP, bool FX = false, bool RAMP1 = false>
 __device__ __forceinline__ void mix_source_lds(const unsigned char* win_bytes, int wrel4, float x, int b, int fast, float frac0, float (&acc)[16],
                                                const float (&fi)[16], uint32_t frame0, uint32_t n_frames, float fixed_gain, float g0, float dg,
-                                               float ds, int win_samples, uint32_t* err, int ring_len = 0, int stereo = 0) {
+                                               float ds, int win_samples, uint32_t* err, int ring_len = 0, int stereo = 0, int fxk = 0) {
     if (!FULL && frame0 >= n_frames) return;   // this lane's 16 frames lie past the end of `out`
     const float* win = reinterpret_cast<const float*>(win_bytes);
+    static_assert(!RAMP1 || FUSED, "the two-step gain ramp is a FAST-mode form");
+    const float gbase = RAMP1 ? __builtin_fmaf(fi[0], dg, g0) : 0.0f;
+#define ODDIO_GAIN_AT(I) (RAMP1 ? __builtin_fmaf((float)(I), dg, gbase) : (FUSED ? __builtin_fmaf(fi[I], dg, g0) : g0 + fi[I] * dg))
     if (WRAP) {
         // Ring::sample (ring.rs:59-78) for a lane whose cursor may pass the ring's end: `x >= len` rewrites the cursor to
         // (x % len) + fract before the step.  The staged window is linear across the ring's end (the ring carries a mirror
@@ -1087,22 +1233,22 @@ __device__ __forceinline__ void mix_source_lds(const unsigned char* win_bytes, i
             x = x + ds;                                                        // :77
             asm volatile("" : "+v"(dg));
             const float v = FUSED ? __builtin_fmaf(fr, bb - a, a) : a + fr * (bb - a);
-            acc_add<FULL, FUSED>(acc[i], v, FUSED ? __builtin_fmaf(fi[i], dg, g0) : g0 + fi[i] * dg, frame0 + (uint32_t)i < n_frames);
+            acc_add<FULL, FUSED>(acc[i], v, ODDIO_GAIN_AT(i), frame0 + (uint32_t)i < n_frames);
         }
         return;
     }
     if (PAD && fast) {
         // frames.rs:180-187 (|ds - 1| <= EPSILON): constant fract, consecutive pairs
         const int w0 = (wrel4 >> 2) + 16 * b;
-        if (!ODDIO_BOUNDS_CHECK(err, w0 >= 0 && w0 + 16 < win_samples && (w0 + 16) + ((w0 + 16) >> 4) < WIN_CAP, BOUNDS_PAD_INDEX, w0, win_samples)) return;
+        if (!ODDIO_BOUNDS_CHECK(err, w0 >= 0 && w0 + 16 < win_samples && (w0 + 16) + ((w0 + 16) >> 4) < CAP, BOUNDS_PAD_INDEX, w0, win_samples)) return;
         float a = win[w0 + (w0 >> 4)];
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
             const int w1 = w0 + i + 1;
             const float bb = win[w1 + (w1 >> 4)];
             float v = FUSED ? __builtin_fmaf(frac0, bb - a, a) : a + frac0 * (bb - a);
-            if (HAS_FG) v = v * fixed_gain;
-            acc_add<FULL, FUSED>(acc[i], v, FUSED ? __builtin_fmaf(fi[i], dg, g0) : g0 + fi[i] * dg, frame0 + (uint32_t)i < n_frames);
+            v = gain_or_fx<HAS_FG, FX>(v, fixed_gain, fxk);
+            acc_add<FULL, FUSED>(acc[i], v, ODDIO_GAIN_AT(i), frame0 + (uint32_t)i < n_frames);
             a = bb;
         }
         return;
@@ -1129,8 +1275,8 @@ __device__ __forceinline__ void mix_source_lds(const unsigned char* win_bytes, i
             const float vl = FUSED ? __builtin_fmaf(f, l1 - l0, l0) : l0 + f * (l1 - l0);   // frame.rs:39-41 per channel
             const float vr = FUSED ? __builtin_fmaf(f, r1 - r0, r0) : r0 + f * (r1 - r0);
             float v = (0.0f + vl) + vr;                                        // downmix.rs:27-29: channels().sum() from 0.0
-            if (HAS_FG) v = v * fixed_gain;
-            acc_add<FULL, FUSED>(acc[i], v, FUSED ? __builtin_fmaf(fi[i], dg, g0) : g0 + fi[i] * dg, frame0 + (uint32_t)i < n_frames);
+            v = gain_or_fx<HAS_FG, FX>(v, fixed_gain, fxk);
+            acc_add<FULL, FUSED>(acc[i], v, ODDIO_GAIN_AT(i), frame0 + (uint32_t)i < n_frames);
             __builtin_amdgcn_sched_barrier(0);     // one frame at a time: the kernel has no registers to spare for reads hoisted across frames
         }
         return;
@@ -1143,7 +1289,7 @@ __device__ __forceinline__ void mix_source_lds(const unsigned char* win_bytes, i
         int w = tr;                                                                     \
         const bool in_ = ODDIO_BOUNDS_CHECK(err, wrel + tr >= 0 && wrel + tr + 1 < win_samples, BOUNDS_WINDOW_INDEX, wrel + tr, win_samples); \
         if (!in_) { a[I] = 0.0f; bb[I] = 0.0f; }                                        \
-        else if (PAD) { w = wrel + tr; w = w + (w >> 4); (void)ODDIO_BOUNDS_CHECK(err, w + 1 < WIN_CAP, BOUNDS_PAD_INDEX, w, win_samples); a[I] = win[w]; bb[I] = win[w + 1]; } \
+        else if (PAD) { w = wrel + tr; w = w + (w >> 4); (void)ODDIO_BOUNDS_CHECK(err, w + 1 < CAP, BOUNDS_PAD_INDEX, w, win_samples); a[I] = win[w]; bb[I] = win[w + 1]; } \
         else { a[I] = wbase[w]; bb[I] = wbase[w + 1]; }         /* one ds_read2_b32 */   \
         x = x + ds;                                             /* frames.rs:194 */      \
     }
@@ -1157,11 +1303,12 @@ __device__ __forceinline__ void mix_source_lds(const unsigned char* win_bytes, i
         // the instruction after it does not read dg (hipcc pads an asm statement whose output is read next with s_nop)
         asm volatile("" : "+v"(dg));
         float v = FUSED ? __builtin_fmaf(fr[i], bb[i] - a[i], a[i]) : a[i] + fr[i] * (bb[i] - a[i]);   // frame.rs:39-41 lerp (unfused in the exact kernels)
-        if (HAS_FG) v = v * fixed_gain;                       // gain.rs:32-37
-        acc_add<FULL, FUSED>(acc[i], v, FUSED ? __builtin_fmaf(fi[i], dg, g0) : g0 + fi[i] * dg, frame0 + (uint32_t)i < n_frames);   // spatial.rs:459-460
+        v = gain_or_fx<HAS_FG, FX>(v, fixed_gain, fxk);                       // gain.rs:32-37
+        acc_add<FULL, FUSED>(acc[i], v, ODDIO_GAIN_AT(i), frame0 + (uint32_t)i < n_frames);   // spatial.rs:459-460
         __builtin_amdgcn_sched_barrier(0);
     }
 #undef ODDIO_ISSUE
+#undef ODDIO_GAIN_AT
 }
 
 // sin(x) for |x| < ~12 600: three-constant Cody-Waite reduction by 2 pi (exact products for |k| <= 2^11), a fold to
@@ -1215,10 +1362,10 @@ constexpr int GEN_BATCH = 2;   // frames whose loads are in flight together in t
 // parked in LDS (slot i of lane l at acc_lds[i * PARK_STRIDE + l]) so that their register needs (sinf range
 // reduction, 64-bit indices) do not inflate the hot kernel's allocation.  They fetch the source's
 // parameters from global memory themselves.
-__device__ __noinline__ void mix_source_rare(float* acc_lds, int lane, uint32_t frame0, uint32_t n_frames, uint32_t c_abs, int path,
-                                             const SrcStatic* __restrict__ st, const EarParams* __restrict__ ear, uint32_t src,
-                                             const float* cycle_rows, uint32_t cycle_plane) {
-    const int b = lane & 15, eB = lane >> 5;
+__device__ __forceinline__ void mix_source_rare_body(float* acc_lds, int lane, uint32_t frame0, uint32_t n_frames, uint32_t c_abs, int path,
+                                                     const SrcStatic* __restrict__ st, const EarParams* __restrict__ ear, uint32_t src,
+                                                     const float* cycle_rows, uint32_t cycle_plane, const int eB) {
+    const int b = lane & 15;
     const SrcStatic s = st[src];
     const EarParams ep = ear[2 * src + eB];
     const float fbase = (float)frame0;
@@ -1253,7 +1400,7 @@ __device__ __noinline__ void mix_source_rare(float* acc_lds, int lane, uint32_t 
             } else {
                 v = s.freq_or_value;
             }
-            v = v * fixed_gain;
+            v = apply_fx(v, fixed_gain, s.fx);
             const float p = v * (g0 + (fbase + (float)i) * dg);
             if (frame0 + (uint32_t)i < n_frames) acc_lds[i * PARK_STRIDE + lane] = acc_lds[i * PARK_STRIDE + lane] + p;
         }
@@ -1319,12 +1466,25 @@ __device__ __noinline__ void mix_source_rare(float* acc_lds, int lane, uint32_t 
         for (int k = 0; k < GEN_BATCH; ++k) {
             const int i = i0 + k;
             const uint32_t f = chunk0 + 16u * (uint32_t)i + (uint32_t)b;
-            const float vg = v[k] * fixed_gain;
+            const float vg = apply_fx(v[k], fixed_gain, s.fx);
             const float p = vg * (g0 + (float)f * dg);
             float* slot = acc_lds + b * PARK_STRIDE + ((lane & ~15) | i);
             if (f < n_frames) *slot = *slot + p;
         }
     }
+}
+
+// spatial_mix: lanes 0-31 are the left ear, 32-63 the right ear
+__device__ __noinline__ void mix_source_rare(float* acc_lds, int lane, uint32_t frame0, uint32_t n_frames, uint32_t c_abs, int path,
+                                             const SrcStatic* __restrict__ st, const EarParams* __restrict__ ear, uint32_t src,
+                                             const float* cycle_rows, uint32_t cycle_plane) {
+    mix_source_rare_body(acc_lds, lane, frame0, n_frames, c_abs, path, st, ear, src, cycle_rows, cycle_plane, lane >> 5);
+}
+// spatial_mix_pair: the whole wavefront renders ear `eB`
+__device__ __noinline__ void mix_source_rare_ear(float* acc_lds, int lane, uint32_t frame0, uint32_t n_frames, uint32_t c_abs, int path,
+                                                 const SrcStatic* __restrict__ st, const EarParams* __restrict__ ear, uint32_t src,
+                                                 const float* cycle_rows, uint32_t cycle_plane, int eB) {
+    mix_source_rare_body(acc_lds, lane, frame0, n_frames, c_abs, path, st, ear, src, cycle_rows, cycle_plane, eB);
 }
 
 // RING: a buffered source that the general kernel rendered (buffered_sources_wave: every shape the fast path does not
@@ -1600,7 +1760,8 @@ __global__ __launch_bounds__(64 * MIX_WG_WAVES, MIX_WAVES_PER_SIMD) void spatial
             const float frac0_ = reinterpret_cast<const float*>(blkB0 + cur * BLK_SRC)[0];   /* checkpoint 0 */           \
             const int fast_e = eB ? (flags_j & SFLAG_FAST_R) : (flags_j & SFLAG_FAST_L);                                  \
             window_repack_padded(win_bytes, (int)((cur_info >> 8) & 255u), lane, P.bounds_err);                                         \
-            mix_source_lds<FULL, true, false, true, FUSED>(win_bytes, wrel4, cx0, bB, fast_e, frac0_, acc, fi, frame0, n_frames, fg, ct.y, ct.z, ct.w, 4 * (int)((cur_info >> 8) & 255u), P.bounds_err); \
+            mix_source_lds<FULL, true, false, true, FUSED, false, false, WIN_CAP, DMX>(win_bytes, wrel4, cx0, bB, fast_e, frac0_, acc, fi, frame0, n_frames, fg, ct.y, ct.z, ct.w, 4 * (int)((cur_info >> 8) & 255u), P.bounds_err, 0, 0, \
+                                                                                         (DMX && !RING) ? (int)((cur_info >> 28) & 7u) : 0); \
         } else if (var_j == 0) {                                                                                          \
             mix_source_lds<FULL, false, true, false, FUSED>(win_bytes, wrel4, cx0, bB, 0, 0.0f, acc, fi, frame0, n_frames, 1.0f, ct.y, ct.z, ct.w, 4 * (int)((cur_info >> 8) & 255u), P.bounds_err); \
         } else {                                                                                                          \
@@ -1616,8 +1777,8 @@ __global__ __launch_bounds__(64 * MIX_WG_WAVES, MIX_WAVES_PER_SIMD) void spatial
                 on_ = lp_ == mpass;                                                                                       \
                 w4_ = wrel4 - 4 * MULTI_STRIDE * mpass;                                                                   \
             }                                                                                                             \
-            if (on_) mix_source_lds<FULL, true, false, false, FUSED, false, DMX>(win_bytes, w4_, cx0, bB, fast_s, frac0_s, acc, fi, frame0, n_frames, fg, ct.y, ct.z, ct.w, \
-                                                                                   4 * (int)((cur_info >> 8) & 255u), P.bounds_err, 0, stereo_); \
+            if (on_) mix_source_lds<FULL, true, false, false, FUSED, false, DMX, WIN_CAP, DMX>(win_bytes, w4_, cx0, bB, fast_s, frac0_s, acc, fi, frame0, n_frames, fg, ct.y, ct.z, ct.w, \
+                                                                                   4 * (int)((cur_info >> 8) & 255u), P.bounds_err, 0, stereo_, (DMX && !RING) ? (int)((cur_info >> 28) & 7u) : 0); \
         }                                                                                                                 \
         buf ^= 1;                                                                                                         \
         if (more_) ++mpass;                                                                                               \
@@ -1715,10 +1876,12 @@ __global__ __launch_bounds__(64 * MIX_WG_WAVES, MIX_WAVES_PER_SIMD) void spatial
     // (addresses derived from an opaque copy of the lane index: computed here, not carried through the walk in VGPRs)
     int le = threadIdx.x & 63;
     asm volatile("" : "+v"(le));
-    float* dst = partials + ((size_t)tile * gridDim.x + blockIdx.x) * PART_STRIDE + (size_t)(le >> 5) * TILE_FRAMES + 16 * (le & 31);
+    // the lane's 16 frames are two blocks of PART_FRAMES frames: partials[(block * n_wgs + wg) * PART_BLOCK + ear * PART_FRAMES + k]
+    float* dst = partials + (((size_t)tile * (TILE_FRAMES / PART_FRAMES) + 2u * (uint32_t)(le & 31)) * gridDim.x + blockIdx.x) * PART_BLOCK + (size_t)(le >> 5) * PART_FRAMES;
+    const size_t dst_step = (size_t)gridDim.x * PART_BLOCK;      // to the lane's second block
     if (MIX_WG_WAVES == 1) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) reinterpret_cast<float4*>(dst)[q] = make_float4(acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]);
+        for (int q = 0; q < 4; ++q) reinterpret_cast<float4*>(dst + (q >> 1) * dst_step)[q & 1] = make_float4(acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]);
         return;
     }
     __syncthreads();   // every wave is done with its slice
@@ -1736,7 +1899,7 @@ __global__ __launch_bounds__(64 * MIX_WG_WAVES, MIX_WAVES_PER_SIMD) void spatial
             for (int k = 0; k < 16; ++k) acc[k] = acc[k] + other[k * 64 + le];
         }
 #pragma unroll
-        for (int q = 0; q < 4; ++q) reinterpret_cast<float4*>(dst)[q] = make_float4(acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]);
+        for (int q = 0; q < 4; ++q) reinterpret_cast<float4*>(dst + (q >> 1) * dst_step)[q & 1] = make_float4(acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]);
     }
 }
 
@@ -1759,16 +1922,20 @@ constexpr int RED_BATCH = 32;    // loads in flight per thread
 // (segment s adds workgroups s, s+16, ... in ascending order; the 16 segment sums are then added in
 // ascending order), applies Reinhard / Tanh and writes the interleaved stereo frames.  With n_wgs == 1
 // (ORDERED mode) the output is that workgroup's value unchanged.
+// SEGS: 16 (256 threads), or 32 (512 threads) for the 2048 partial tiles per tile that spatial_mix_pair leaves -- twice the
+// data with the same ~64 loads per thread.
+template <int SEGS = RED_SEGS>
 __device__ __forceinline__ void reduce_partials_body(const float* __restrict__ partials, float* __restrict__ out, uint32_t n_wgs,
                                                      uint32_t n_frames, int postfx, uint32_t block) {
+    constexpr int RED_SEGS = SEGS;     // (shadows the default for the code below)
     __shared__ float red[RED_SEGS][2 * RED_FRAMES];
     const uint32_t ox = threadIdx.x & (2 * RED_FRAMES - 1), seg = threadIdx.x / (2 * RED_FRAMES);
     const uint32_t e = ox / RED_FRAMES;
     const uint32_t f = block * RED_FRAMES + (ox % RED_FRAMES);      // output frame
-    const uint32_t tile = f / TILE_FRAMES, fin = f % TILE_FRAMES;
+    static_assert(RED_FRAMES == PART_FRAMES, "a reduce block sums one block of the partial sums");
     float s = 0.0f;
     if (f < n_frames) {
-        const float* p = partials + (size_t)tile * n_wgs * PART_STRIDE + (size_t)e * TILE_FRAMES + fin;
+        const float* p = partials + (size_t)block * n_wgs * PART_BLOCK + ox;      // (ox == e * PART_FRAMES + frame in block)
         // the first addend is taken as is (0.0f + x would turn a -0.0 into +0.0); the rest in batches whose loads
         // are all in flight together (the partials were just written by other XCDs: every load is a ~1 us miss)
         bool first = true;
@@ -1777,7 +1944,7 @@ __device__ __forceinline__ void reduce_partials_body(const float* __restrict__ p
 #pragma unroll
             for (int k = 0; k < RED_BATCH; ++k) {
                 const uint32_t wk = w + (uint32_t)k * RED_SEGS;
-                v[k] = wk < n_wgs ? p[(size_t)wk * PART_STRIDE] : 0.0f;
+                v[k] = wk < n_wgs ? p[(size_t)wk * PART_BLOCK] : 0.0f;
             }
 #pragma unroll
             for (int k = 0; k < RED_BATCH; ++k)

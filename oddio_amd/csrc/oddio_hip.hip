@@ -24,6 +24,7 @@
 
 #include "../../include/oddio_hip.h"
 #include "kernels.h"
+#include "pair_kernels.h"
 #include "mixer_kernels.h"
 #include "buffered_kernels.h"
 #include "buffered_fast.h"

@@ -1,0 +1,319 @@
+// pair_kernels.h -- spatial_mix_pair: the Seek-set mix kernel of large FAST-mode scenes (gfx950, wave64).
+//
+// spatial_mix (kernels.h) renders a 512-frame tile per wavefront, both ears: every source's window crosses HBM -> LDS twice
+// per 1024-frame callback (once per tile, 2.3 KB each, with the ~40 samples the two tiles' windows share read twice), and
+// every wavefront issues the three DMA instructions of its own window.  Measured (profiles/r05_*): with all windows
+// served from L2 the kernel takes 0.203 ms, from HBM 0.216-0.219; random 2.3 KB reads reach 5.4-5.6 TB/s on this part,
+// 4.3 KB reads 5.8-5.9.
+//
+// Here a WORKGROUP of two wavefronts renders the whole callback (up to 1024 frames = four 256-frame chunks,
+// spatial.rs:393,456) of its sources, wave 0 the left ear and wave 1 the right: the source's window -- every sample both
+// ears touch in the callback, ~4.3 KB -- is staged ONCE, each wave issuing half of its 1 KiB DMA pieces, and an s_barrier
+// per source hands the two halves over (and frees the other window buffer for the next source).  Lane l of a wave owns
+// the 16 consecutive frames 16 l .. 16 l + 15 of its ear (chunk l >> 4, block l & 15): the same 16 register
+// accumulators, checkpointed exact cursor scan (frames.rs:189-196) and per-sample loop (mix_source_lds) as spatial_mix.
+// The two waves write disjoint halves of the workgroup's partial tiles; no cross-wave sum.
+//
+// Per source the walk leaves one 96-byte PairRec (make_pair_rec) instead of two 64-byte TileRecs.
+// LDS per workgroup: two window buffers of PAIR_WIN_CAP samples + one 5 KB block of stream checkpoints per wave
+// = 19 712 B -> 8 workgroups = 16 waves per CU, the occupancy of spatial_mix.
+//
+// Used for FAST / FAST_UNFUSED callbacks of 513..1024 frames over scenes large enough to give every workgroup of a full
+// chip at least one group of 16 sources (scene_host.inc); everything else keeps spatial_mix.  Sources without a staged
+// variant here (windows beyond the stage, Downmix, Sine, Constant, Cycle rows) run out of line on parked accumulators,
+// exactly as in spatial_mix.
+#pragma once
+#include "kernels.h"
+
+namespace oddio_hip {
+
+constexpr int PAIR_WIN_BYTES = PAIR_WIN_CAP * 4;
+constexpr int PAIR_LDS_WIN0 = 0;
+constexpr int PAIR_LDS_WIN1 = PAIR_WIN_BYTES;
+constexpr int PAIR_LDS_STREAM = 2 * PAIR_WIN_BYTES;
+constexpr int PAIR_STREAM_BYTES = 64 * STREAM_WORDS * 4;                  // one wave's 64 stream blocks
+constexpr int PAIR_LDS_TOTAL = PAIR_LDS_STREAM + 2 * PAIR_STREAM_BYTES;
+constexpr int PAIR_TAIL_LANES = (PAIR_WIN_BYTES - 4096) / 16;             // lanes of the fifth 1 KiB piece that stay inside the window buffer
+static_assert(PAIR_WIN_BYTES % 16 == 0 && PAIR_LDS_TOTAL % 16 == 0, "16-byte aligned window buffers and stream blocks");
+static_assert(PAIR_LDS_TOTAL * 8 <= 160 * 1024, "8 workgroups (16 waves) per CU");
+static_assert(16 * PARK_STRIDE * 4 <= PAIR_WIN_BYTES, "a wave parks its accumulators in one window buffer");
+static_assert(PAIR_WIN_BYTES > 4096 && PAIR_WIN_BYTES <= 5120 && PAIR_TAIL_LANES > 0 && PAIR_TAIL_LANES <= 64, "five 1 KiB pieces cover a window buffer");
+
+// s_barrier of the two waves with the LDS hand-over made explicit for the compiler (the builtin alone is not a memory barrier)
+__device__ __forceinline__ void pair_barrier() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
+// HBM -> LDS, this wave's half of a source's window: the 1 KiB pieces first, first + 2 (and 4 when first == 0) through the
+// bounds-checked descriptor of the PairRec (window_desc: lanes outside the clip get zeros, frames.rs:105-123).
+// The instruction offset moves the global and the LDS address alike (see window_dma).
+__device__ __forceinline__ void pair_window_dma(uint32_t lds_dst, uint32_t d0, uint32_t d1, uint32_t d2, uint32_t info, int lane16, int first) {
+    u32x4 rsrc;
+    rsrc.x = d0; rsrc.y = d1; rsrc.z = d2;
+    rsrc.w = 0x00020000u;
+    const int nvec = (int)((info >> 8) & 511u);
+    const int neg = -16 * (int)((info >> 17) & 511u);
+#ifdef ODDIO_HIP_BOUNDS
+    if (nvec * 16 > PAIR_WIN_BYTES || (int)d2 > nvec * 16 + neg + 16) asm volatile("s_trap 2");
+#endif
+    const int voff = neg + lane16 + 1024 * first;
+    const uint32_t m0v = lds_dst + 1024u * (uint32_t)first;
+    uint32_t keep;
+    // (pieces 0-3 from every lane: lanes past the window write zeros inside the buffer, no traffic)
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 4\n\t"
+                 "buffer_load_dwordx4 %1, %2, 0 offen" ODDIO_WIN_POLICY " lds\n\tbuffer_load_dwordx4 %1, %2, 0 offen offset:2048" ODDIO_WIN_POLICY " lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(rsrc), "s"(m0v) : "memory");
+    if (first == 0 && nvec > 256) {
+        if (lane16 < 16 * PAIR_TAIL_LANES)
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen" ODDIO_WIN_POLICY " lds\n\ts_mov_b32 m0, %0"
+                         : "=&s"(keep) : "v"(voff + 4096), "s"(rsrc), "s"(m0v + 4096u) : "memory");
+    }
+}
+
+// Near-unit sources: plain -> padded layout in place (window_repack_padded), the two waves of the workgroup together:
+// wave w moves the 16-byte vectors of the 1 KiB pieces w, w + 2, w + 4.  Every read of either wave precedes every write.
+__device__ __forceinline__ void pair_repack_padded(unsigned char* win_bytes, int nvec, int lane, int wv, uint32_t* err) {
+    asm volatile("" : "+v"(lane));
+    u32x4 v[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const int q = lane + 64 * (2 * k + wv);
+        v[k] = (q < nvec) ? *reinterpret_cast<const u32x4*>(win_bytes + 16 * q) : u32x4{0u, 0u, 0u, 0u};
+    }
+    pair_barrier();
+    unsigned int* win = reinterpret_cast<unsigned int*>(win_bytes);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const int q = lane + 64 * (2 * k + wv);
+        if (q < nvec) {
+            const int li = 4 * q;
+            const int pos = li + (li >> 4);
+            if (!ODDIO_BOUNDS_CHECK(err, pos + 3 < PAIR_WIN_CAP, BOUNDS_REPACK, pos, nvec)) continue;
+            win[pos + 0] = v[k].x; win[pos + 1] = v[k].y; win[pos + 2] = v[k].z; win[pos + 3] = v[k].w;
+            if ((li & 15) == 0 && li > 0) win[pos - 1] = v[k].x;
+        }
+    }
+    pair_barrier();
+}
+
+// grid = workgroups; block = 128 (wave 0: left ear, wave 1: right ear).  Workgroup w walks groups [g_lo, g_hi) of 16 slots
+// in DESCENDING order (the reference's reverse set walk, spatial.rs:204) and leaves its partial sums in spatial_mix's
+// layout (kernels.h PART_BLOCK) for reduce_partials.
+template <bool FULL, bool FUSED>
+__global__ __launch_bounds__(128, MIX_WAVES_PER_SIMD) void spatial_mix_pair(SceneParams P, const SrcStatic* __restrict__ st,
+                                                                            const EarParams* __restrict__ ear, const PairRec* __restrict__ recs,
+                                                                            float* __restrict__ partials, const float* __restrict__ init,
+                                                                            uint32_t groups_per_wg, uint32_t n_groups,
+                                                                            const uint32_t* __restrict__ n_sources_ptr) {
+    __shared__ __attribute__((aligned(16))) unsigned char smem[PAIR_LDS_TOTAL];
+    const uint32_t n_sources = *n_sources_ptr;
+    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));       // this wave's ear
+    const uint32_t lds_base = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uintptr_t)smem);
+    const int lane = threadIdx.x & 63;
+    const int lane16 = 16 * lane;
+    const uint32_t n_frames = P.n_frames;
+    float acc[16], fi[16];
+    // phase-B role: chunk c, block b -> the 16 consecutive frames 256 c + 16 b ..
+    const int cB = lane >> 4, bB = lane & 15;
+    const uint32_t frame0 = 16u * (uint32_t)lane;
+    const float fbase = (float)frame0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) { acc[k] = 0.0f; fi[k] = fbase + (float)k; }   // `i as f32` (spatial.rs:459)
+    if (init != nullptr && blockIdx.x == 0) {
+        // the buffered set is walked before the seekable one (spatial.rs:395-438): its sum is what the first source is added to
+#pragma unroll
+        for (int k = 0; k < 16; ++k)
+            if (frame0 + (uint32_t)k < n_frames) acc[k] = init[2 * (frame0 + (uint32_t)k) + (uint32_t)wv];
+    }
+    const uint32_t g_lo = blockIdx.x * groups_per_wg;
+    uint32_t g_hi = g_lo + groups_per_wg;
+    if (g_hi > n_groups) g_hi = n_groups;
+
+    unsigned char* const sbase = smem + PAIR_LDS_STREAM + wv * PAIR_STREAM_BYTES;   // this wave's stream blocks: block 4 j + c
+    unsigned char* const blkB0 = sbase + cB * (STREAM_WORDS * 4);
+    constexpr int BLK_SRC = 4 * STREAM_WORDS * 4;
+
+    // The records of a group -- lanes 0-15: {descriptor words, info} of source `lane`; lane (j, c): {ds, g0, dg} of this
+    // wave's ear, the chunk's frac0 and wrel -- are fetched one group ahead (see spatial_mix).
+#define PAIR_LOAD_GROUP(GG, V, Q, F, W)                                                                                   \
+    {                                                                                                                     \
+        int la_ = lane;                                                                                                   \
+        asm volatile("" : "+v"(la_));                                                                                     \
+        const PairRec* __restrict__ grec_ = recs + (size_t)(GG) * MIX_GROUP;                                              \
+        V = make_uint4(0u, 0u, 0u, 0u); Q = f4u{0.0f, 0.0f, 0.0f, 0.0f}; F = 0.0f; W = 0u;                                \
+        if (la_ < MIX_GROUP && (GG) * MIX_GROUP + (uint32_t)la_ < n_sources) V = *reinterpret_cast<const uint4*>(grec_ + la_); \
+        if ((GG) * MIX_GROUP + (uint32_t)(la_ >> 2) < n_sources) {                                                        \
+            const PairEar* pe_ = &grec_[la_ >> 2].ear[wv];                                                                \
+            Q = *reinterpret_cast<const f4u*>(pe_);                              /* {ds, g0, dg, .} */                    \
+            F = pe_->frac0[la_ & 3];                                                                                      \
+            W = (uint32_t)pe_->wrel[la_ & 3];                                                                             \
+        }                                                                                                                 \
+    }
+    uint4 pv = make_uint4(0u, 0u, 0u, 0u);
+    f4u pq = {0.0f, 0.0f, 0.0f, 0.0f};
+    float pf = 0.0f;
+    uint32_t pw = 0u;
+    if (g_hi > g_lo) PAIR_LOAD_GROUP(g_hi - 1u, pv, pq, pf, pw)
+    int buf = 0;
+    bool pre_issued = false;     // the last source of the previous group already started this group's first window
+    for (uint32_t g = g_hi; g-- > g_lo;) {
+        // ------------------------------ phase A ------------------------------
+        const uint4 vdesc = pv;
+        const f4u q = pq;
+        const float frac0 = pf;
+        const uint32_t wr0 = pw;
+        bool need_prefetch = g > g_lo;
+        int laneA = lane;
+        asm volatile("" : "+v"(laneA));
+        const int pj = (int)(vdesc.w & 7u);
+        const unsigned lds_mask = (unsigned)__ballot(laneA < MIX_GROUP && pj == PATH_LDS) & 0xffffu;
+        const unsigned rare_mask = (unsigned)__ballot(laneA < MIX_GROUP && pj != PATH_LDS && pj != PATH_SKIP) & 0xffffu;
+        int cur = lds_mask ? 31 - __builtin_clz(lds_mask) : -1;
+        uint32_t cur_info = 0;
+#define PAIR_ISSUE_WINDOW_OF(VD, JN, BUF)                                                                                 \
+    pair_window_dma(lds_base + (uint32_t)((BUF) ? PAIR_LDS_WIN1 : PAIR_LDS_WIN0), (uint32_t)__builtin_amdgcn_readlane((int)(VD).x, (JN)), \
+                    (uint32_t)__builtin_amdgcn_readlane((int)(VD).y, (JN)), (uint32_t)__builtin_amdgcn_readlane((int)(VD).z, (JN)), \
+                    (uint32_t)__builtin_amdgcn_readlane((int)(VD).w, (JN)), lane16, wv ^ ((JN) & 1));
+#define PAIR_ISSUE_WINDOW(JN, BUF) PAIR_ISSUE_WINDOW_OF(vdesc, JN, BUF)
+        if (cur >= 0) {   // the first window is on its way while the cursors are scanned
+            cur_info = (uint32_t)__builtin_amdgcn_readlane((int)vdesc.w, cur);
+            if (!pre_issued) PAIR_ISSUE_WINDOW(cur, buf)
+        }
+        pre_issued = false;
+        {
+            // exact f32 cursor scan (frames.rs:189-196) of stream (source j = lane >> 2, chunk c = lane & 3) of this wave's ear
+            float* blk = reinterpret_cast<float*>(sbase + laneA * (STREAM_WORDS * 4));
+            const float ds = q.x;
+            float x = frac0;
+#pragma unroll 1
+            for (int b = 0; b < 15; ++b) {
+                blk[b] = x;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) x = x + ds;
+            }
+            blk[15] = x;
+            *reinterpret_cast<float4*>(blk + 16) = make_float4(__uint_as_float(4u * wr0), q.y, q.z, q.x);
+        }
+        wave_sync();
+
+        // ------------------------------ phase B ------------------------------
+        float cx0 = 0.0f;
+        float4 ct = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+#define PAIR_LANE_DATA(J, X0, T)                                                                                          \
+    {                                                                                                                     \
+        const unsigned char* blk_ = blkB0 + (J) * BLK_SRC;                                                                \
+        X0 = reinterpret_cast<const float*>(blk_)[bB];                                                                    \
+        T = *reinterpret_cast<const float4*>(blk_ + 64);                                                                  \
+    }
+        if (cur >= 0) PAIR_LANE_DATA(cur, cx0, ct)
+        // VAR: 0 the common source, 1 padded layout (resample ratio within PAD_EPS of 1), 2 FixedGain and/or a cursor that starts negative
+#define PAIR_VARIANT(INFO) ((((INFO) >> 3) & SFLAG_PAD) ? 1 : ((((INFO) >> 3) & (SFLAG_FG | SFLAG_NEG)) ? 2 : 0))
+#define PAIR_STAGED_SOURCE(VAR, PRE)                                                                                      \
+    {                                                                                                                     \
+        const int flags_j = (int)((cur_info >> 3) & 31u);                                                                 \
+        unsigned char* win_bytes = smem + (buf ? PAIR_LDS_WIN1 : PAIR_LDS_WIN0);                                          \
+        const int nvec_j = (int)((cur_info >> 8) & 511u);                                                                 \
+        window_wait();                                    /* this wave's half of the window has landed */                 \
+        pair_barrier();                                   /* ... and the other wave's; both are done with the other buffer */ \
+        asm volatile("" : "+v"(pv.x), "+v"(pv.y), "+v"(pv.z), "+v"(pv.w), "+v"(pq.x), "+v"(pq.y), "+v"(pq.z), "+v"(pq.w), "+v"(pf), "+v"(pw)); \
+        const bool fetched_before = !need_prefetch;                                                                       \
+        if (need_prefetch) { PAIR_LOAD_GROUP(g - 1u, pv, pq, pf, pw) need_prefetch = false; }                             \
+        const unsigned below = lds_mask & ((1u << cur) - 1u);                                                             \
+        const int nxt = below ? 31 - __builtin_clz(below) : -1;                                                           \
+        uint32_t nxt_info = 0;                                                                                            \
+        float nx0 = 0.0f;                                                                                                 \
+        float4 nt = make_float4(0.0f, 0.0f, 0.0f, 0.0f);                                                                  \
+        if (nxt >= 0) {          /* start the next staged source of this group; lands while we compute */                \
+            nxt_info = (uint32_t)__builtin_amdgcn_readlane((int)vdesc.w, nxt);                                            \
+            PAIR_ISSUE_WINDOW(nxt, buf ^ 1)                                                                               \
+            PAIR_LANE_DATA(nxt, nx0, nt)                                                                                  \
+        } else if ((PRE) && g > g_lo && fetched_before) {                                                                 \
+            /* last staged source of the group: the other window buffer is free for the next group's first window */     \
+            int lb_ = lane;                                                                                               \
+            asm volatile("" : "+v"(lb_));                                                                                 \
+            const unsigned nm_ = (unsigned)__ballot(lb_ < MIX_GROUP && (int)(pv.w & 7u) == PATH_LDS) & 0xffffu;           \
+            if (nm_) { PAIR_ISSUE_WINDOW_OF(pv, 31 - __builtin_clz(nm_), buf ^ 1) pre_issued = true; }                    \
+        }                                                                                                                 \
+        const int wrel4 = __float_as_int(ct.x);                                                                           \
+        if ((VAR) == 1) {                                                                                                 \
+            const float fg = (flags_j & SFLAG_FG) ? st[g * MIX_GROUP + (uint32_t)cur].fixed_gain : 1.0f;   /* v * 1.0 == v */ \
+            const float frac0_ = reinterpret_cast<const float*>(blkB0 + cur * BLK_SRC)[0];   /* checkpoint 0 */           \
+            const int fast_e = wv ? (flags_j & SFLAG_FAST_R) : (flags_j & SFLAG_FAST_L);                                  \
+            pair_repack_padded(win_bytes, nvec_j, lane, wv, P.bounds_err);                                                \
+            mix_source_lds<FULL, true, false, true, FUSED, false, false, PAIR_WIN_CAP, true, FUSED>(win_bytes, wrel4, cx0, bB, fast_e, frac0_, acc, fi, frame0, n_frames, fg, ct.y, ct.z, ct.w, 4 * nvec_j, P.bounds_err, \
+                                                                                             0, 0, (int)((cur_info >> 28) & 7u)); \
+        } else if ((VAR) == 0) {                                                                                          \
+            mix_source_lds<FULL, false, true, false, FUSED, false, false, PAIR_WIN_CAP, false, FUSED>(win_bytes, wrel4, cx0, bB, 0, 0.0f, acc, fi, frame0, n_frames, 1.0f, ct.y, ct.z, ct.w, 4 * nvec_j, P.bounds_err); \
+        } else {                                                                                                          \
+            const float fg = (flags_j & SFLAG_FG) ? st[g * MIX_GROUP + (uint32_t)cur].fixed_gain : 1.0f;                  \
+            mix_source_lds<FULL, true, false, false, FUSED, false, false, PAIR_WIN_CAP, true, FUSED>(win_bytes, wrel4, cx0, bB, 0, 0.0f, acc, fi, frame0, n_frames, fg, ct.y, ct.z, ct.w, 4 * nvec_j, P.bounds_err, \
+                                                                                              0, 0, (int)((cur_info >> 28) & 7u)); \
+        }                                                                                                                 \
+        buf ^= 1;                                                                                                         \
+        cur = nxt; cur_info = nxt_info; cx0 = nx0; ct = nt;                                                               \
+    }
+        // rare path: both waves park their accumulators (wave w over window buffer w: a window in flight is awaited first and
+        // fetched again afterwards), run out of line, fetch them back
+#define PAIR_RARE_SOURCE(J)                                                                                               \
+    {                                                                                                                     \
+        const int path_j = __builtin_amdgcn_readlane((int)vdesc.w, (J)) & 7;                                              \
+        float* park = reinterpret_cast<float*>(smem + wv * PAIR_WIN_BYTES);                                               \
+        float ph_ = 0.0f;                                                                                                 \
+        float4 t_ = make_float4(0.0f, 0.0f, 0.0f, 0.0f);                                                                  \
+        if (path_j == PATH_SINE_INLINE) { PAIR_LANE_DATA((J), ph_, t_) ph_ = reinterpret_cast<const float*>(blkB0 + (J) * BLK_SRC)[0]; } \
+        window_wait();                                                                                                    \
+        pair_barrier();                                   /* no window DMA of either wave is in flight any more */       \
+        _Pragma("unroll") for (int k = 0; k < 16; ++k) park[k * PARK_STRIDE + lane] = acc[k];                             \
+        wave_sync();                                                                                                      \
+        if (path_j == PATH_SINE_INLINE)                                                                                   \
+            mix_source_sine(park, lane, frame0, n_frames, ph_, t_.w, __int_as_float(__builtin_amdgcn_readlane((int)vdesc.x, (J))), \
+                            __int_as_float(__builtin_amdgcn_readlane((int)vdesc.y, (J))), t_.y, t_.z);                    \
+        else mix_source_rare_ear(park, lane, frame0, n_frames, (uint32_t)cB, path_j, st, ear, g * MIX_GROUP + (uint32_t)(J), P.cycle_rows, P.cycle_plane, wv); \
+        wave_sync();                                                                                                      \
+        _Pragma("unroll") for (int k = 0; k < 16; ++k) acc[k] = park[k * PARK_STRIDE + lane];                             \
+        pair_barrier();                                   /* both park areas are free again */                            \
+        if (cur >= 0) PAIR_ISSUE_WINDOW(cur, buf)                                                                         \
+    }
+        {
+            unsigned rm = rare_mask;
+            while (cur >= 0 || rm) {
+                const int rj = rm ? 31 - __builtin_clz(rm) : -1;
+                if (rj > cur) {
+                    rm &= ~(1u << rj);
+                    PAIR_RARE_SOURCE(rj)
+                    continue;
+                }
+#pragma unroll 1
+                while (cur > rj && PAIR_VARIANT(cur_info) == 0) PAIR_STAGED_SOURCE(0, rm == 0)
+#pragma unroll 1
+                while (cur > rj && PAIR_VARIANT(cur_info) == 1) PAIR_STAGED_SOURCE(1, rm == 0)
+#pragma unroll 1
+                while (cur > rj && PAIR_VARIANT(cur_info) == 2) PAIR_STAGED_SOURCE(2, rm == 0)
+            }
+        }
+#undef PAIR_RARE_SOURCE
+#undef PAIR_STAGED_SOURCE
+#undef PAIR_VARIANT
+#undef PAIR_LANE_DATA
+#undef PAIR_ISSUE_WINDOW
+#undef PAIR_ISSUE_WINDOW_OF
+        if (need_prefetch) PAIR_LOAD_GROUP(g - 1u, pv, pq, pf, pw)   // a group without a staged source
+        wave_sync();   // before the next group's phase A overwrites the stream blocks
+    }
+#undef PAIR_LOAD_GROUP
+
+    // ---- this wave's half of the workgroup's partial tiles: ear wv, frames 16 lane .. (tile = lane >> 5) ----
+    int le = threadIdx.x & 63;
+    asm volatile("" : "+v"(le));
+    if (16u * (uint32_t)le < n_frames) {
+        // the lane's 16 frames are two blocks of PART_FRAMES frames (kernels.h: the partial sums' layout)
+        float* dst = partials + ((size_t)(2 * le) * gridDim.x + blockIdx.x) * PART_BLOCK + (size_t)wv * PART_FRAMES;
+        const size_t dst_step = (size_t)gridDim.x * PART_BLOCK;
+#pragma unroll
+        for (int q4 = 0; q4 < 4; ++q4) reinterpret_cast<float4*>(dst + (q4 >> 1) * dst_step)[q4 & 1] = make_float4(acc[4 * q4], acc[4 * q4 + 1], acc[4 * q4 + 2], acc[4 * q4 + 3]);
+    }
+}
+
+}  // namespace oddio_hip

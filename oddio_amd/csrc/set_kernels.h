@@ -140,12 +140,13 @@ __global__ __launch_bounds__(256) void compact_set(CompactArgs<S, D> A) { compac
 // The callback's last kernel: the fixed-order sum of the workgroup partial tiles + Reinhard / Tanh (blocks
 // [0, n_red)), and -- in two extra blocks that need nothing from the others -- set.remove() of what the walk
 // stopped (spatial.rs:258-261), so that neither a second reduce stage nor compaction costs a launch of its own.
-__global__ __launch_bounds__(256) void reduce_partials_compact(const float* __restrict__ partials, float* __restrict__ out, uint32_t n_wgs,
-                                                               uint32_t n_frames, int postfx, uint32_t n_red,
-                                                               CompactArgs<SrcStatic, SrcDyn> seek, CompactArgs<BufStatic, BufDyn> buf) {
+template <int SEGS = RED_SEGS>
+__global__ __launch_bounds__(2 * RED_FRAMES * SEGS) void reduce_partials_compact(const float* __restrict__ partials, float* __restrict__ out, uint32_t n_wgs,
+                                                                                uint32_t n_frames, int postfx, uint32_t n_red,
+                                                                                CompactArgs<SrcStatic, SrcDyn> seek, CompactArgs<BufStatic, BufDyn> buf) {
     if (blockIdx.x == n_red) { compact_set_block(seek); return; }
     if (blockIdx.x == n_red + 1u) { compact_set_block(buf); return; }
-    reduce_partials_body(partials, out, n_wgs, n_frames, postfx, blockIdx.x);
+    reduce_partials_body<SEGS>(partials, out, n_wgs, n_frames, postfx, blockIdx.x);
 }
 
 // Motion updates carry handle ids (spatial.rs:137-149: the handle, not the set position)

@@ -196,6 +196,16 @@ def speed_control_set(sp, factor):
     sp["speed"] = f32(factor)
 
 
+def reinhard_filter(inner):
+    """Reinhard::new(inner) (src/reinhard.rs:16-20) around a source: `x / (1 + |x|)` on every sample (:28-35)."""
+    return {"kind": "reinhard", "inner": inner}
+
+
+def tanh_filter(inner):
+    """Tanh::new(inner) (src/tanh.rs:10-14) around a source: `tanh(x)` on every sample (:22-29)."""
+    return {"kind": "tanh", "inner": inner}
+
+
 def _smoothed_get(g):
     """Smoothed::get (src/smooth.rs:67-72) with f32::interpolate (:84-89): prev + progress * (next - prev)."""
     diff = g["next"] - g["prev"]
@@ -218,6 +228,10 @@ def src_sample(src, interval, n):
         return (src_sample(src["inner"], interval, n) * src["gain"]).astype(f32)
     if kind == "speed":                                   # Speed::sample, src/speed.rs:32-35
         return src_sample(src["inner"], interval * src["speed"], n)
+    if kind == "reinhard":                                # Reinhard::sample, src/reinhard.rs:28-35
+        return reinhard(src_sample(src["inner"], interval, n))
+    if kind == "tanh":                                    # Tanh::sample, src/tanh.rs:22-29
+        return tanh_clip(src_sample(src["inner"], interval, n))
     if kind == "gain":                                    # Gain::sample, src/gain.rs:103-122
         out = src_sample(src["inner"], interval, n)
         if src["next"] != src["shared"]:                  # :106-108 -> Smoothed::set, src/smooth.rs:57-64
@@ -313,6 +327,8 @@ def src_sample(src, interval, n):
 
 def src_seek(src, seconds):
     seconds = f32(seconds)
+    if src["kind"] in ("fixed", "reinhard", "tanh"):      # Seek passes through (gain.rs:44-50, reinhard.rs:46-49, tanh.rs:40-43)
+        return src_seek(src["inner"], seconds)
     if src["kind"] in ("frames", "downmix"):
         src["t"] = src["t"] + f64(seconds)
     elif src["kind"] == "sine":
@@ -324,7 +340,7 @@ def src_seek(src, seconds):
 
 
 def src_is_finished(src):
-    if src["kind"] in ("fixed", "gain", "speed"):         # is_finished passes through the filters (gain.rs:39-41,124-126, speed.rs:37-39)
+    if src["kind"] in ("fixed", "gain", "speed", "reinhard", "tanh"):   # is_finished passes through the filters (gain.rs:39-41,124-126, speed.rs:37-39, reinhard.rs:37-39, tanh.rs:31-33)
         return src_is_finished(src["inner"])
     if src["kind"] in ("frames", "downmix"):
         return bool(src["t"] >= f64(len(src["samples"]) - 1) / f64(src["rate"]))

@@ -6,6 +6,7 @@ from __future__ import annotations
 import numpy as np
 
 FIXED, GAIN, SPEED = 1, 2, 3          # chain entries (kind, param), innermost first; GAIN's param: initial amplitude ratio or NaN
+REINHARD, TANH = 4, 5                 # per-source soft clips (reinhard.rs:22-50, tanh.rs:16-44), param unused
 
 
 def pack(spec, expected):
@@ -76,6 +77,9 @@ class CBackend(_Backend):
                 if kind == FIXED:
                     sig = oc.FixedGain(sig, p)
                     ctl.append(None)
+                elif kind in (REINHARD, TANH):
+                    sig = oc.Reinhard(sig) if kind == REINHARD else oc.Tanh(sig)
+                    ctl.append(None)
                 elif kind == GAIN:
                     sig = oc.Gain(sig)
                     if not np.isnan(p):
@@ -118,6 +122,9 @@ class NumpyBackend(_Backend):
             for kind, p in s["chain"]:
                 if kind == FIXED:
                     src = on.fixed_gain_filter(src, p)
+                    ctl.append(None)
+                elif kind in (REINHARD, TANH):
+                    src = on.reinhard_filter(src) if kind == REINHARD else on.tanh_filter(src)
                     ctl.append(None)
                 elif kind == GAIN:
                     src = on.gain_filter(src, None if np.isnan(p) else p)
@@ -163,6 +170,9 @@ class HipBackend(_Backend):
             for kind, p in s["chain"]:
                 if kind == FIXED:
                     sig = oa.FixedGain(sig, p)
+                    ctl.append(None)
+                elif kind in (REINHARD, TANH):
+                    sig = oa.Reinhard(sig) if kind == REINHARD else oa.Tanh(sig)
                     ctl.append(None)
                 elif kind == GAIN:
                     gc, sig = oa.Gain.new(sig)

@@ -72,10 +72,52 @@ def mixer_spec(seed, n_src, n_frames, n_callbacks):
     return spec
 
 
+def clip_scene_spec(seed, n_src, n_frames, n_callbacks):
+    """Round 5: per-source Reinhard (reinhard.rs:22-50) -- Seek sources played with `play` ([FixedGain] [Reinhard] in either order,
+    moving, static (resample ratio exactly 1) and with a cursor that starts before the clip) and buffered chains with the clip
+    anywhere among the filters."""
+    spec = scene_spec(seed, n_src, n_frames, n_callbacks)
+    R = (chains.REINHARD, 0.0)
+    seek_shapes = ([R], [(chains.FIXED, -3.0), R], [R, (chains.FIXED, 2.5)], [])
+    buf_shapes = ([(chains.GAIN, np.nan), R], [R, (chains.SPEED, 0.97)], [(chains.FIXED, 1.5), R, (chains.GAIN, 0.7)])
+    for i, s in enumerate(spec["sources"]):
+        s["buffered"] = i % 3 == 2
+        s["chain"] = list(buf_shapes[(i // 3) % 3] if s["buffered"] else seek_shapes[i % 4])
+        s["start"] = 0.0 if s["buffered"] else (0.1, 0.1, -0.003)[i % 3]
+        if i % 5 == 1:
+            s["vel"] = np.zeros(3, np.float32)
+    spec["ctl"] = [(cb, i, w, v) for cb, i, w, v in spec["ctl"] if False]
+    for cb in (1, 3):
+        for i, s in enumerate(spec["sources"]):
+            for w, (kind, _) in enumerate(s["chain"]):
+                if kind == chains.GAIN:
+                    spec["ctl"].append((cb, i, w, 0.3 + 0.2 * ((i + cb) % 4)))
+                if kind == chains.SPEED and cb == 3:
+                    spec["ctl"].append((cb, i, w, 1.03))
+    return spec
+
+
+def clip_mixer_spec(seed, n_src, n_frames, n_callbacks):
+    spec = mixer_spec(seed, n_src, n_frames, n_callbacks)
+    R = (chains.REINHARD, 0.0)
+    shapes = ([R], [(chains.FIXED, 2.0), R], [R, (chains.GAIN, np.nan)], [(chains.SPEED, 1.05), R, (chains.FIXED, -2.0)], [])
+    for i, s in enumerate(spec["sources"]):
+        s["chain"] = list(shapes[i % 5])
+    spec["ctl"] = []
+    for cb in (1, 2):
+        for i, s in enumerate(spec["sources"]):
+            for w, (kind, _) in enumerate(s["chain"]):
+                if kind == chains.GAIN:
+                    spec["ctl"].append((cb, i, w, 0.4 + 0.15 * ((i + cb) % 3)))
+    return spec
+
+
 def main():
     make("chains_buffered_scene", scene_spec(2001, 10, 1024, 6))
     make("chains_buffered_scene_ragged", scene_spec(2002, 7, 700, 5))
     make("chains_mixer", mixer_spec(2003, 10, 1024, 6))
+    make("chains_source_clip_scene", clip_scene_spec(2004, 12, 1024, 5))
+    make("chains_source_clip_mixer", clip_mixer_spec(2005, 10, 1024, 4))
 
 
 if __name__ == "__main__":
