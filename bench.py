@@ -423,8 +423,8 @@ def buffered_cpu_and_parity(device: int, seed: int, budget_s: float) -> tuple[di
 
 
 def bench_mixer(device: int, frames_bank) -> dict:
-    """The Mixer leg (mixer.rs is on the north_star's path; BASELINE configs[0] is a Mixer): host-output callbacks (the Mixer has no
-    device-output entry point), a few of each, reported only.  `frames_bank`: Frames of the Seek workload's clips."""
+    """The Mixer leg (mixer.rs is on the north_star's path; BASELINE configs[0] is a Mixer): host-output callbacks, a few of each, and the
+    headline-size Mixer through the device-output entry with its roofline; reported only.  `frames_bank`: Frames of the Seek workload's clips."""
     import oddio_amd as oa
     interval = np.float32(1.0) / np.float32(RATE)
 
@@ -455,6 +455,37 @@ def bench_mixer(device: int, frames_bank) -> dict:
     mixer.close()
     out.update({"sources": S, "fast_ms_per_callback": fast, "ordered_ms_per_callback": ordered,
                 "fast_source_frames_per_s": float(S) * N_FRAMES / (fast * 1e-3), "ordered_source_frames_per_s": float(S) * N_FRAMES / (ordered * 1e-3)})
+    # The Mixer at the headline size through its device-output entry (oddio_hip_mixer_sample_device: callbacks enqueued back to back,
+    # one synchronisation), with a roofline of its own.  Algorithmic bytes per callback: S * (4 * N + P) + 8 * N -- every source reads
+    # N mono f32 samples once (the resample ratio of a Mixer source is 1: no Doppler) plus P = 128 bytes of per-source records, and
+    # the stereo mix is written once.
+    import torch
+    S2 = min(262144, len(frames_bank))
+    control, mixer = oa.Mixer(device=device, max_sources=S2, max_frames=N_FRAMES)
+    for i in range(S2):
+        control.play(oa.MonoToStereo(oa.FramesSignal(frames_bank[i], 0.25)))
+    dev_out = torch.zeros((N_FRAMES, 2), dtype=torch.float32, device=torch.device("cuda", device))
+    for _ in range(6):
+        mixer.sample_device(interval, dev_out.data_ptr(), N_FRAMES)
+    mixer.synchronize()
+    reps = 20
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        mixer.sample_device(interval, dev_out.data_ptr(), N_FRAMES)
+    mixer.synchronize()
+    dev_ms = (time.perf_counter() - t0) / reps * 1e3
+    assert bool(torch.isfinite(dev_out).all()) and float(dev_out.abs().max()) > 0.0
+    host_ms = timed(mixer, 8, 2)                       # the same mixer through the reference's own boundary (host slice)
+    assert len(mixer) == S2, len(mixer)
+    mixer.close()
+    b_alg = float(S2) * (4.0 * N_FRAMES + 128.0) + 8.0 * N_FRAMES
+    out["device_output"] = {
+        "sources": S2, "boundary": "oddio_hip_mixer_sample_device (frames stay in HBM, callbacks enqueued back to back)",
+        "ms_per_callback": dev_ms, "host_output_ms_per_callback": host_ms,
+        "source_frames_per_s": float(S2) * N_FRAMES / (dev_ms * 1e-3),
+        "roofline": {"bound": "hbm", "kernel": "mixer_prepass + mixer_mix + mixer_reduce (the whole callback)", "algorithmic_bytes_per_callback": b_alg,
+                     "achieved": b_alg / (dev_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": b_alg / (dev_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                     "frac_host_output": b_alg / (host_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS}}
     # the same with a GainControl on every source (Gain<MonoToStereo<FramesSignal>>: the mixer's chain path, gain.rs + smooth.rs)
     control, mixer = oa.Mixer(device=device, max_sources=S, max_frames=N_FRAMES)
     gains = []

@@ -97,6 +97,8 @@ extern "C" {
     fn oddio_hip_mixer_is_stopped(m: *mut RawMixer, id: u32, stopped: *mut c_int) -> c_int;
     fn oddio_hip_mixer_set_postfx(m: *mut RawMixer, postfx: c_int) -> c_int;
     fn oddio_hip_mixer_sample(m: *mut RawMixer, interval: f32, out: *mut f32, n_frames: usize) -> c_int;
+    fn oddio_hip_mixer_sample_device(m: *mut RawMixer, interval: f32, dev_out: *mut f32, n_frames: usize) -> c_int;
+    fn oddio_hip_mixer_synchronize(m: *mut RawMixer) -> c_int;
 }
 
 fn check(rc: c_int) {
@@ -367,6 +369,20 @@ impl HipMixer {
     pub fn with_postfx(self, postfx: c_int) -> Self {
         check(unsafe { oddio_hip_mixer_set_postfx((self.0).0, postfx) });
         self
+    }
+}
+impl HipMixer {
+    /// `Mixer::sample` with the frames left in device memory (`dev_out`: 2 * n_frames floats on the mixer's device) and no wait, for
+    /// hosts that consume the mix on the GPU or enqueue several callbacks; `synchronize` waits for the mixer's stream.  Not part of
+    /// the reference's interface (src/mixer.rs:92-119 fills a host slice): the counterpart of `HipSpatialScene::sample_device`.
+    ///
+    /// # Safety
+    /// `dev_out` must be device memory of at least `2 * n_frames` floats that stays valid until the callback has executed.
+    pub unsafe fn sample_device(&mut self, interval: f32, dev_out: *mut f32, n_frames: usize) {
+        check(oddio_hip_mixer_sample_device((self.0).0, interval, dev_out, n_frames));
+    }
+    pub fn synchronize(&mut self) {
+        check(unsafe { oddio_hip_mixer_synchronize((self.0).0) });
     }
 }
 impl Signal for HipMixer {

@@ -453,6 +453,15 @@ int oddio_hip_mixer_set_mode(oddio_hip_mixer* mixer, int mode);
 /* Signal::sample for Mixer (src/mixer.rs:92-119) / oddio::run */
 int oddio_hip_mixer_sample(oddio_hip_mixer* mixer, float interval, float* out, size_t n_frames);
 int oddio_hip_mixer_run(oddio_hip_mixer* mixer, uint32_t sample_rate, float* out, size_t n_frames);
+/* Mixer::sample (src/mixer.rs:92-119) with the frames left in DEVICE memory (`dev_out`: channels * n_frames floats on the
+ * mixer's device) and no wait: the counterpart of oddio_hip_scene_sample_device for hosts that consume the mix on the GPU
+ * or enqueue several callbacks.  The work runs on the mixer's stream in call order.  Sources the callback stopped are
+ * skipped by later callbacks at once; the handles (oddio_hip_mixer_is_stopped) and the slot bookkeeping learn of them when
+ * a later call settles the callback's pinned snapshot -- every oddio_hip_mixer_sample call and, in ORDERED mode (where the
+ * sum order is the set order), every call does so before it starts. */
+int oddio_hip_mixer_sample_device(oddio_hip_mixer* mixer, float interval, float* dev_out, size_t n_frames);
+/* Waits for everything enqueued on the mixer's stream (device-output callbacks). */
+int oddio_hip_mixer_synchronize(oddio_hip_mixer* mixer);
 
 #ifdef __cplusplus
 }

@@ -170,6 +170,8 @@ def lib():
         "oddio_hip_mixer_set_postfx": (i32, [vp, i32]),
         "oddio_hip_mixer_set_mode": (i32, [vp, i32]),
         "oddio_hip_mixer_sample": (i32, [vp, f32, fp, sz]),
+        "oddio_hip_mixer_sample_device": (i32, [vp, f32, vp, sz]),
+        "oddio_hip_mixer_synchronize": (i32, [vp]),
         "oddio_hip_mixer_run": (i32, [vp, u32, fp, sz]),
     }
     for name, (res, args) in sig.items():

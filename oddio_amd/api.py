@@ -832,6 +832,14 @@ class _MixerSignal(Signal):
     def sample_n(self, interval, n):
         return self.sample(interval, np.zeros((n, 2) if self.channels == 2 else (n,), dtype=np.float32))
 
+    def sample_device(self, interval, dev_ptr: int, n_frames: int):
+        """Mixer::sample with the frames left in device memory (channels * n_frames floats at `dev_ptr`) and no wait
+        (oddio_hip_mixer_sample_device); `synchronize()` waits for the mixer's stream."""
+        _lib.check(_lib.lib().oddio_hip_mixer_sample_device(self._h, np.float32(interval), C.c_void_p(dev_ptr), int(n_frames)))
+
+    def synchronize(self):
+        _lib.check(_lib.lib().oddio_hip_mixer_synchronize(self._h))
+
     def is_finished(self):
         return False
 
