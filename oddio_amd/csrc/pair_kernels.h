@@ -27,23 +27,18 @@
 
 namespace oddio_hip {
 
-constexpr int PAIR_GROUP = 8;                                             // sources per cursor-scan step (8 sources x 4 chunks = 32 lanes)
-constexpr int PAIR_STREAM_WORDS = 17;                                     // 16 checkpoints + 4 * wrel (odd: the scan's 32 lanes write conflict-free)
+constexpr int PAIR_GROUP = MIX_GROUP;                                     // sources per cursor-scan step (16 sources x 4 chunks = 64 lanes)
 constexpr int PAIR_WIN_BYTES = PAIR_WIN_CAP * 4;
 constexpr int PAIR_LDS_WIN0 = 0;
 constexpr int PAIR_LDS_WIN1 = PAIR_WIN_BYTES;
 constexpr int PAIR_LDS_STREAM = 2 * PAIR_WIN_BYTES;
-constexpr int PAIR_STREAM_BYTES = 4 * PAIR_GROUP * PAIR_STREAM_WORDS * 4; // one wave's 32 stream blocks
-constexpr int PAIR_LDS_RECS = PAIR_LDS_STREAM + 2 * PAIR_STREAM_BYTES;    // the PairRecs of one group, staged by DMA one group ahead
-constexpr int PAIR_REC_BYTES = PAIR_GROUP * (int)sizeof(PairRec);
-constexpr int PAIR_LDS_TOTAL = PAIR_LDS_RECS + PAIR_REC_BYTES;
+constexpr int PAIR_STREAM_BYTES = 64 * STREAM_WORDS * 4;                  // one wave's 64 stream blocks
+constexpr int PAIR_LDS_TOTAL = PAIR_LDS_STREAM + 2 * PAIR_STREAM_BYTES;
 constexpr int PAIR_TAIL_LANES = (PAIR_WIN_BYTES - 4096) / 16;             // lanes of the fifth 1 KiB piece that stay inside the window buffer
-constexpr int PAIR_WAVES_PER_SIMD = 5;                                    // register budget 512 / 5 -> 96 VGPRs: 10 workgroups = 20 waves per CU
-static_assert(PAIR_WIN_BYTES % 16 == 0 && PAIR_LDS_RECS % 16 == 0 && PAIR_LDS_TOTAL % 16 == 0, "16-byte aligned window buffers and record stage");
-static_assert(PAIR_LDS_TOTAL * 10 <= 160 * 1024, "10 workgroups (20 waves) per CU");
+static_assert(PAIR_WIN_BYTES % 16 == 0 && PAIR_LDS_TOTAL % 16 == 0, "16-byte aligned window buffers and stream blocks");
+static_assert(PAIR_LDS_TOTAL * 8 <= 160 * 1024, "8 workgroups (16 waves) per CU");
 static_assert(16 * PARK_STRIDE * 4 <= PAIR_WIN_BYTES, "a wave parks its accumulators in one window buffer");
 static_assert(PAIR_WIN_BYTES > 4096 && PAIR_WIN_BYTES <= 5120 && PAIR_TAIL_LANES > 0 && PAIR_TAIL_LANES <= 64, "five 1 KiB pieces cover a window buffer");
-static_assert(PAIR_REC_BYTES <= 1024 && PAIR_REC_BYTES % 16 == 0, "one DMA instruction stages a group's records");
 
 // s_barrier of the two waves with the LDS hand-over made explicit for the compiler (the builtin alone is not a memory barrier)
 __device__ __forceinline__ void pair_barrier() {
@@ -65,7 +60,7 @@ __device__ __forceinline__ void pair_window_dma(uint32_t lds_dst, uint32_t d0, u
     if (nvec * 16 > PAIR_WIN_BYTES || (int)d2 > nvec * 16 + neg + 16) asm volatile("s_trap 2");
 #endif
     const int voff = neg + lane16 + 1024 * first;
-    const uint32_t m0v = lds_dst + 1024u * (uint32_t)first;
+    const uint32_t m0v = (uint32_t)__builtin_amdgcn_readfirstlane((int)(lds_dst + 1024u * (uint32_t)first));   // (wave-uniform; M0 wants an SGPR)
     uint32_t keep;
     // (pieces 0-3 from every lane: lanes past the window write zeros inside the buffer, no traffic)
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 4\n\t"
@@ -104,37 +99,15 @@ __device__ __forceinline__ void pair_repack_padded(unsigned char* win_bytes, int
     pair_barrier();
 }
 
-// HBM -> LDS: the PairRecs of group `g` (PAIR_GROUP consecutive records) into the record stage.  The descriptor covers the records
-// of the live slots only: records past the set's end read as zeros (info == 0: PATH_SKIP).
-__device__ __forceinline__ void pair_rec_dma(uint32_t lds_dst, uint32_t d0, uint32_t d1, uint32_t d2, uint32_t g, int lane16) {
-    u32x4 rsrc;
-    rsrc.x = d0; rsrc.y = d1; rsrc.z = d2;
-    rsrc.w = 0x00020000u;
-    const int voff = (int)(g * (uint32_t)PAIR_REC_BYTES) + lane16;
-    uint32_t keep;
-    if (lane16 < PAIR_REC_BYTES)
-        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 4\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds\n\ts_mov_b32 m0, %0"
-                     : "=&s"(keep) : "v"(voff), "s"(rsrc), "s"(lds_dst) : "memory");
-}
-
-// grid = workgroups; block = 128 (wave 0: left ear, wave 1: right ear).  Workgroup w walks groups [g_lo, g_hi) of PAIR_GROUP slots
+// grid = workgroups; block = 128 (wave 0: left ear, wave 1: right ear).  Workgroup w walks groups [g_lo, g_hi) of 16 slots
 // in DESCENDING order (the reference's reverse set walk, spatial.rs:204) and leaves its partial sums in spatial_mix's
 // layout (kernels.h PART_BLOCK) for reduce_partials.
-//
-// Registers and LDS are budgeted for FIVE waves per SIMD (10 workgroups per CU; spatial_mix: four): measured on the first version
-// of this kernel, 12 -> 14 -> 16 waves per CU took 0.243 -> 0.234 -> 0.222 ms.  What pays for it:
-//   * groups of 8 sources (the scan runs on 32 lanes) and 17-word stream blocks: 4.3 KB of checkpoints per workgroup, not 10;
-//   * the next group's records come HBM -> LDS by DMA (768 bytes, issued by wave 0 behind the group's first hand-over) instead of
-//     waiting in ten VGPRs per lane; phase A reads them from LDS;
-//   * the ear's {ds, g0, dg} are wave-uniform here -- the whole wave renders one ear -- and are fetched per source from the scan
-//     lanes' registers with v_readlane (SGPRs), not from the stream blocks into VGPRs;
-//   * FAST mode's gain ramp takes the frame index as a literal (mix_source_lds RAMP1): one `frame as f32` register, not 16.
 template <bool FULL, bool FUSED>
-__global__ __launch_bounds__(128, PAIR_WAVES_PER_SIMD) void spatial_mix_pair(SceneParams P, const SrcStatic* __restrict__ st,
-                                                                             const EarParams* __restrict__ ear, const PairRec* __restrict__ recs,
-                                                                             float* __restrict__ partials, const float* __restrict__ init,
-                                                                             uint32_t groups_per_wg, uint32_t n_groups,
-                                                                             const uint32_t* __restrict__ n_sources_ptr) {
+__global__ __launch_bounds__(128, MIX_WAVES_PER_SIMD) void spatial_mix_pair(SceneParams P, const SrcStatic* __restrict__ st,
+                                                                            const EarParams* __restrict__ ear, const PairRec* __restrict__ recs,
+                                                                            float* __restrict__ partials, const float* __restrict__ init,
+                                                                            uint32_t groups_per_wg, uint32_t n_groups,
+                                                                            const uint32_t* __restrict__ n_sources_ptr) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[PAIR_LDS_TOTAL];
     const uint32_t n_sources = *n_sources_ptr;
     const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));       // this wave's ear
@@ -155,145 +128,137 @@ __global__ __launch_bounds__(128, PAIR_WAVES_PER_SIMD) void spatial_mix_pair(Sce
         for (int k = 0; k < 16; ++k)
             if (frame0 + (uint32_t)k < n_frames) acc[k] = init[2 * (frame0 + (uint32_t)k) + (uint32_t)wv];
     }
-    // n_groups = gridDim.x * groups_per_wg + rem: the first `rem` workgroups walk one group more (in dispatch order they are spread
-    // evenly over the CUs: with 10 workgroups per CU and 12.8 groups per workgroup every CU gets 8 x 13 + 2 x 12 groups, not 10 x 13
-    // on most CUs and 9 x 13 on the rest)
+    // (the loads above are awaited here, once: left pending, hipcc puts its `s_waitcnt vmcnt(0)` for them in front of every loop of
+    // the walk that touches the accumulators)
+#pragma unroll
+    for (int k = 0; k < 16; ++k) asm volatile("" : "+v"(acc[k]));
+    // n_groups = gridDim.x * groups_per_wg + rem: the first `rem` workgroups walk one group more
     const uint32_t rem = n_groups - gridDim.x * groups_per_wg;
     const uint32_t g_lo = blockIdx.x * groups_per_wg + (blockIdx.x < rem ? blockIdx.x : rem);
     const uint32_t g_hi = g_lo + groups_per_wg + (blockIdx.x < rem ? 1u : 0u);
 
     unsigned char* const sbase = smem + PAIR_LDS_STREAM + wv * PAIR_STREAM_BYTES;   // this wave's stream blocks: block 4 j + c
-    unsigned char* const blkB0 = sbase + cB * (PAIR_STREAM_WORDS * 4);
-    constexpr int BLK_SRC = 4 * PAIR_STREAM_WORDS * 4;
-    const unsigned char* const rstage = smem + PAIR_LDS_RECS;
-    // buffer descriptor of the record array, clipped to the live slots
-    const uint32_t rd0 = (uint32_t)(uintptr_t)recs, rd1 = (uint32_t)((uintptr_t)recs >> 32) & 0xffffu;
-    const uint32_t rd2 = (n_sources < 0x02aaaaaau ? n_sources : 0x02aaaaaau) * (uint32_t)sizeof(PairRec);
+    unsigned char* const blkB0 = sbase + cB * (STREAM_WORDS * 4);
+    constexpr int BLK_SRC = 4 * STREAM_WORDS * 4;
 
-    // the first group's records
-    if (g_hi > g_lo) {
-        if (wv == 0) pair_rec_dma(lds_base + (uint32_t)PAIR_LDS_RECS, rd0, rd1, rd2, g_hi - 1u, lane16);
-        window_wait();
-        pair_barrier();
+    // The records of a group -- lanes 0-15: {descriptor words, info} of source `lane`; lane (j, c): {ds, g0, dg} of this
+    // wave's ear, the chunk's frac0 and wrel -- are fetched one group ahead (see spatial_mix).
+#define PAIR_LOAD_GROUP(GG, V, Q, F, W)                                                                                   \
+    {                                                                                                                     \
+        int la_ = lane;                                                                                                   \
+        asm volatile("" : "+v"(la_));                                                                                     \
+        const PairRec* __restrict__ grec_ = recs + (size_t)(GG) * MIX_GROUP;                                              \
+        V = make_uint4(0u, 0u, 0u, 0u); Q = f4u{0.0f, 0.0f, 0.0f, 0.0f}; F = 0.0f; W = 0u;                                \
+        if (la_ < MIX_GROUP && (GG) * MIX_GROUP + (uint32_t)la_ < n_sources) V = *reinterpret_cast<const uint4*>(grec_ + la_); \
+        if ((GG) * MIX_GROUP + (uint32_t)(la_ >> 2) < n_sources) {                                                        \
+            const PairEar* pe_ = &grec_[la_ >> 2].ear[wv];                                                                \
+            Q = *reinterpret_cast<const f4u*>(pe_);                              /* {ds, g0, dg, .} */                    \
+            F = pe_->frac0[la_ & 3];                                                                                      \
+            W = (uint32_t)pe_->wrel[la_ & 3];                                                                             \
+        }                                                                                                                 \
     }
+    uint4 pv = make_uint4(0u, 0u, 0u, 0u);
+    f4u pq = {0.0f, 0.0f, 0.0f, 0.0f};
+    float pf = 0.0f;
+    uint32_t pw = 0u;
+    if (g_hi > g_lo) PAIR_LOAD_GROUP(g_hi - 1u, pv, pq, pf, pw)
     int buf = 0;
     bool pre_issued = false;     // the last source of the previous group already started this group's first window
     for (uint32_t g = g_hi; g-- > g_lo;) {
         // ------------------------------ phase A ------------------------------
-        // lanes 0-7 keep {descriptor words, info} of source `lane` for the whole group, lane (j, c) = 4 j + c the {ds, g0, dg} of
-        // source j's ear (read per source with v_readlane: wave-uniform values in SGPRs)
+        const uint4 vdesc = pv;
+        const f4u q = pq;
+        const float frac0 = pf;
+        const uint32_t wr0 = pw;
+        bool need_prefetch = g > g_lo;
         int laneA = lane;
         asm volatile("" : "+v"(laneA));
-        uint4 vdesc = make_uint4(0u, 0u, 0u, 0u);
-        float qds = 0.0f, qg0 = 0.0f, qdg = 0.0f, frac0 = 0.0f;
-        uint32_t wr0 = 0u;
-        if (laneA < PAIR_GROUP) vdesc = *reinterpret_cast<const uint4*>(rstage + laneA * (int)sizeof(PairRec));
-        if (laneA < 4 * PAIR_GROUP) {
-            const unsigned char* pe = rstage + (laneA >> 2) * (int)sizeof(PairRec) + 16 + (int)sizeof(PairEar) * wv;
-            qds = reinterpret_cast<const float*>(pe)[0]; qg0 = reinterpret_cast<const float*>(pe)[1]; qdg = reinterpret_cast<const float*>(pe)[2];
-            frac0 = reinterpret_cast<const float*>(pe + 16)[laneA & 3];
-            wr0 = (uint32_t)reinterpret_cast<const uint16_t*>(pe + 32)[laneA & 3];
-        }
         const int pj = (int)(vdesc.w & 7u);
-        const unsigned lds_mask = (unsigned)__ballot(laneA < PAIR_GROUP && pj == PATH_LDS) & 0xffu;
-        const unsigned rare_mask = (unsigned)__ballot(laneA < PAIR_GROUP && pj != PATH_LDS && pj != PATH_SKIP) & 0xffu;
+        const unsigned lds_mask = (unsigned)__ballot(laneA < MIX_GROUP && pj == PATH_LDS) & 0xffffu;
+        const unsigned rare_mask = (unsigned)__ballot(laneA < MIX_GROUP && pj != PATH_LDS && pj != PATH_SKIP) & 0xffffu;
         int cur = lds_mask ? 31 - __builtin_clz(lds_mask) : -1;
         uint32_t cur_info = 0;
-#define PAIR_ISSUE_WINDOW(JN, BUF)                                                                                        \
-    pair_window_dma(lds_base + (uint32_t)((BUF) ? PAIR_LDS_WIN1 : PAIR_LDS_WIN0), (uint32_t)__builtin_amdgcn_readlane((int)vdesc.x, (JN)), \
-                    (uint32_t)__builtin_amdgcn_readlane((int)vdesc.y, (JN)), (uint32_t)__builtin_amdgcn_readlane((int)vdesc.z, (JN)), \
-                    (uint32_t)__builtin_amdgcn_readlane((int)vdesc.w, (JN)), lane16, wv ^ ((JN) & 1));
+#define PAIR_ISSUE_WINDOW_OF(VD, JN, BUF)                                                                                 \
+    pair_window_dma(lds_base + (uint32_t)((BUF) ? PAIR_LDS_WIN1 : PAIR_LDS_WIN0), (uint32_t)__builtin_amdgcn_readlane((int)(VD).x, (JN)), \
+                    (uint32_t)__builtin_amdgcn_readlane((int)(VD).y, (JN)), (uint32_t)__builtin_amdgcn_readlane((int)(VD).z, (JN)), \
+                    (uint32_t)__builtin_amdgcn_readlane((int)(VD).w, (JN)), lane16, wv ^ ((JN) & 1));
+#define PAIR_ISSUE_WINDOW(JN, BUF) PAIR_ISSUE_WINDOW_OF(vdesc, JN, BUF)
         if (cur >= 0) {   // the first window is on its way while the cursors are scanned
             cur_info = (uint32_t)__builtin_amdgcn_readlane((int)vdesc.w, cur);
             if (!pre_issued) PAIR_ISSUE_WINDOW(cur, buf)
         }
         pre_issued = false;
-        if (laneA < 4 * PAIR_GROUP) {
+        {
             // exact f32 cursor scan (frames.rs:189-196) of stream (source j = lane >> 2, chunk c = lane & 3) of this wave's ear
-            float* blk = reinterpret_cast<float*>(sbase + laneA * (PAIR_STREAM_WORDS * 4));
+            float* blk = reinterpret_cast<float*>(sbase + laneA * (STREAM_WORDS * 4));
+            const float ds = q.x;
             float x = frac0;
 #pragma unroll 1
             for (int b = 0; b < 15; ++b) {
                 blk[b] = x;
 #pragma unroll
-                for (int i = 0; i < 16; ++i) x = x + qds;
+                for (int i = 0; i < 16; ++i) x = x + ds;
             }
             blk[15] = x;
-            blk[16] = __uint_as_float(4u * wr0);
+            *reinterpret_cast<float4*>(blk + 16) = make_float4(__uint_as_float(4u * wr0), q.y, q.z, q.x);
         }
         wave_sync();
-        // the next group's records: wave 0 starts their DMA behind the group's first hand-over (both waves have read this group's
-        // by then) and has awaited it -- window_wait -- before the second; a group with fewer hand-overs settles it at its end
-        bool rec_issued = false, rec_ready = g == g_lo;
-#define PAIR_HANDOVER_DONE()                                                                                              \
-    if (!rec_ready) {                                                                                                     \
-        if (rec_issued) rec_ready = true;                                                                                 \
-        else { if (wv == 0) pair_rec_dma(lds_base + (uint32_t)PAIR_LDS_RECS, rd0, rd1, rd2, g - 1u, lane16); rec_issued = true; } \
-    }
 
         // ------------------------------ phase B ------------------------------
         float cx0 = 0.0f;
-        int cw4 = 0;
-#define PAIR_LANE_DATA(J, X0, W4)                                                                                         \
+        float4 ct = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+#define PAIR_LANE_DATA(J, X0, T)                                                                                          \
     {                                                                                                                     \
         const unsigned char* blk_ = blkB0 + (J) * BLK_SRC;                                                                \
         X0 = reinterpret_cast<const float*>(blk_)[bB];                                                                    \
-        W4 = reinterpret_cast<const int*>(blk_)[16];                                                                      \
+        T = *reinterpret_cast<const float4*>(blk_ + 64);                                                                  \
     }
-        if (cur >= 0) PAIR_LANE_DATA(cur, cx0, cw4)
-        // VAR: 0 the common source, 1 padded layout (resample ratio within PAD_EPS of 1), 2 FixedGain / soft clip and/or a cursor that starts negative
+        if (cur >= 0) PAIR_LANE_DATA(cur, cx0, ct)
+        // VAR: 0 the common source, 1 padded layout (resample ratio within PAD_EPS of 1), 2 FixedGain and/or a cursor that starts negative
 #define PAIR_VARIANT(INFO) ((((INFO) >> 3) & SFLAG_PAD) ? 1 : ((((INFO) >> 3) & (SFLAG_FG | SFLAG_NEG)) ? 2 : 0))
 #define PAIR_STAGED_SOURCE(VAR, PRE)                                                                                      \
     {                                                                                                                     \
         const int flags_j = (int)((cur_info >> 3) & 31u);                                                                 \
         unsigned char* win_bytes = smem + (buf ? PAIR_LDS_WIN1 : PAIR_LDS_WIN0);                                          \
         const int nvec_j = (int)((cur_info >> 8) & 511u);                                                                 \
-        const float ds_j = rl_f(qds, 4 * cur), g0_j = rl_f(qg0, 4 * cur), dg_j = rl_f(qdg, 4 * cur);                      \
         window_wait();                                    /* this wave's half of the window has landed */                 \
         pair_barrier();                                   /* ... and the other wave's; both are done with the other buffer */ \
-        PAIR_HANDOVER_DONE()                                                                                              \
+        asm volatile("" : "+v"(pv.x), "+v"(pv.y), "+v"(pv.z), "+v"(pv.w), "+v"(pq.x), "+v"(pq.y), "+v"(pq.z), "+v"(pq.w), "+v"(pf), "+v"(pw)); \
+        const bool fetched_before = !need_prefetch;                                                                       \
+        if (need_prefetch) { PAIR_LOAD_GROUP(g - 1u, pv, pq, pf, pw) need_prefetch = false; }                             \
         const unsigned below = lds_mask & ((1u << cur) - 1u);                                                             \
         const int nxt = below ? 31 - __builtin_clz(below) : -1;                                                           \
         uint32_t nxt_info = 0;                                                                                            \
         float nx0 = 0.0f;                                                                                                 \
-        int nw4 = 0;                                                                                                      \
+        float4 nt = make_float4(0.0f, 0.0f, 0.0f, 0.0f);                                                                  \
         if (nxt >= 0) {          /* start the next staged source of this group; lands while we compute */                \
             nxt_info = (uint32_t)__builtin_amdgcn_readlane((int)vdesc.w, nxt);                                            \
             PAIR_ISSUE_WINDOW(nxt, buf ^ 1)                                                                               \
-            PAIR_LANE_DATA(nxt, nx0, nw4)                                                                                 \
-        } else if ((PRE) && g > g_lo && rec_ready) {                                                                      \
-            /* last staged source of the group: the other window buffer is free for the next group's first window, whose */ \
-            /* record is in the stage */                                                                                  \
+            PAIR_LANE_DATA(nxt, nx0, nt)                                                                                  \
+        } else if ((PRE) && g > g_lo && fetched_before) {                                                                 \
+            /* last staged source of the group: the other window buffer is free for the next group's first window */     \
             int lb_ = lane;                                                                                               \
             asm volatile("" : "+v"(lb_));                                                                                 \
-            uint32_t ni_ = 0u;                                                                                            \
-            if (lb_ < PAIR_GROUP) ni_ = *reinterpret_cast<const uint32_t*>(rstage + lb_ * (int)sizeof(PairRec) + 12);     \
-            const unsigned nm_ = (unsigned)__ballot(lb_ < PAIR_GROUP && (int)(ni_ & 7u) == PATH_LDS) & 0xffu;             \
-            if (nm_) {                                                                                                    \
-                const int jn_ = 31 - __builtin_clz(nm_);                                                                  \
-                const uint4 nd_ = *reinterpret_cast<const uint4*>(rstage + jn_ * (int)sizeof(PairRec));   /* (one address: a broadcast read) */ \
-                pair_window_dma(lds_base + (uint32_t)((buf ^ 1) ? PAIR_LDS_WIN1 : PAIR_LDS_WIN0), (uint32_t)__builtin_amdgcn_readfirstlane((int)nd_.x), \
-                                (uint32_t)__builtin_amdgcn_readfirstlane((int)nd_.y), (uint32_t)__builtin_amdgcn_readfirstlane((int)nd_.z), \
-                                (uint32_t)__builtin_amdgcn_readfirstlane((int)nd_.w), lane16, wv ^ (jn_ & 1));             \
-                pre_issued = true;                                                                                        \
-            }                                                                                                             \
+            const unsigned nm_ = (unsigned)__ballot(lb_ < MIX_GROUP && (int)(pv.w & 7u) == PATH_LDS) & 0xffffu;           \
+            if (nm_) { PAIR_ISSUE_WINDOW_OF(pv, 31 - __builtin_clz(nm_), buf ^ 1) pre_issued = true; }                    \
         }                                                                                                                 \
+        const int wrel4 = __float_as_int(ct.x);                                                                           \
         if ((VAR) == 1) {                                                                                                 \
-            const float fg = (flags_j & SFLAG_FG) ? st[g * PAIR_GROUP + (uint32_t)cur].fixed_gain : 1.0f;   /* v * 1.0 == v */ \
+            const float fg = (flags_j & SFLAG_FG) ? st[g * MIX_GROUP + (uint32_t)cur].fixed_gain : 1.0f;   /* v * 1.0 == v */ \
             const float frac0_ = reinterpret_cast<const float*>(blkB0 + cur * BLK_SRC)[0];   /* checkpoint 0 */           \
             const int fast_e = wv ? (flags_j & SFLAG_FAST_R) : (flags_j & SFLAG_FAST_L);                                  \
             pair_repack_padded(win_bytes, nvec_j, lane, wv, P.bounds_err);                                                \
-            mix_source_lds<FULL, true, false, true, FUSED, false, false, PAIR_WIN_CAP, true, FUSED>(win_bytes, cw4, cx0, bB, fast_e, frac0_, acc, fi, frame0, n_frames, fg, g0_j, dg_j, ds_j, 4 * nvec_j, P.bounds_err, \
-                                                                                                    0, 0, (int)((cur_info >> 28) & 7u)); \
+            mix_source_lds<FULL, true, false, true, FUSED, false, false, PAIR_WIN_CAP, true, FUSED>(win_bytes, wrel4, cx0, bB, fast_e, frac0_, acc, fi, frame0, n_frames, fg, ct.y, ct.z, ct.w, 4 * nvec_j, P.bounds_err, \
+                                                                                             0, 0, (int)((cur_info >> 28) & 7u)); \
         } else if ((VAR) == 0) {                                                                                          \
-            mix_source_lds<FULL, false, true, false, FUSED, false, false, PAIR_WIN_CAP, false, FUSED>(win_bytes, cw4, cx0, bB, 0, 0.0f, acc, fi, frame0, n_frames, 1.0f, g0_j, dg_j, ds_j, 4 * nvec_j, P.bounds_err); \
+            mix_source_lds<FULL, false, true, false, FUSED, false, false, PAIR_WIN_CAP, false, FUSED>(win_bytes, wrel4, cx0, bB, 0, 0.0f, acc, fi, frame0, n_frames, 1.0f, ct.y, ct.z, ct.w, 4 * nvec_j, P.bounds_err); \
         } else {                                                                                                          \
-            const float fg = (flags_j & SFLAG_FG) ? st[g * PAIR_GROUP + (uint32_t)cur].fixed_gain : 1.0f;                 \
-            mix_source_lds<FULL, true, false, false, FUSED, false, false, PAIR_WIN_CAP, true, FUSED>(win_bytes, cw4, cx0, bB, 0, 0.0f, acc, fi, frame0, n_frames, fg, g0_j, dg_j, ds_j, 4 * nvec_j, P.bounds_err, \
-                                                                                                     0, 0, (int)((cur_info >> 28) & 7u)); \
+            const float fg = (flags_j & SFLAG_FG) ? st[g * MIX_GROUP + (uint32_t)cur].fixed_gain : 1.0f;                  \
+            mix_source_lds<FULL, true, false, false, FUSED, false, false, PAIR_WIN_CAP, true, FUSED>(win_bytes, wrel4, cx0, bB, 0, 0.0f, acc, fi, frame0, n_frames, fg, ct.y, ct.z, ct.w, 4 * nvec_j, P.bounds_err, \
+                                                                                              0, 0, (int)((cur_info >> 28) & 7u)); \
         }                                                                                                                 \
         buf ^= 1;                                                                                                         \
-        cur = nxt; cur_info = nxt_info; cx0 = nx0; cw4 = nw4;                                                             \
+        cur = nxt; cur_info = nxt_info; cx0 = nx0; ct = nt;                                                               \
     }
         // rare path: both waves park their accumulators (wave w over window buffer w: a window in flight is awaited first and
         // fetched again afterwards), run out of line, fetch them back
@@ -301,16 +266,17 @@ __global__ __launch_bounds__(128, PAIR_WAVES_PER_SIMD) void spatial_mix_pair(Sce
     {                                                                                                                     \
         const int path_j = __builtin_amdgcn_readlane((int)vdesc.w, (J)) & 7;                                              \
         float* park = reinterpret_cast<float*>(smem + wv * PAIR_WIN_BYTES);                                               \
-        const float ph_ = reinterpret_cast<const float*>(blkB0 + (J) * BLK_SRC)[0];       /* (an inline Sine: the chunk's phase) */ \
+        float ph_ = 0.0f;                                                                                                 \
+        float4 t_ = make_float4(0.0f, 0.0f, 0.0f, 0.0f);                                                                  \
+        if (path_j == PATH_SINE_INLINE) { PAIR_LANE_DATA((J), ph_, t_) ph_ = reinterpret_cast<const float*>(blkB0 + (J) * BLK_SRC)[0]; } \
         window_wait();                                                                                                    \
         pair_barrier();                                   /* no window DMA of either wave is in flight any more */       \
-        PAIR_HANDOVER_DONE()                                                                                              \
         _Pragma("unroll") for (int k = 0; k < 16; ++k) park[k * PARK_STRIDE + lane] = acc[k];                             \
         wave_sync();                                                                                                      \
         if (path_j == PATH_SINE_INLINE)                                                                                   \
-            mix_source_sine(park, lane, frame0, n_frames, ph_, rl_f(qds, 4 * (J)), __int_as_float(__builtin_amdgcn_readlane((int)vdesc.x, (J))), \
-                            __int_as_float(__builtin_amdgcn_readlane((int)vdesc.y, (J))), rl_f(qg0, 4 * (J)), rl_f(qdg, 4 * (J))); \
-        else mix_source_rare_ear(park, lane, frame0, n_frames, (uint32_t)cB, path_j, st, ear, g * PAIR_GROUP + (uint32_t)(J), P.cycle_rows, P.cycle_plane, wv); \
+            mix_source_sine(park, lane, frame0, n_frames, ph_, t_.w, __int_as_float(__builtin_amdgcn_readlane((int)vdesc.x, (J))), \
+                            __int_as_float(__builtin_amdgcn_readlane((int)vdesc.y, (J))), t_.y, t_.z);                    \
+        else mix_source_rare_ear(park, lane, frame0, n_frames, (uint32_t)cB, path_j, st, ear, g * MIX_GROUP + (uint32_t)(J), P.cycle_rows, P.cycle_plane, wv); \
         wave_sync();                                                                                                      \
         _Pragma("unroll") for (int k = 0; k < 16; ++k) acc[k] = park[k * PARK_STRIDE + lane];                             \
         pair_barrier();                                   /* both park areas are free again */                            \
@@ -338,19 +304,13 @@ __global__ __launch_bounds__(128, PAIR_WAVES_PER_SIMD) void spatial_mix_pair(Sce
 #undef PAIR_VARIANT
 #undef PAIR_LANE_DATA
 #undef PAIR_ISSUE_WINDOW
-        if (!rec_ready) {        // fewer than two hand-overs in this group: settle the next group's records here
-            if (!rec_issued) {
-                pair_barrier();                           // both waves are past this group's phase A
-                if (wv == 0) pair_rec_dma(lds_base + (uint32_t)PAIR_LDS_RECS, rd0, rd1, rd2, g - 1u, lane16);
-            }
-            window_wait();
-            pair_barrier();
-        }
-#undef PAIR_HANDOVER_DONE
+#undef PAIR_ISSUE_WINDOW_OF
+        if (need_prefetch) PAIR_LOAD_GROUP(g - 1u, pv, pq, pf, pw)   // a group without a staged source
         wave_sync();   // before the next group's phase A overwrites the stream blocks
     }
+#undef PAIR_LOAD_GROUP
 
-    // ---- this wave's half of the workgroup's partial sums: ear wv, frames 16 lane .. ----
+    // ---- this wave's half of the workgroup's partial tiles: ear wv, frames 16 lane .. (tile = lane >> 5) ----
     int le = threadIdx.x & 63;
     asm volatile("" : "+v"(le));
     if (16u * (uint32_t)le < n_frames) {

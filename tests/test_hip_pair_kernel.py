@@ -1,6 +1,6 @@
 """spatial_mix_pair (csrc/pair_kernels.h): the two-wavefront-per-source mix kernel that large FAST-mode scenes take for
 callbacks of 513..1024 frames.  ODDIO_HIP_PAIR_MIN_GROUPS=1 sends small scenes through it, where what it must produce can
-be written down exactly: workgroup w renders groups of 8 slots, each ear in one wavefront that adds its sources in
+be written down exactly: workgroup w renders groups of 16 slots, each ear in one wavefront that adds its sources in
 descending slot order from zero (spatial.rs:204,459-460); reduce_partials adds the workgroups in ascending order.  In
 MODE_FAST_UNFUSED every contribution carries the reference's own roundings, so the result is bit for bit that sum of
 single-source oracle renders; MODE_FAST (fused lerp / ramp / accumulate) stays within the north_star's 1e-5 of the
@@ -148,12 +148,12 @@ def test_pair_kernel_unfused_is_the_sum_of_exact_contributions(monkeypatch, n_sr
     got, n_live = _render_hip(monkeypatch, oa.MODE_FAST_UNFUSED, sources, n_frames, n_cb, pair=True)
     ref, ref_live = _render_oracle(sources, n_frames, n_cb)
     assert n_live == ref_live
-    n_groups = (n_src + 7) // 8
+    n_groups = (n_src + 15) // 16
     for cb in range(n_cb):
         want = None
-        for w in range(n_groups):                                  # one workgroup per group of 8 slots (PAIR_GROUP)
+        for w in range(n_groups):                                  # one workgroup per group of 16 slots (PAIR_GROUP)
             acc = np.zeros((n_frames, 2), dtype=np.float32)
-            for i in range(min(8 * w + 8, n_src) - 1, 8 * w - 1, -1):
+            for i in range(min(16 * w + 16, n_src) - 1, 16 * w - 1, -1):
                 acc = acc + contrib[i][cb]
             want = acc if want is None else want + acc             # reduce_partials: workgroups in ascending order
         np.testing.assert_array_equal(got[cb], want, err_msg=f"callback {cb}")
