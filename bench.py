@@ -422,6 +422,67 @@ def buffered_cpu_and_parity(device: int, seed: int, budget_s: float) -> tuple[di
     return cpu, parity
 
 
+def multi_gpu_selfcheck(device: int, rank: int, world: int, dist, reduce_pref: str) -> dict:
+    """Before anything is timed on more than one rank: ONE seeded 4 096-source scene rendered (a) whole on this rank's GPU and (b) in
+    `world` contiguous index shards, one per rank, summed by the library's own reduce -- the RCCL all-reduce, or, when its communicator
+    cannot be created (ncclCommInitRank fails: ranks that share a device, no usable librccl), the rank-ordered peer-to-peer reduce --
+    and the two compared on every rank.  A sharded scene that does not reproduce the unsharded one ends the run here, not in a number.
+    -> {"reduce": the reduce that works on this box, "rccl_error": what RCCL said if it failed, "max_rel_err": worst rank's}"""
+    import torch
+
+    import oddio_amd as oa
+    from oddio_amd import sharding, synth
+    S, CL, SEED = 4096, 8192, 777
+    dev = torch.device("cuda", device)
+    gen = torch.Generator(device=dev).manual_seed(SEED)
+    clips = (torch.rand((S, CL), device=dev, dtype=torch.float32, generator=gen) * 2.0 - 1.0).contiguous()   # (the same on every rank)
+    frames = [oa.Frames.from_device_ptr(RATE, clips.data_ptr() + 4 * CL * i, CL, device=device, copy=False) for i in range(S)]
+    sc = synth.make_scene(SEED, S, cube=10.0)
+    interval = np.float32(1.0) / np.float32(RATE)
+
+    def render(control, scene, lo, hi):
+        control.play_frames_batch(frames[lo:hi], np.full(hi - lo, 0.06), sc["position"][lo:hi], sc["velocity"][lo:hi], sc["radius"][lo:hi])
+        outs = []
+        for _ in range(2):
+            o = torch.zeros((N_FRAMES, 2), dtype=torch.float32, device=dev)
+            scene.sample_device(interval, o.data_ptr(), N_FRAMES)
+            scene.synchronize()
+            outs.append(o.cpu().numpy())
+        return outs
+    control, scene = oa.SpatialScene(device=device, max_sources=S, max_frames=N_FRAMES)
+    whole = render(control, scene, 0, S)
+    scene.close()
+    kind, rccl_error = reduce_pref, None
+    sh = None
+    if kind == "rccl":
+        uid = sharding.exchange_unique_id(dist)
+        try:
+            sh = sharding.ShardedSpatialScene(device, S, N_FRAMES, rank, world, uid, reduce="rccl", dist=dist)
+            ok = True
+        except Exception as e:      # ncclCommInitRank refused (oddio_hip_scene_reduce_init returns its error)
+            ok, rccl_error = False, str(e)[:300]
+        flags = [None] * world
+        dist.all_gather_object(flags, (ok, rccl_error))
+        if not all(f[0] for f in flags):
+            rccl_error = next(f[1] for f in flags if not f[0])
+            if sh is not None:
+                sh.scene.close()
+            sh, kind = None, "p2p"
+    if sh is None:
+        sh = sharding.ShardedSpatialScene(device, S, N_FRAMES, rank, world, None, reduce="p2p", dist=dist)
+    lo, hi = sh.shard
+    got = render(sh.control, sh.scene, lo, hi)
+    sh.scene.close()
+    err = max(float(np.abs(g - w).max()) / max(float(np.abs(w).max()), 1e-30) for g, w in zip(got, whole))
+    errs = [None] * world
+    dist.all_gather_object(errs, err)
+    if max(errs) > 1e-5:
+        raise SystemExit(f"multi-GPU self-check failed: the {world}-shard scene (reduce: {kind}) differs from the unsharded one by {max(errs):.3g} "
+                         f"of its peak on some rank (per rank: {errs})")
+    del frames, clips
+    return {"sources": S, "reduce": kind, "rccl_error": rccl_error, "max_rel_err": max(errs)}
+
+
 def bench_mixer(device: int, frames_bank) -> dict:
     """The Mixer leg (mixer.rs is on the north_star's path; BASELINE configs[0] is a Mixer): host-output callbacks, a few of each, and the
     headline-size Mixer through the device-output entry with its roofline; reported only.  `frames_bank`: Frames of the Seek workload's clips."""
@@ -720,6 +781,7 @@ def main():
     ap.add_argument("--reduce", choices=["rccl", "p2p"], default="rccl",
                     help="--mode sharded: the cross-rank sum of the stereo buffer -- RCCL all-reduce, or the library's deterministic "
                          "peer-to-peer reduce (rank-ordered sum on rank 0; works with several ranks on one GPU)")
+    ap.add_argument("--no-selfcheck", action="store_true", help="--gpus N > 1: skip the sharded-vs-unsharded scene check that precedes the timed run")
     ap.add_argument("--share-devices", action="store_true", help="smoke-testing on a box with fewer GPUs than ranks: rank r uses device r %% count")
     ap.add_argument("--reset-every", type=int, default=320, help="callbacks between host-side motion resets of all sources")
     ap.add_argument("--precondition-hold", type=int, default=32,
@@ -776,6 +838,13 @@ def main():
         print(json.dumps(bench_buffered(args, device)), flush=True)
         return
     S, L = args.sources, args.clip_len
+    selfcheck = None
+    if world > 1 and not args.no_selfcheck:
+        selfcheck = multi_gpu_selfcheck(device, rank, world, dist, args.reduce)
+        if selfcheck["reduce"] != args.reduce:
+            if rank == 0:
+                print(f"[bench] RCCL reduce group unavailable ({selfcheck['rccl_error']}); the sharded scene uses the peer-to-peer reduce", file=sys.stderr)
+            args.reduce = selfcheck["reduce"]
     sharded = args.mode == "sharded" and world > 1
     # clips start 1.0 s in: the propagation delay (<= 0.25 s at set-up) may grow by the drift of the
     # constant-velocity sources (<= 34.6 m/s) for `reset_every` callbacks without reading before the clip
@@ -941,12 +1010,14 @@ def main():
 
     ranks_seen = 1
     per_rank_ms = [elapsed / args.steps * 1e3]
+    per_rank_mix_ms = [float(hist[:, 1].mean())]
     reduce_info = scene.reduce_info() if hasattr(scene, "reduce_info") else {"kind": "none", "world": 1, "rccl_version": 0, "rccl_lib": None}
     if dist is not None:
         # every rank's own time (the line's ms_per_step is their maximum) and what every rank's library says about its reduce group
         gathered = [None] * world
-        dist.all_gather_object(gathered, {"ms": elapsed / args.steps * 1e3, "reduce": reduce_info})
+        dist.all_gather_object(gathered, {"ms": elapsed / args.steps * 1e3, "reduce": reduce_info, "mix_ms": float(hist[:, 1].mean())})
         per_rank_ms = [g_["ms"] for g_ in gathered]
+        per_rank_mix_ms = [g_["mix_ms"] for g_ in gathered]
         t = torch.tensor([elapsed], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -1003,6 +1074,9 @@ def main():
                 "parallelism": ("single-gpu" if world == 1 else ((f"source-sharded scene + stereo-buffer reduce ({args.reduce})") if sharded else "scene-parallel")),
                 "ranks_seen": ranks_seen,
                 "ms_per_step_by_rank": per_rank_ms,
+                # every rank's own roofline fraction (its mix kernel's average over the timed callbacks against the 8 TB/s peak)
+                "roofline_frac_by_rank": [algorithmic_bytes(len(g["ids"]), N_FRAMES) / (m_ * 1e-3) / 1e9 / HBM_PEAK_GBPS for m_ in per_rank_mix_ms],
+                "multi_gpu_selfcheck": selfcheck,        # (N > 1) the sharded-vs-unsharded scene check that ran before the timed region, and the reduce it found working
                 "reduce_group": reduce_info,            # rank 0's: kind, world (ncclCommCount / slab), librccl path and version
             },
             # the figure that conforms to the north_star tolerance at this source count: ORDERED mode (the reference's sum order,

@@ -204,13 +204,18 @@ int oddio_hip_scene_set_control_batch(oddio_hip_scene* scene, size_t n, const ui
 /* The same n stores, and n Spatial::set_motion calls (src/spatial.rs:137-149; positions / velocities
  * [n][3]), with the handle ids and the values in DEVICE memory (readable on the scene's device): one
  * message on the control queue, applied by a kernel in message order at the next sample call -- for
- * hosts that compute gains or trajectories on the GPU.  The arrays must stay valid until that sample
- * call has executed (e.g. oddio_hip_scene_synchronize after it).  Ids of sources that have left the
+ * hosts that compute gains or trajectories on the GPU.  The arrays must stay valid until the sample call
+ * that consumes the message has executed (oddio_hip_scene_device_updates_pending below tells when).  Ids of sources that have left the
  * scene are skipped.  The get_* calls above do not see device-side stores. */
 int oddio_hip_scene_set_control_device(oddio_hip_scene* scene, size_t n, const uint32_t* d_source_ids,
                                        int filter_index, const float* d_values);
 int oddio_hip_scene_set_motion_device(oddio_hip_scene* scene, size_t n, const uint32_t* d_source_ids,
                                       const float* d_positions, const float* d_velocities, int discontinuity);
+/* How long the arrays of the two calls above must live: a message is consumed by the sample call that drains it from the
+ * control queue -- normally the next one, a later one when that call's staging was still busy -- and read by a kernel
+ * that call enqueues.  *n_pending = the device-array messages no sample call has handed to the stream yet; once it is 0,
+ * oddio_hip_scene_synchronize (or any wait on the scene's stream) makes every array passed so far free to release. */
+int oddio_hip_scene_device_updates_pending(oddio_hip_scene* scene, size_t* n_pending);
 /* Which kernels render the buffered set (results are identical): 1 (default) = the batched path for
  * FramesSignal leaves under FixedGain / Gain / Speed chains (ring write 16 sources per wavefront, ring
  * reads in the Seek set's mix kernel) with the general kernel for every other shape; 0 = the general

@@ -108,6 +108,7 @@ def lib():
         "oddio_hip_source_set_motion": (i32, [vp, u32, fp, fp, i32]),
         "oddio_hip_scene_reserve_buffered": (i32, [vp, u32]),
         "oddio_hip_scene_play_buffered": (i32, [vp, i32, vp, f64, f32, f32, vp, i32, fp, fp, f32, f32, u32, f32, u32p]),
+        "oddio_hip_scene_device_updates_pending": (i32, [vp, C.POINTER(sz)]),
         "oddio_hip_scene_play_filtered": (i32, [vp, i32, vp, f64, f32, f32, vp, i32, fp, fp, f32, u32p]),
         "oddio_hip_source_set_gain": (i32, [vp, u32, i32, f32]),
         "oddio_hip_source_set_gain_db": (i32, [vp, u32, i32, f32]),

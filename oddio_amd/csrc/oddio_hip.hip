@@ -64,6 +64,38 @@ struct DeviceGuard {
     ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
 };
 
+// The host-output calls wait for a ticket that the callback's last kernel stores in pinned memory (a D2H copy + hipStreamSynchronize
+// costs 30-50 us of wake-up latency per callback, the ticket ~5).  The spin is bounded by what the caller's callbacks have been
+// taking -- 8 x the longest recent wait, at least 2 ms, at most 200 ms -- after which the caller falls back to the stream
+// synchronisation (a wedged device then surfaces as that call's error instead of 200 ms of a spinning core per callback).
+// `ewma_us`: the caller's running estimate of its waits, updated here.
+static inline void cpu_relax() {
+#if defined(__x86_64__) || defined(__i386__)
+    __builtin_ia32_pause();
+#elif defined(__aarch64__)
+    asm volatile("isb" ::: "memory");
+#else
+    asm volatile("" ::: "memory");
+#endif
+}
+static inline bool spin_for_ticket(const uint32_t* flag, uint32_t ticket, double* ewma_us) {
+    const double budget_us = std::min(200000.0, std::max(2000.0, 8.0 * *ewma_us));
+    const auto t0 = std::chrono::steady_clock::now();
+    bool seen = false;
+    double us = 0.0;
+    for (uint32_t it = 0;; ++it) {
+        if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) == ticket) { seen = true; break; }
+        if ((it & 255u) == 255u) {
+            us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+            if (us > budget_us) break;
+        }
+        cpu_relax();
+    }
+    if (seen) us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+    *ewma_us = seen ? std::max(us, 0.9 * *ewma_us) : std::max(*ewma_us, budget_us);   // (decays slowly, jumps up at once)
+    return seen;
+}
+
 // ---------------------------------------------------------------------------------------------
 // Frames
 // ---------------------------------------------------------------------------------------------

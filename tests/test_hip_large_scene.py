@@ -316,6 +316,9 @@ def test_bench_self_launch_two_ranks_sharded():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["config"]["ranks_seen"] == 2 and d["value"] > 0
     assert "p2p" in d["config"]["parallelism"]
+    chk = d["config"]["multi_gpu_selfcheck"]              # the sharded-vs-unsharded scene check that precedes the timed region
+    assert chk["reduce"] == "p2p" and chk["max_rel_err"] <= 1e-5 and chk["sources"] == 4096
+    assert len(d["config"]["roofline_frac_by_rank"]) == 2 and min(d["config"]["roofline_frac_by_rank"]) > 0
 
 
 def test_sharded_scene_two_gpus_p2p(tmp_path):
@@ -360,3 +363,8 @@ def test_bench_self_launch_two_ranks():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["config"]["ranks_seen"] == 2 and d["value"] > 0
     assert d["roofline"]["frac"] > 0 and d["roofline"]["frac_callback"] > 0
+    # the default reduce is RCCL; two ranks on ONE device cannot form a communicator (ncclCommInitRank refuses duplicate devices):
+    # the self-check falls back to the peer-to-peer reduce, says why, and still holds the sharded scene to the unsharded one
+    chk = d["config"]["multi_gpu_selfcheck"]
+    assert chk["reduce"] == "p2p" and chk["rccl_error"] and chk["max_rel_err"] <= 1e-5
+    assert len(d["config"]["roofline_frac_by_rank"]) == 2
