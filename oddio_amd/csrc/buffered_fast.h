@@ -48,7 +48,11 @@ constexpr int BW_LDS_TOTAL = BW_LDS_CK + 64 * BW_CK_STRIDE * 4;
 static_assert(BW_WIN_BYTES % 16 == 0 && BW_WIN_PIECES == 5, "leaf window buffer: five 1-KiB DMA pieces, the last one partial");
 
 enum : uint32_t { BW_SKIP = 0, BW_FAST = 1, BW_SLOW = 2 };
-enum : uint32_t { BWF_LEAF_FAST = 8u, BWF_SEG2 = 16u, BWF_SPECIAL = 32u, BWF_PAD = 64u };
+// BWF_SYNTH (round 5): the leaf has no clip -- a Constant (the record's nvec field = 0; constant.rs:16-18) or a Sine (nvec = 1;
+// sine.rs:34-40: frac0[s] = the phase the s-th inner.sample call starts from, ds = the interval at the leaf) -- and is computed
+// where a FramesSignal's window would be read: the same chain, ring stores and sums as a clip source (before, such sources took the
+// general kernel, one wavefront and a slab each: 12x the time at scale).
+enum : uint32_t { BWF_LEAF_FAST = 8u, BWF_SEG2 = 16u, BWF_SPECIAL = 32u, BWF_PAD = 64u, BWF_SYNTH = 128u };
 
 // What the walk leaves for buffered_write per slot.
 //   desc     buffer descriptor words 0-2 of the leaf window (window_desc: clipped to the clip, zeros outside it)
@@ -70,14 +74,15 @@ struct alignas(16) WriteRec {
     uint32_t ops;
     float c[MAX_WRAP];
     float rprev[2], rnext[2], rp0[2], rstep[2];
-    uint32_t pad[6];
+    float leaf_a;             // a synthesised leaf (BWF_SYNTH): Sine's freq in rad/s (sine.rs:21) or the Constant's value
+    uint32_t pad[5];
 };
 static_assert(sizeof(WriteRec) == 128, "WriteRec layout");
 // (buffered_write reads the record as 32-bit words through v_readlane: word indices below)
 static_assert(offsetof(WriteRec, info) == 12 && offsetof(WriteRec, ring) == 16 && offsetof(WriteRec, ring_len) == 24 && offsetof(WriteRec, start_idx) == 28 &&
               offsetof(WriteRec, frac0) == 32 && offsetof(WriteRec, ds) == 40 && offsetof(WriteRec, wrel) == 44 && offsetof(WriteRec, cnt) == 48 &&
               offsetof(WriteRec, ops) == 52 && offsetof(WriteRec, c) == 56 && offsetof(WriteRec, rprev) == 72 && offsetof(WriteRec, rnext) == 80 &&
-              offsetof(WriteRec, rp0) == 88 && offsetof(WriteRec, rstep) == 96, "WriteRec word indices");
+              offsetof(WriteRec, rp0) == 88 && offsetof(WriteRec, rstep) == 96 && offsetof(WriteRec, leaf_a) == 104, "WriteRec word indices");
 
 // the per-ear scalars of spatial.rs:409-423 for a source the general kernel renders after buffered_walk
 struct alignas(16) BufEar { float prev_offset, dt, g0, dg; };
@@ -177,10 +182,12 @@ __device__ __forceinline__ bool ring_tile_rec(TileRec& r, const SceneParams& P, 
 // Mixer's chain sources (mixer_chain_walk, mixer_kernels.h), whose "ring" is the source's slab.
 __device__ __forceinline__ bool chain_write_rec(WriteRec& wr, uint32_t* bounds_err, const BufStatic& s, const BufDyn& d, const SrcDyn& c, float interval,
                                                 uint32_t cnt1, uint32_t cnt2, bool seg2, size_t start_idx, float* ring, uint32_t rlen, uint32_t src_index,
-                                                bool fast, double& t_new, float (&sm_prev)[MAX_WRAP], float (&sm_next)[MAX_WRAP], float (&sm_prog)[MAX_WRAP]) {
+                                                bool fast, double& t_new, float (&sm_prev)[MAX_WRAP], float (&sm_next)[MAX_WRAP], float (&sm_prog)[MAX_WRAP],
+                                                float& phase_new) {
     // the chain: interval per level (speed.rs:32-35), Smoothed::set (gain.rs:106-109) -- on copies; committed only if fast
     uint32_t ops = s.n_wrap & 7u;
     t_new = c.t;
+    phase_new = c.phase;
     if (fast) {
         float level_interval[MAX_WRAP];
         float cur = interval;
@@ -221,6 +228,32 @@ __device__ __forceinline__ bool chain_write_rec(WriteRec& wr, uint32_t* bounds_e
             }
         }
         if (n_ramp > 2) fast = false;
+        if (s.kind == KIND_CONSTANT || s.kind == KIND_SINE) {
+            // a leaf without a clip: nothing to stage, no cursor to scan
+            const bool sine = s.kind == KIND_SINE;
+            uint32_t fl = BWF_SYNTH | BWF_LEAF_FAST;
+            if (seg2) fl |= BWF_SEG2;
+            if (seg2 || start_idx < RING_MIRROR || cnt1 + cnt2 != BW_FRAMES) fl |= BWF_SPECIAL;
+            if (sine) {
+                // sin_small's argument reduction is exact for |x| < ~12 600 (kernels.h): the phase is in (-TAU, TAU), t * freq below:
+                if (!(fabsf((cur * (float)BW_FRAMES) * s.freq_or_value) < 12000.0f)) fast = false;
+                wr.frac0[0] = c.phase;
+                const float ph1 = fmodf(c.phase + (cur * (float)cnt1) * s.freq_or_value, ODDIO_TAU);     // sine.rs:39 after the first call
+                wr.frac0[1] = ph1;
+                phase_new = seg2 ? fmodf(ph1 + (cur * (float)cnt2) * s.freq_or_value, ODDIO_TAU) : ph1;
+            }
+            if (fast) {
+                wr.desc[0] = 0u; wr.desc[1] = 0u; wr.desc[2] = 0u;              // (an empty descriptor: the window DMA moves nothing)
+                wr.info = BW_FAST | fl | ((sine ? 1u : 0u) << 8);
+                wr.ring = ring; wr.ring_len = rlen; wr.start_idx = (uint32_t)start_idx;
+                wr.ds = cur;
+                wr.leaf_a = s.freq_or_value;
+                wr.wrel = 0u;
+                wr.cnt = cnt1 | ((cnt1 + cnt2) << 16);
+                wr.ops = ops;
+            }
+            return fast;
+        }
         // leaf: frames.rs:176-181 per inner.sample call
         const float ds = cur * (float)s.clip_rate;
         if (!(ds > 0.0f) || !(ds < 64.0f)) fast = false;
@@ -389,7 +422,8 @@ __global__ __launch_bounds__(128) void buffered_walk(SceneParams P, const BufSta
             }
             float sm_prev[MAX_WRAP], sm_next[MAX_WRAP], sm_prog[MAX_WRAP];
             double t_new = c.t;
-            fast = chain_write_rec(wr, P.bounds_err, s, d, c, 1.0f / (float)s.rate, cnt1, cnt2, seg2, start_idx, s.ring, rlen, i, fast, t_new, sm_prev, sm_next, sm_prog);
+            float phase_new = c.phase;
+            fast = chain_write_rec(wr, P.bounds_err, s, d, c, 1.0f / (float)s.rate, cnt1, cnt2, seg2, start_idx, s.ring, rlen, i, fast, t_new, sm_prev, sm_next, sm_prog, phase_new);
             // the ring reads of this callback start from the cursor Ring::write leaves (ring.rs:40)
             if (fast) {
 #pragma unroll
@@ -398,6 +432,7 @@ __global__ __launch_bounds__(128) void buffered_walk(SceneParams P, const BufSta
             }
             if (fast) {
                 c.t = t_new;
+                c.phase = phase_new;
                 d.ring_write = end;
 #pragma unroll
                 for (int w = 0; w < MAX_WRAP; ++w) { d.sm_prev[w] = sm_prev[w]; d.sm_next[w] = sm_next[w]; d.sm_progress[w] = sm_prog[w]; }
@@ -628,7 +663,21 @@ __global__ __launch_bounds__(64) void buffered_write(const WriteRec* __restrict_
             (void)win_slots;
             const float* ckl = ck + lane * BW_CK_STRIDE;
             // ---- the leaf: FramesSignal::sample (frames.rs:176-201) for this lane's 16 frames ----
-            if (!seg2) {
+            if (info & BWF_SYNTH) {
+                const float la = ODDIO_RF(26, j);
+                if (nvec == 0) {          // Constant::sample (constant.rs:16-18)
+#pragma unroll
+                    for (int k = 0; k < 16; ++k) out[k] = la;
+                } else {                  // Sine::sample (sine.rs:34-38): sin((interval * i as f32) * freq + phase), i counted from the call's first frame
+#pragma unroll 4
+                    for (int k = 0; k < 16; ++k) {
+                        const uint32_t f = f0 + (uint32_t)k;
+                        const bool second = seg2 && f >= cnt1;
+                        const float t = ds * (float)(second ? f - cnt1 : f);
+                        out[k] = sin_small(t * la + (second ? fr1 : fr0));
+                    }
+                }
+            } else if (!seg2) {
                 if (leaf_fast) {          // :180-187 constant fract, consecutive pairs (padded layout)
                     const int w0 = wrel0 + (int)f0;
                     {   // (the frames this lane stores: the last of them reads the pair (w0 + kv - 1, w0 + kv))

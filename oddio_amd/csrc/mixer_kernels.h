@@ -498,11 +498,12 @@ __global__ __launch_bounds__(128) void mixer_chain_walk(uint32_t n_sources, uint
     if (i >= n_sources) return;
     const BufStatic s = st[i];
     WriteRec wr = {};                                   // info == BW_SKIP: nothing to render
-    if (!(s.flags & BUF_FAST_OK) || s.fader || s.kind != KIND_FRAMES || s.channels != 1u) { wr.info = BW_SLOW; wrecs[i] = wr; return; }
+    const bool clip_leaf = s.kind == KIND_FRAMES;
+    if (!(s.flags & BUF_FAST_OK) || s.fader || !(clip_leaf || s.kind == KIND_SINE || s.kind == KIND_CONSTANT) || s.channels != 1u) { wr.info = BW_SLOW; wrecs[i] = wr; return; }
     const BufDyn d = dyn[i];
     if (d.common.flags & MIXDYN_STOPPED) { skip[i] = 1; wrecs[i] = wr; return; }
     bool fin = (d.common.flags & MIXDYN_STOP_REQUESTED) != 0;                                                       // mixer.rs:102
-    fin = fin || d.common.t >= (double)(s.clip_len - 1u) / (double)s.clip_rate;                                      // frames.rs:204-206
+    if (clip_leaf) fin = fin || d.common.t >= (double)(s.clip_len - 1u) / (double)s.clip_rate;                       // frames.rs:204-206 (a Sine / Constant never finishes)
     if (fin) {
         dyn[i].common.flags = d.common.flags | MIXDYN_STOPPED;
         const uint32_t k = atomicAdd(&stopped_hdr[0], 1u);
@@ -514,10 +515,12 @@ __global__ __launch_bounds__(128) void mixer_chain_walk(uint32_t n_sources, uint
     double t_new;
     float sm_prev[MAX_WRAP], sm_next[MAX_WRAP], sm_prog[MAX_WRAP];
     float* ring = slabs + (size_t)i * 2 * n_frames - RING_MIRROR;
+    float phase_new;
     const bool fast = chain_write_rec(wr, bounds_err, s, d, d.common, interval, n_frames, 0u, false, (size_t)RING_MIRROR, ring, 1u << 24, i, true,
-                                      t_new, sm_prev, sm_next, sm_prog);
+                                      t_new, sm_prev, sm_next, sm_prog, phase_new);
     if (fast) {
         dyn[i].common.t = t_new;                                                                                     // frames.rs:198
+        dyn[i].common.phase = phase_new;                                                                             // sine.rs:39
 #pragma unroll
         for (int w = 0; w < MAX_WRAP; ++w) { dyn[i].sm_prev[w] = sm_prev[w]; dyn[i].sm_next[w] = sm_next[w]; dyn[i].sm_progress[w] = sm_prog[w]; }
         skip[i] = acc_mode ? 1u : 0u;
@@ -644,7 +647,7 @@ __global__ void mixer_convert_to_general(uint32_t n, const MixStatic* __restrict
     BufStatic s = {};
     s.clip = ms[i].clip; s.clip_len = ms[i].clip_len; s.clip_rate = ms[i].clip_rate; s.freq_or_value = ms[i].freq_or_value;
     s.kind = ms[i].kind; s.channels = 1;
-    s.flags = ms[i].kind == KIND_FRAMES ? BUF_FAST_OK : 0u;      // (a chain source from now on: mixer_chain_walk)
+    s.flags = (ms[i].kind == KIND_FRAMES || ms[i].kind == KIND_SINE || ms[i].kind == KIND_CONSTANT) ? BUF_FAST_OK : 0u;      // (a chain source from now on: mixer_chain_walk)
     if (ms[i].fixed_gain != 1.0f) { s.n_wrap = 1; s.wrap_kind[0] = WRAP_FIXED_GAIN; s.wrap_param[0] = ms[i].fixed_gain; }
     BufDyn d = {};
     d.common.t = md[i].t; d.common.phase = md[i].phase; d.common.flags = md[i].flags; d.common.id = md[i].id;

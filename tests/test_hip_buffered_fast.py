@@ -143,8 +143,9 @@ def test_ragged_callbacks_and_unit_speed_fast_branch():
 
 
 def test_fast_equals_general_kernel_and_other_shapes_ride_along():
-    """Sine / Constant / Cycle leaves and a Fader keep the general kernel (their slab rows are added at their place in
-    the walk); the same scene rendered with the batched path switched off gives the same bits."""
+    """Cycle leaves (and Stream leaves, Faders) keep the general kernel -- their slab rows are added at their place in the walk --
+    while a Constant leaf rides the batched path since round 5; the same scene rendered with the batched path switched off gives
+    the same bits."""
     import oddio_amd as oa
     outs = []
     for fast in (True, False):
@@ -162,7 +163,7 @@ def test_fast_equals_general_kernel_and_other_shapes_ride_along():
         for cb in range(9):
             a, b = ref.sample_n(INTERVAL, 1024), scene.sample_n(INTERVAL, 1024)
             if fast:
-                assert scene.debug_buffered_slow() == len(extra)
+                assert scene.debug_buffered_slow() == 1            # the Speed<Cycle>
             np.testing.assert_array_equal(b, a, err_msg=f"fast={fast} callback {cb}")
             res.append(b)
         outs.append(np.stack(res))
@@ -376,4 +377,51 @@ def test_control_and_motion_updates_from_device_memory():
                 rh[i].set_motion(sc2["position"][i], sc2["velocity"][i], False)
         a, b = ref.sample_n(INTERVAL, 1024), scene.sample_n(INTERVAL, 1024)
         np.testing.assert_array_equal(b, a, err_msg=f"callback {cb}")
+    scene.close()
+
+
+@pytest.mark.parametrize("with_sine", [False, True])
+def test_synthesised_leaves_take_the_batched_path(with_sine):
+    """Round 5: Constant and Sine leaves under FixedGain / Gain / Speed chains are rendered by buffered_write like clip sources (the
+    leaf is computed where a clip's window would be read) -- no source of a 1024-frame callback is left to the general kernel.
+    Constant leaves are exact (ORDERED: bit for bit, rings wrapping inside the run included); Sine leaves go through the device's sine
+    (sin_small, ~1e-7 absolute): the north_star's 1e-5."""
+    import oddio_amd as oa
+    n_src = 150
+    sc = synth.make_scene(77, n_src, cube=15.0, vmax=18.0)
+    control, scene = oa.SpatialScene(max_sources=n_src + 8, max_frames=1024)
+    scene.reserve_buffered(n_src)
+    scene.set_mode(oa.MODE_ORDERED)
+    ref = oc.SpatialScene()
+    gains = []
+    for i in range(n_src):
+        kind = i % 3
+        if kind == 0:
+            clip = synth.noise_clip(77, i, 20000)
+            leaf_h, leaf_o = oa.FramesSignal(oa.Frames.from_slice(48000, clip), 0.0), oc.FramesSignal(oc.Frames(48000, clip), 0.0)
+        elif kind == 1 or not with_sine:
+            leaf_h, leaf_o = oa.Constant(0.3 + 0.001 * i), oc.Constant(0.3 + 0.001 * i)
+        else:
+            leaf_h, leaf_o = oa.Sine(0.05 * i, 200.0 + 3.0 * i), oc.Sine(0.05 * i, 200.0 + 3.0 * i)
+        if i % 4 == 1:
+            leaf_h, leaf_o = oa.FixedGain(leaf_h, -2.0), oc.FixedGain(leaf_o, -2.0)
+        gc, sig_h = oa.Gain.new(leaf_h)
+        sig_o = oc.Gain(leaf_o)
+        if i % 5 == 2:
+            spc, sig_h = oa.Speed.new(sig_h)
+            spc.set_speed(1.03)
+            sig_o = oc.Speed(sig_o)
+            sig_o.set_speed(1.03)
+        gains.append((gc, sig_o if i % 5 != 2 else None))
+        o = (sc["position"][i], sc["velocity"][i], 0.1)
+        # short rings (max_distance 20 m, 0.05 s): they wrap every few callbacks -- Ring::write's two inner.sample calls
+        control.play_buffered(sig_h, oa.SpatialOptions(*o), 20.0, 48000, 0.05)
+        ref.play_buffered(sig_o, oc.SpatialOptions(*o), 20.0, 48000, 0.05)
+    for cb in range(8):
+        got, want = scene.sample_n(INTERVAL, 1024), ref.sample_n(INTERVAL, 1024)
+        assert scene.debug_buffered_slow() == 0, cb
+        if with_sine:
+            assert np.abs(got - want).max() <= 1e-5 * np.abs(want).max(), cb
+        else:
+            np.testing.assert_array_equal(got, want, err_msg=f"callback {cb}")
     scene.close()

@@ -25,7 +25,42 @@ def time_calls(sig, n=1024, reps=20):
     return (time.perf_counter() - t0) / reps * 1e3
 
 
+def scale_table(n_src):
+    """Buffered spatial sources at scale, by leaf: Gain<FramesSignal> / Gain<Sine> / Gain<Constant> / Gain<Cycle> (device-output
+    callbacks enqueued back to back; `slow` = sources the callback left to the one-wavefront-per-source general kernel)."""
+    import torch
+    sc = synth.make_scene(11, n_src)
+    clip = oa.Frames.from_slice(48000, synth.noise_clip(1, 0, 480000))
+    cyc = oa.Frames.from_slice(48000, synth.noise_clip(3, 0, 5000))
+    out = torch.zeros((1024, 2), dtype=torch.float32, device="cuda:0")
+    leaves = [("Gain<FramesSignal>", lambda i: oa.FramesSignal(clip, 0.0)), ("Gain<Sine>", lambda i: oa.Sine(0.1 * i, 110.0 + 0.01 * i)),
+              ("Gain<Constant>", lambda i: oa.Constant(0.5)), ("Gain<Cycle>", lambda i: oa.Cycle(cyc))]
+    base = None
+    for name, mk in leaves:
+        control, scene = oa.SpatialScene(max_sources=n_src, max_frames=1024)
+        scene.reserve_buffered(n_src)
+        for i in range(n_src):
+            gc, g = oa.Gain.new(mk(i))
+            control.play_buffered(g, oa.SpatialOptions(sc["position"][i], sc["velocity"][i], 0.1), 100.0, 48000, 0.1)
+        for _ in range(6):
+            scene.sample_device(INTERVAL, out.data_ptr(), 1024)
+        scene.synchronize()
+        t0 = time.perf_counter()
+        reps = 12
+        for _ in range(reps):
+            scene.sample_device(INTERVAL, out.data_ptr(), 1024)
+        scene.synchronize()
+        ms = (time.perf_counter() - t0) / reps * 1e3
+        slow = scene.debug_buffered_slow() if hasattr(scene, "debug_buffered_slow") else -1
+        base = ms if base is None else base
+        print(f"buffered spatial sources at scale ({name}): {n_src:6d} -> {ms:8.3f} ms / 1024-frame callback ({ms / base:5.2f}x Gain<FramesSignal>; {slow} on the general kernel)", flush=True)
+        scene.close()
+
+
 def main():
+    if len(sys.argv) > 2 and sys.argv[1] == "--scale":
+        scale_table(int(sys.argv[2]))
+        return
     clip = oa.Frames.from_slice(48000, synth.noise_clip(1, 0, 480000))
     for n_src in (1, 64, 1024, 4096):
         control, scene = oa.SpatialScene(max_sources=8192, max_frames=1024)
