@@ -326,6 +326,110 @@ __global__ __launch_bounds__(64) void mixer_mix(uint32_t n_sources, uint32_t n_f
     for (int q = 0; q < 8; ++q) dst[q] = make_float4(acc[2 * q], acc[2 * q], acc[2 * q + 1], acc[2 * q + 1]);
 }
 
+// mixer_mix_unit (round 5): the Mixer's FAST-mode kernel when every live source is a plain MonoToStereo<FramesSignal> (mono clip,
+// optional FixedGain) whose clip rate is the output rate -- `interval * rate` within EPSILON of 1, FramesSignal's constant-fract branch
+// (frames.rs:180-187): out[i] = lerp(pair(base + i), fract) with ONE fract per source and callback.  No cursor to scan, no window to
+// stage: the wave reads the source's 1024 samples straight from HBM, 16 bytes per lane and instruction, fully coalesced -- lane l owns
+// the frames 4 l + 256 k .. + 3 (k = 0..3) -- once at the pair's first samples and once four bytes further on (the second samples: the
+// same cache lines).  Out-of-clip indices read zeros through a bounds-checked buffer descriptor (frames.rs:105-123).  Per source that
+// is 8 loads and 32 VALU operations per lane for 16 output frames; the sources of a group of 64 are software-pipelined two deep.
+// Arithmetic per contribution exactly the reference's (lerp, FixedGain); the sum is FAST mode's tree over waves (mixer_reduce).
+// The host launches it only when its own bookkeeping says every live source has that shape (mixer_host.inc: n_unit == len).
+// Algorithmic bytes per callback: S * (4 * N + 64) + 8 * N; mixer_mix (cursor scan, window through LDS) reached 0.46-0.48 of the
+// 8 TB/s peak on it, this kernel is bound by HBM alone.
+typedef float mixf4 __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(64) void mixer_mix_unit(uint32_t n_sources, uint32_t n_frames, float interval,
+                                                     const MixStatic* __restrict__ st, const MixParams* __restrict__ par,
+                                                     float* __restrict__ partials, uint32_t groups_per_wave, uint32_t n_groups) {
+    const int lane = threadIdx.x;
+    const uint32_t wave = blockIdx.x, tile = blockIdx.y;
+    mixf4 acc[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) acc[k] = mixf4{0.0f, 0.0f, 0.0f, 0.0f};
+    const uint32_t split_log2 = groups_per_wave >> 24;
+    uint32_t g_lo = wave * (groups_per_wave & 0xffffffu);
+    uint32_t g_hi = g_lo + (groups_per_wave & 0xffffffu);
+    int j_lo = 0, j_hi = MIXER_GROUP;
+    if (split_log2) {
+        g_lo = wave >> split_log2;
+        g_hi = g_lo + 1u;
+        const int per = MIXER_GROUP >> split_log2;
+        j_lo = (int)(wave & ((1u << split_log2) - 1u)) * per;
+        j_hi = j_lo + per;
+    }
+    if (g_hi > n_groups) g_hi = n_groups;
+    const int voff_lane = 16 * lane;                 // byte offset of this lane's first frame inside a 256-frame block
+
+    for (uint32_t g = g_hi; g-- > g_lo;) {
+        // ---- one lane per source: the clock split of frames.rs:177-181 ----
+        const uint32_t srcA = g * MIXER_GROUP + (uint32_t)lane;
+        MixParams mp = {};
+        MixStatic ss = {};
+        mp.flags = EAR_SKIP;
+        if (srcA < n_sources) { mp = par[srcA]; ss = st[srcA]; }
+        const bool live = srcA < n_sources && !(mp.flags & EAR_SKIP) && ss.kind == KIND_FRAMES;
+        int base_i = 0;
+        float frac0 = 0.0f;
+        if (live) {
+            double t_c = mp.t_start;
+            for (uint32_t cc = 0; cc < tile; ++cc) t_c = t_c + (double)interval * 1024.0;      // frames.rs:198 per earlier staging chunk
+            const double s0 = t_c * (double)ss.clip_rate;
+            const long long base = f64_as_isize(s0);
+            frac0 = (float)(s0 - (double)base);
+            // (indices beyond +-2^30 samples lie outside every clip: clamped so that the 32-bit byte offsets below stay out of range)
+            base_i = (int)(base > (1ll << 30) ? (1ll << 30) : (base < -(1ll << 30) ? -(1ll << 30) : base));
+        }
+        const unsigned long long live_mask = __ballot(live);
+        const uint32_t clip_lo = (uint32_t)((uint64_t)ss.clip & 0xffffffffu), clip_hi = (uint32_t)((uint64_t)ss.clip >> 32) & 0xffffu;
+        // ---- the sources of the group in descending slot order (mixer.rs:100), two in flight ----
+        mixf4 a[2][4], b[2][4];
+#define MIXU_LOAD(J, SLOT)                                                                                                \
+    {                                                                                                                     \
+        const __amdgpu_buffer_rsrc_t r_ = __builtin_amdgcn_make_buffer_rsrc(                                              \
+            (void*)(((uint64_t)(uint32_t)rl_i((int)clip_hi, (J)) << 32) | (uint64_t)(uint32_t)rl_i((int)clip_lo, (J))), 0,  \
+            (int)(4u * (uint32_t)rl_i((int)ss.clip_len, (J))), 0x00020000);                                               \
+        const int vo_ = 4 * rl_i(base_i, (J)) + voff_lane;                                                                \
+        _Pragma("unroll") for (int k = 0; k < 4; ++k) {                                                                   \
+            a[SLOT][k] = __builtin_bit_cast(mixf4, __builtin_amdgcn_raw_buffer_load_b128(r_, vo_ + 1024 * k, 0, 0));       \
+            b[SLOT][k] = __builtin_bit_cast(mixf4, __builtin_amdgcn_raw_buffer_load_b128(r_, vo_ + 1024 * k + 4, 0, 0));   \
+        }                                                                                                                 \
+    }
+        unsigned long long todo = live_mask;
+        if (j_hi < 64) todo &= (1ull << j_hi) - 1ull;
+        todo &= ~((1ull << j_lo) - 1ull);
+        int slot = 0;
+        int cur = todo ? 63 - __builtin_clzll(todo) : -1;
+        if (cur >= 0) MIXU_LOAD(cur, 0)
+        while (cur >= 0) {
+            todo &= ~(1ull << cur);
+            const int nxt = todo ? 63 - __builtin_clzll(todo) : -1;
+            if (nxt >= 0) {
+                if (slot == 0) MIXU_LOAD(nxt, 1) else MIXU_LOAD(nxt, 0)
+            }
+            const float fr = rl_f(frac0, cur), fg = rl_f(ss.fixed_gain, cur);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const mixf4 av = slot == 0 ? a[0][k] : a[1][k], bv = slot == 0 ? b[0][k] : b[1][k];
+                mixf4 v = av + fr * (bv - av);                      // frame.rs:39-41 (unfused)
+                v = v * fg;                                          // gain.rs:32-37 (x * 1.0 == x without FixedGain)
+                acc[k] = acc[k] + v;                                 // mixer.rs:114-116
+            }
+            slot ^= 1;
+            cur = nxt;
+        }
+#undef MIXU_LOAD
+    }
+    // MonoToStereo: duplicate (signal.rs:73-80); the partial tile is interleaved stereo like mixer_mix's
+    float* dst = partials + ((size_t)tile * gridDim.x + wave) * (2 * MIXER_TILE);
+    (void)n_frames;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        float4* d4 = reinterpret_cast<float4*>(dst + 2 * (4 * lane + 256 * k));
+        d4[0] = make_float4(acc[k].x, acc[k].x, acc[k].y, acc[k].y);
+        d4[1] = make_float4(acc[k].z, acc[k].z, acc[k].w, acc[k].w);
+    }
+}
+
 // out[o] = sum over waves (fixed order) of interleaved partial tiles, then Reinhard / Tanh
 __global__ __launch_bounds__(1024) void mixer_reduce(const float* __restrict__ partials, float* __restrict__ out,
                                                      uint32_t n_waves, uint32_t n_frames, int postfx) {
