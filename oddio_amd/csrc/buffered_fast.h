@@ -52,7 +52,11 @@ enum : uint32_t { BW_SKIP = 0, BW_FAST = 1, BW_SLOW = 2 };
 // sine.rs:34-40: frac0[s] = the phase the s-th inner.sample call starts from, ds = the interval at the leaf) -- and is computed
 // where a FramesSignal's window would be read: the same chain, ring stores and sums as a clip source (before, such sources took the
 // general kernel, one wavefront and a slab each: 12x the time at scale).
-enum : uint32_t { BWF_LEAF_FAST = 8u, BWF_SEG2 = 16u, BWF_SPECIAL = 32u, BWF_PAD = 64u, BWF_SYNTH = 128u };
+// BWF_CYCLE (round 5): the leaf is a Cycle (cycle.rs:26-53) over a mono clip at least as long as the callback's window: its cursor is
+// the pair (base, offset) -- the scan replays cycle.rs:37-42's rewrite at the clip's end (and :28-29's split at the second
+// inner.sample call of a wrapping Ring::write), `base` travels in the checkpoint rows of ramp slot B (such a chain has at most one
+// ramping Gain) -- and its window, linear modulo the clip length, is staged by plain loads; the wave leaves the cursor in BufDyn.
+enum : uint32_t { BWF_LEAF_FAST = 8u, BWF_SEG2 = 16u, BWF_SPECIAL = 32u, BWF_PAD = 64u, BWF_SYNTH = 128u, BWF_CYCLE = 1u << 28 };
 
 // What the walk leaves for buffered_write per slot.
 //   desc     buffer descriptor words 0-2 of the leaf window (window_desc: clipped to the clip, zeros outside it)
@@ -75,14 +79,15 @@ struct alignas(16) WriteRec {
     float c[MAX_WRAP];
     float rprev[2], rnext[2], rp0[2], rstep[2];
     float leaf_a;             // a synthesised leaf (BWF_SYNTH): Sine's freq in rad/s (sine.rs:21) or the Constant's value
-    uint32_t pad[5];
+    uint32_t cyc_base;        // a Cycle leaf (BWF_CYCLE): `base` of cycle.rs:28 at the callback's start (frac0[0] = its `offset`, :29)
+    uint32_t pad[4];
 };
 static_assert(sizeof(WriteRec) == 128, "WriteRec layout");
 // (buffered_write reads the record as 32-bit words through v_readlane: word indices below)
 static_assert(offsetof(WriteRec, info) == 12 && offsetof(WriteRec, ring) == 16 && offsetof(WriteRec, ring_len) == 24 && offsetof(WriteRec, start_idx) == 28 &&
               offsetof(WriteRec, frac0) == 32 && offsetof(WriteRec, ds) == 40 && offsetof(WriteRec, wrel) == 44 && offsetof(WriteRec, cnt) == 48 &&
               offsetof(WriteRec, ops) == 52 && offsetof(WriteRec, c) == 56 && offsetof(WriteRec, rprev) == 72 && offsetof(WriteRec, rnext) == 80 &&
-              offsetof(WriteRec, rp0) == 88 && offsetof(WriteRec, rstep) == 96 && offsetof(WriteRec, leaf_a) == 104, "WriteRec word indices");
+              offsetof(WriteRec, rp0) == 88 && offsetof(WriteRec, rstep) == 96 && offsetof(WriteRec, leaf_a) == 104 && offsetof(WriteRec, cyc_base) == 108, "WriteRec word indices");
 
 // the per-ear scalars of spatial.rs:409-423 for a source the general kernel renders after buffered_walk
 struct alignas(16) BufEar { float prev_offset, dt, g0, dg; };
@@ -253,6 +258,30 @@ __device__ __forceinline__ bool chain_write_rec(WriteRec& wr, uint32_t* bounds_e
                 wr.ops = ops;
             }
             return fast;
+        }
+        if (s.kind == KIND_CYCLE) {
+            const float dsc = cur * (float)s.clip_rate;                                           // cycle.rs:27
+            const uint32_t cnt = cnt1 + cnt2;
+            if (n_ramp > 1 || !(dsc > 0.0f) || !(dsc < 8.0f) || s.clip_len < 2u || !(c.t >= 0.0) || !(c.t < 1073741824.0)) fast = false;
+            const uint32_t w_count = fast ? (uint32_t)((float)cnt * dsc * 1.0001f) + 8u : 0u;      // every index the callback can read, as one stretch
+            if (w_count > (uint32_t)BW_WIN_CAP || w_count > s.clip_len) fast = false;              // (shorter loops lap inside a callback: general kernel)
+            if (fast) {
+                const uint32_t base0 = (uint32_t)c.t;                                              // `cursor as usize` (:28)
+                uint32_t fl = BWF_CYCLE;
+                if (seg2) fl |= BWF_SEG2;
+                if (seg2 || start_idx < RING_MIRROR || cnt != BW_FRAMES) fl |= BWF_SPECIAL;
+                const uint64_t cp = (uint64_t)s.clip;
+                wr.desc[0] = (uint32_t)(cp & 0xffffffffu); wr.desc[1] = (uint32_t)(cp >> 32) & 0xffffu; wr.desc[2] = 4u * s.clip_len;
+                wr.info = BW_FAST | fl;
+                wr.ring = ring; wr.ring_len = rlen; wr.start_idx = (uint32_t)start_idx;
+                wr.frac0[0] = (float)(c.t - (double)base0);                                        // :29
+                wr.ds = dsc;
+                wr.cyc_base = base0;
+                wr.wrel = 0u;
+                wr.cnt = cnt1 | (cnt << 16);
+                wr.ops = ops;
+            }
+            return fast;                               // (the cursor is advanced by buffered_write: it is the scan's result)
         }
         // leaf: frames.rs:176-181 per inner.sample call
         const float ds = cur * (float)s.clip_rate;
@@ -543,7 +572,8 @@ __global__ __launch_bounds__(64) void buffered_write(const WriteRec* __restrict_
         uint32_t infoA = 0;
         float x = 0.0f, inc = 0.0f, cap = __builtin_inff(), x2 = 0.0f;
         uint32_t n1 = 0xffffu;
-        bool is_ramp = false, is_cursor = false;
+        bool is_ramp = false, is_cursor = false, is_cyc = false;
+        uint32_t cb = 0u, clen = 0u;                   // a Cycle's `base` and clip length (slot-0 lane of the source)
         if (srcA < n_sources && slot < BW_SLOTS) {
             const WriteRec* r = wrecs + srcA;
             infoA = r->info;
@@ -553,6 +583,7 @@ __global__ __launch_bounds__(64) void buffered_write(const WriteRec* __restrict_
                         is_cursor = true;
                         x = r->frac0[0]; inc = r->ds;
                         if (infoA & BWF_SEG2) { n1 = r->cnt & 0xffffu; x2 = r->frac0[1]; }
+                        if (infoA & BWF_CYCLE) { is_cyc = true; cb = r->cyc_base; clen = r->desc[2] >> 2; }
                     }
                 } else {
                     const uint32_t ops = r->ops;
@@ -584,6 +615,7 @@ __global__ __launch_bounds__(64) void buffered_write(const WriteRec* __restrict_
 #define ODDIO_BW_ISSUE(J, BUF)                                                                                            \
     {                                                                                                                     \
         const uint32_t i_ = ODDIO_RW(3, (J));                                                                             \
+        if (!(i_ & BWF_CYCLE))     /* (a Cycle's window is staged by plain loads at its turn) */                           \
         leaf_window_dma(lds_base + (uint32_t)((BUF) ? BW_LDS_WIN1 : BW_LDS_WIN0), ODDIO_RW(0, (J)), ODDIO_RW(1, (J)), ODDIO_RW(2, (J)),  \
                         (int)((i_ >> 8) & 0xfffu), (int)((i_ >> 20) & 0xffu), lane16);                                    \
     }
@@ -598,10 +630,28 @@ __global__ __launch_bounds__(64) void buffered_write(const WriteRec* __restrict_
                 if (n1j < BW_FRAMES) restart_blocks |= 1ull << (n1j >> 4);
             }
             const bool any_ramp = __any(is_ramp);
+            const bool any_cyc = __any(is_cyc);
+            const bool own_row = lane < BW_STREAMS && !(slot == 2 && (infoA & BWF_CYCLE));   // (slot B's rows of a Cycle source hold its `base`)
             float* row = ck + lane;
 #pragma unroll 1
             for (int b = 0; b < 64; ++b) {
-                if (lane < BW_STREAMS) row[b * BW_CK_STRIDE] = x;
+                if (own_row) row[b * BW_CK_STRIDE] = x;
+                if (is_cyc) row[b * BW_CK_STRIDE + 2 * BW_GROUP] = __uint_as_float(cb);
+                // a block in which a Cycle's cursor may reach its clip's end, or restarts: cycle.rs:37-42 / :28-29 step by step
+                if (any_cyc && __any(is_cyc && (cb + f32_as_index(x + 17.0f * inc) + 2u >= clen || ((uint32_t)b == (n1 >> 4) && n1 < BW_FRAMES)))) {
+#pragma unroll 1
+                    for (int k = 0; k < 16; ++k) {
+                        if ((uint32_t)(16 * b + k) == n1) {
+                            if (is_cyc) { const double cur_ = (double)cb + (double)x; cb = (uint32_t)cur_; x = (float)(cur_ - (double)cb); }   // the second call's :28-29
+                            else x = x2;
+                        }
+                        if (is_cyc) {
+                            const uint32_t tr = f32_as_index(x);
+                            if (cb + tr >= clen) { const float fr = x - (float)tr; x = (float)((cb + tr) % clen) + fr; cb = 0u; }            // :39-41
+                        }
+                        x = fminf(x + inc, cap);
+                    }
+                } else
                 if ((restart_blocks >> b) & 1ull) {
 #pragma unroll 1
                     for (int k = 0; k < 16; ++k) {
@@ -663,7 +713,42 @@ __global__ __launch_bounds__(64) void buffered_write(const WriteRec* __restrict_
             (void)win_slots;
             const float* ckl = ck + lane * BW_CK_STRIDE;
             // ---- the leaf: FramesSignal::sample (frames.rs:176-201) for this lane's 16 frames ----
-            if (info & BWF_SYNTH) {
+            bool cyc_store = false;                       // (a Cycle: this lane holds the cursor after the callback's last frame)
+            uint32_t cyc_cb = 0u; float cyc_off = 0.0f;
+            if (info & BWF_CYCLE) {
+                // Cycle::sample (cycle.rs:26-53).  The window -- every index the callback reads, from the first one on, linear modulo
+                // the clip length (the pair's second sample, s[x + 1] or s[0] behind s[len - 1], is always the next slot) -- by plain loads:
+                const uint32_t clen_ = ODDIO_RW(2, j) >> 2;
+                const float* clip_ = reinterpret_cast<const float*>(((uint64_t)ODDIO_RW(1, j) << 32) | (uint64_t)ODDIO_RW(0, j));
+                const uint32_t w_start = (ODDIO_RW(27, j) + f32_as_index(fr0)) % clen_;
+                const uint32_t w_count = (uint32_t)((float)cnt * ds * 1.0001f) + 8u;             // (<= BW_WIN_CAP, <= clen_: chain_write_rec)
+                float* wst = reinterpret_cast<float*>(win_bytes);
+                for (uint32_t p_ = (uint32_t)lane; p_ < w_count; p_ += 64u) {
+                    uint32_t idx = w_start + p_;
+                    idx = idx >= clen_ ? idx - clen_ : idx;
+                    wst[p_] = clip_[idx];
+                }
+                wave_sync();
+                float off = ckl[j];
+                uint32_t cbv = __float_as_uint(ckl[2 * BW_GROUP + j]);
+#pragma unroll 1
+                for (int k = 0; k < 16; ++k) {
+                    const uint32_t f = f0 + (uint32_t)k;
+                    if (seg2 && f == cnt1) { const double cur_ = (double)cbv + (double)off; cbv = (uint32_t)cur_; off = (float)(cur_ - (double)cbv); }   // :28-29 of the second call
+                    const uint32_t tr = f32_as_index(off);
+                    const float fr = off - (float)tr;                                             // :31-32
+                    uint32_t xi = cbv + tr;
+                    if (xi >= clen_) { cbv = 0u; off = (float)(xi % clen_) + fr; xi = f32_as_index(off); }   // :39-41
+                    uint32_t p_ = xi >= w_start ? xi - w_start : xi + clen_ - w_start;
+                    (void)ODDIO_BOUNDS_CHECK(bounds_err, f >= cnt || p_ + 1u < w_count, BOUNDS_WINDOW_INDEX, p_, src);
+                    p_ = p_ < w_count - 1u ? p_ : w_count - 2u;                                   // (frames past cnt, not stored)
+                    const float a = wst[p_], bb = wst[p_ + 1u];
+                    out[k] = a + fr * (bb - a);
+                    off = off + ds;                                                               // :50
+                    if (f + 1u == cnt) { cyc_store = true; cyc_cb = cbv; cyc_off = off; }
+                }
+                wave_sync();          // (the stores below reuse the window buffer)
+            } else if (info & BWF_SYNTH) {
                 const float la = ODDIO_RF(26, j);
                 if (nvec == 0) {          // Constant::sample (constant.rs:16-18)
 #pragma unroll
@@ -771,6 +856,7 @@ __global__ __launch_bounds__(64) void buffered_write(const WriteRec* __restrict_
                     if ((uint32_t)lane == last_lane) dyn[src].sm_progress[(ops >> (12 + 2 * ri)) & 3u] = pfin;
                 }
             }
+            if (cyc_store) dyn[src].common.t = (double)cyc_cb + (double)cyc_off;                  // cycle.rs:52
             if (ACC) {
 #pragma unroll
                 for (int k = 0; k < 16; ++k) if (f0 + (uint32_t)k < cnt) acc[k] = acc[k] + out[k];
@@ -811,7 +897,7 @@ __global__ __launch_bounds__(64) void buffered_write(const WriteRec* __restrict_
                 }
             }
             // stores of this source: 4 vector stores + one per ramping Gain (its progress), issued after the next window's DMA
-            light = (info & BWF_SPECIAL) ? 0 : 4 + (int)(((ops >> 4) & 3u) != 0u) + (int)(((ops >> 6) & 3u) != 0u) + (int)(((ops >> 8) & 3u) != 0u) + (int)(((ops >> 10) & 3u) != 0u);
+            light = (info & (BWF_SPECIAL | BWF_CYCLE)) ? 0 : 4 + (int)(((ops >> 4) & 3u) != 0u) + (int)(((ops >> 6) & 3u) != 0u) + (int)(((ops >> 8) & 3u) != 0u) + (int)(((ops >> 10) & 3u) != 0u);
             wave_sync();      // every lane is done with this window buffer before it is refilled two sources on
             buf ^= 1;
         }

@@ -603,7 +603,7 @@ __global__ __launch_bounds__(128) void mixer_chain_walk(uint32_t n_sources, uint
     const BufStatic s = st[i];
     WriteRec wr = {};                                   // info == BW_SKIP: nothing to render
     const bool clip_leaf = s.kind == KIND_FRAMES;
-    if (!(s.flags & BUF_FAST_OK) || s.fader || !(clip_leaf || s.kind == KIND_SINE || s.kind == KIND_CONSTANT) || s.channels != 1u) { wr.info = BW_SLOW; wrecs[i] = wr; return; }
+    if (!(s.flags & BUF_FAST_OK) || s.fader || !(clip_leaf || s.kind == KIND_SINE || s.kind == KIND_CONSTANT || s.kind == KIND_CYCLE) || s.channels != 1u) { wr.info = BW_SLOW; wrecs[i] = wr; return; }
     const BufDyn d = dyn[i];
     if (d.common.flags & MIXDYN_STOPPED) { skip[i] = 1; wrecs[i] = wr; return; }
     bool fin = (d.common.flags & MIXDYN_STOP_REQUESTED) != 0;                                                       // mixer.rs:102

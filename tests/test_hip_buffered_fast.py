@@ -143,9 +143,9 @@ def test_ragged_callbacks_and_unit_speed_fast_branch():
 
 
 def test_fast_equals_general_kernel_and_other_shapes_ride_along():
-    """Cycle leaves (and Stream leaves, Faders) keep the general kernel -- their slab rows are added at their place in the walk --
-    while a Constant leaf rides the batched path since round 5; the same scene rendered with the batched path switched off gives
-    the same bits."""
+    """Cycle leaves over loops shorter than a callback's window (and Stream leaves, Faders) keep the general kernel -- their slab
+    rows are added at their place in the walk -- while a Constant leaf rides the batched path since round 5; the same scene rendered
+    with the batched path switched off gives the same bits."""
     import oddio_amd as oa
     outs = []
     for fast in (True, False):
@@ -153,8 +153,8 @@ def test_fast_equals_general_kernel_and_other_shapes_ride_along():
         scene.set_buffered_fast(fast)
         extra = [
             (lambda m: (m.Gain(m.Constant(0.5)) if m is oc else m.Gain.new(m.Constant(0.5))[1]), [1.0, 2.0, 2.0]),
-            (lambda m: (m.Speed(m.Cycle(m.Frames(32000, synth.noise_clip(31, 0, 1234)))) if m is oc
-                        else m.Speed.new(m.Cycle(m.Frames.from_slice(32000, synth.noise_clip(31, 0, 1234))))[1]), [6.0, 1.0, 2.0]),
+            (lambda m: (m.Speed(m.Cycle(m.Frames(32000, synth.noise_clip(31, 0, 300)))) if m is oc      # (a loop shorter than a callback's window)
+                        else m.Speed.new(m.Cycle(m.Frames.from_slice(32000, synth.noise_clip(31, 0, 300))))[1]), [6.0, 1.0, 2.0]),
         ]
         for mk, p in extra:
             control.play_buffered(mk(oa), opts(oa, p, [0.5, 0.0, -1.0]), 30.0, 48000, 0.03)
@@ -382,10 +382,11 @@ def test_control_and_motion_updates_from_device_memory():
 
 @pytest.mark.parametrize("with_sine", [False, True])
 def test_synthesised_leaves_take_the_batched_path(with_sine):
-    """Round 5: Constant and Sine leaves under FixedGain / Gain / Speed chains are rendered by buffered_write like clip sources (the
-    leaf is computed where a clip's window would be read) -- no source of a 1024-frame callback is left to the general kernel.
-    Constant leaves are exact (ORDERED: bit for bit, rings wrapping inside the run included); Sine leaves go through the device's sine
-    (sin_small, ~1e-7 absolute): the north_star's 1e-5."""
+    """Round 5: Constant, Sine and Cycle leaves under FixedGain / Gain / Speed chains are rendered by buffered_write like clip sources
+    (a synthesised leaf is computed where a clip's window would be read; a Cycle's (base, offset) cursor is scanned with its rewrite
+    at the clip's end) -- no source of a 1024-frame callback is left to the general kernel.  Constant and Cycle leaves are exact
+    (ORDERED: bit for bit, rings wrapping inside the run included); Sine leaves go through the device's sine (sin_small, ~1e-7
+    absolute): the north_star's 1e-5."""
     import oddio_amd as oa
     n_src = 150
     sc = synth.make_scene(77, n_src, cube=15.0, vmax=18.0)
@@ -399,6 +400,11 @@ def test_synthesised_leaves_take_the_batched_path(with_sine):
         if kind == 0:
             clip = synth.noise_clip(77, i, 20000)
             leaf_h, leaf_o = oa.FramesSignal(oa.Frames.from_slice(48000, clip), 0.0), oc.FramesSignal(oc.Frames(48000, clip), 0.0)
+        elif kind == 1 and i % 2 == 1:
+            # Cycle (cycle.rs:26-53): loops of 1.3 k .. 6 k samples at 48 / 44.1 kHz -- most callbacks pass the loop's end, some twice
+            # per Ring::write (the ring wraps too)
+            loop = synth.noise_clip(78, i, 1300 + 37 * i)
+            leaf_h, leaf_o = oa.Cycle(oa.Frames.from_slice((48000, 44100)[i % 4 == 1], loop)), oc.Cycle(oc.Frames((48000, 44100)[i % 4 == 1], loop))
         elif kind == 1 or not with_sine:
             leaf_h, leaf_o = oa.Constant(0.3 + 0.001 * i), oc.Constant(0.3 + 0.001 * i)
         else:
@@ -417,7 +423,11 @@ def test_synthesised_leaves_take_the_batched_path(with_sine):
         # short rings (max_distance 20 m, 0.05 s): they wrap every few callbacks -- Ring::write's two inner.sample calls
         control.play_buffered(sig_h, oa.SpatialOptions(*o), 20.0, 48000, 0.05)
         ref.play_buffered(sig_o, oc.SpatialOptions(*o), 20.0, 48000, 0.05)
-    for cb in range(8):
+    for cb in range(10):
+        if cb in (2, 5):
+            for k, (gc, og) in enumerate(gains):
+                if og is not None and k % 3 != 2:
+                    gc.set_amplitude_ratio(0.4 + 0.05 * ((k + cb) % 9)); og.set_amplitude_ratio(0.4 + 0.05 * ((k + cb) % 9))
         got, want = scene.sample_n(INTERVAL, 1024), ref.sample_n(INTERVAL, 1024)
         assert scene.debug_buffered_slow() == 0, cb
         if with_sine:
