@@ -1168,11 +1168,20 @@ __device__ __forceinline__ void window_repack_padded(unsigned char* win_bytes, i
 
 // A per-source soft clip (apply_fx) in the staged-window loops: FX instantiations (the Downmix-capable spatial_mix kernels, spatial_mix_pair) render Reinhard
 // sources inline -- `fxk` is wave-uniform -- (Tanh sources take the exact per-lane path: the library's tanhf does not fit the loop)
-template <bool HAS_FG, bool FX>
+// FAST (the fused FAST-mode kernels, whose contract is the 1e-5 tolerance): the quotient from v_rcp_f32 and one Newton step -- within
+// an ulp of the correctly rounded divide the exact kernels keep, a third of its instructions.
+template <bool HAS_FG, bool FX, bool FAST = false>
 __device__ __forceinline__ float gain_or_fx(float v, float fixed_gain, int fxk) {
     if (FX && fxk) {
         if (!(fxk & FX_CLIP_FIRST)) v = v * fixed_gain;
-        v = v / (1.0f + fabsf(v));                            // reinhard.rs:32
+        const float d = 1.0f + fabsf(v);
+        if (FAST) {
+            const float r = __builtin_amdgcn_rcpf(d);
+            const float q = v * r;
+            v = __builtin_fmaf(__builtin_fmaf(-d, q, v), r, q);
+        } else {
+            v = v / d;                                        // reinhard.rs:32
+        }
         if (fxk & FX_CLIP_FIRST) v = v * fixed_gain;
         return v;
     }
@@ -1247,7 +1256,7 @@ __device__ __forceinline__ void mix_source_lds(const unsigned char* win_bytes, i
             const int w1 = w0 + i + 1;
             const float bb = win[w1 + (w1 >> 4)];
             float v = FUSED ? __builtin_fmaf(frac0, bb - a, a) : a + frac0 * (bb - a);
-            v = gain_or_fx<HAS_FG, FX>(v, fixed_gain, fxk);
+            v = gain_or_fx<HAS_FG, FX, FUSED>(v, fixed_gain, fxk);
             acc_add<FULL, FUSED>(acc[i], v, ODDIO_GAIN_AT(i), frame0 + (uint32_t)i < n_frames);
             a = bb;
         }
@@ -1275,7 +1284,7 @@ __device__ __forceinline__ void mix_source_lds(const unsigned char* win_bytes, i
             const float vl = FUSED ? __builtin_fmaf(f, l1 - l0, l0) : l0 + f * (l1 - l0);   // frame.rs:39-41 per channel
             const float vr = FUSED ? __builtin_fmaf(f, r1 - r0, r0) : r0 + f * (r1 - r0);
             float v = (0.0f + vl) + vr;                                        // downmix.rs:27-29: channels().sum() from 0.0
-            v = gain_or_fx<HAS_FG, FX>(v, fixed_gain, fxk);
+            v = gain_or_fx<HAS_FG, FX, FUSED>(v, fixed_gain, fxk);
             acc_add<FULL, FUSED>(acc[i], v, ODDIO_GAIN_AT(i), frame0 + (uint32_t)i < n_frames);
             __builtin_amdgcn_sched_barrier(0);     // one frame at a time: the kernel has no registers to spare for reads hoisted across frames
         }
@@ -1303,7 +1312,7 @@ __device__ __forceinline__ void mix_source_lds(const unsigned char* win_bytes, i
         // the instruction after it does not read dg (hipcc pads an asm statement whose output is read next with s_nop)
         asm volatile("" : "+v"(dg));
         float v = FUSED ? __builtin_fmaf(fr[i], bb[i] - a[i], a[i]) : a[i] + fr[i] * (bb[i] - a[i]);   // frame.rs:39-41 lerp (unfused in the exact kernels)
-        v = gain_or_fx<HAS_FG, FX>(v, fixed_gain, fxk);                       // gain.rs:32-37
+        v = gain_or_fx<HAS_FG, FX, FUSED>(v, fixed_gain, fxk);                       // gain.rs:32-37
         acc_add<FULL, FUSED>(acc[i], v, ODDIO_GAIN_AT(i), frame0 + (uint32_t)i < n_frames);   // spatial.rs:459-460
         __builtin_amdgcn_sched_barrier(0);
     }

@@ -7,6 +7,7 @@
 Every scene has `--sources` moving sources of ONE kind (positions / velocities of the bench generator):
   frames48 / frames96 / frames192   FramesSignal over clips of that rate (resample ratio 1 / 2 / 4 at 48 kHz output),
                                     4096 distinct clips, scattered
+  reinhard / tanh                   Reinhard<FramesSignal> / Tanh<FramesSignal>: a per-source soft clip around a 48 kHz clip source
   sine                              Sine (closed form, sinf per sample)
   downmix                           Downmix<FramesSignal<[f32;2]>> over 48 kHz stereo clips
   cycle / cycle48k                  Cycle over 5000-sample loops (0.1 s: a tenth of all tiles touches the loop's end and takes the
@@ -30,7 +31,7 @@ def main():
     ap.add_argument("--sources", type=int, default=65536)
     ap.add_argument("--callbacks", type=int, default=24)
     ap.add_argument("--warm", type=int, default=64, help="untimed callbacks first (the chip leaves its idle clock state under load only)")
-    ap.add_argument("--kinds", default="frames48,frames96,frames192,sine,downmix,cycle,cycle48k")
+    ap.add_argument("--kinds", default="frames48,frames96,frames192,reinhard,tanh,sine,downmix,cycle,cycle48k")
     args = ap.parse_args()
     os.environ.setdefault("ODDIO_HIP_MAX_CYCLE", str(args.sources))
     import torch
@@ -48,13 +49,19 @@ def main():
     for kind in args.kinds.split(","):
         control, scene = oa.SpatialScene(max_sources=S, max_frames=N)
         keep = []
-        if kind.startswith("frames") or kind == "downmix":
+        if kind.startswith("frames") or kind in ("downmix", "reinhard", "tanh"):
             rate = int(kind[6:]) * 1000 if kind.startswith("frames") else RATE
             ch = 2 if kind == "downmix" else 1
             length = (int(rate * (1.0 + (args.callbacks + args.warm + 8) * N / RATE * 1.15)) + 4096) & ~3
             clips = (torch.rand((n_clips, length * ch), device=dev, dtype=torch.float32) * 2.0 - 1.0).contiguous()
             keep.append(clips)
-            if ch == 1:
+            if ch == 1 and kind in ("reinhard", "tanh"):
+                # per-source soft clips (reinhard.rs:22-50, tanh.rs:16-44): Reinhard is rendered inline by the staged loops, Tanh by the exact per-lane path
+                frames = [oa.Frames.from_device_ptr(rate, clips.data_ptr() + 4 * length * i, length, device=0, copy=False) for i in range(n_clips)]
+                wrap = oa.Reinhard if kind == "reinhard" else oa.Tanh
+                for i in range(S):
+                    control.play(wrap(oa.FramesSignal(frames[int(pick[i])], 1.0)), oa.SpatialOptions(sc["position"][i], sc["velocity"][i], 0.1))
+            elif ch == 1:
                 frames = [oa.Frames.from_device_ptr(rate, clips.data_ptr() + 4 * length * i, length, device=0, copy=False) for i in range(n_clips)]
                 control.play_frames_batch([frames[int(k)] for k in pick], np.full(S, 1.0), sc["position"], sc["velocity"], sc["radius"])
             else:
