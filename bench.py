@@ -1093,7 +1093,10 @@ def main():
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
                 "traffic": traffic, "traffic_source": traffic_source,
-                "kernel": "spatial_mix", "avg_kernel_ms": mix_ms, "algorithmic_bytes_per_launch": b_alg,
+                # (callbacks of 513..1024 frames over >= 32 768 sources run spatial_mix_pair -- csrc/pair_kernels.h, ODDIO_HIP_PAIR=0 keeps the
+                # 512-frame-tile kernel spatial_mix; smaller scenes always run spatial_mix)
+                "kernel": ("spatial_mix_pair" if (os.environ.get("ODDIO_HIP_PAIR", "1") != "0" and len(g["ids"]) >= 32768) else "spatial_mix"),
+                "avg_kernel_ms": mix_ms, "algorithmic_bytes_per_launch": b_alg,
                 "frac_callback": b_alg / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBPS,
                 # through the reference's own boundary -- a host slice per call (oddio::run, src/lib.rs:90-93): + an 8 KiB D2H copy and a
                 # stream synchronisation per callback, the GPU idle while the host turns around

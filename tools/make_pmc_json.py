@@ -39,6 +39,10 @@ def _ring(k):      # spatial_mix<FULL, STORE, FUSED, RING, DMX>: the buffered se
 d_all = d
 d = {k: v for k, v in d.items() if not (k.startswith("spatial_mix<") and _ring(k))}
 cands = [k for k in d if k.startswith("spatial_mix<true, false, true") or k.startswith("spatial_mix<false, false, true")]
+# round 5: large FAST-mode scenes run spatial_mix_pair<FULL, FUSED> (pair_kernels.h) instead
+pair = [k for k in d if k.startswith("spatial_mix_pair<true, true") or k.startswith("spatial_mix_pair<false, true")]
+if pair and (not cands or max(d[k].get("_dispatches") or 0 for k in pair) >= max(d[k].get("_dispatches") or 0 for k in cands)):
+    cands = pair
 if not cands:
     cands = [k for k in d if k.startswith("spatial_mix<true, false") or k.startswith("spatial_mix<false, false")]
 k = max(cands, key=lambda k: d[k].get("_dispatches") or 0)
