@@ -287,6 +287,9 @@ __device__ __forceinline__ double f64_rem_euclid(double a, double b) {   // core
 #endif
 
 constexpr int MIX_WG_WAVES = ODDIO_MIX_WG_WAVES;       // waves per workgroup
+#ifndef ODDIO_DIAG
+#define ODDIO_DIAG 0   // diagnostic builds only (tools/ubench, profiles/r05_exp_*): 1 conflict-free (wrong) LDS addresses, 2 no sample loop, 4 no cursor scan, 8 no window DMA
+#endif
 constexpr int MIX_WAVES_PER_SIMD = ODDIO_MIX_WAVES;    // register budget: 512 / this
 constexpr int MIX_DEPTH = ODDIO_MIX_DEPTH;             // samples whose LDS pair reads are in flight together
 constexpr int MIX_WAVES_PER_CU = 16;                   // default grid size (waves per CU)
@@ -1299,6 +1302,7 @@ __device__ __forceinline__ void mix_source_lds(const unsigned char* win_bytes, i
         const bool in_ = ODDIO_BOUNDS_CHECK(err, wrel + tr >= 0 && wrel + tr + 1 < win_samples, BOUNDS_WINDOW_INDEX, wrel + tr, win_samples); \
         if (!in_) { a[I] = 0.0f; bb[I] = 0.0f; }                                        \
         else if (PAD) { w = wrel + tr; w = w + (w >> 4); (void)ODDIO_BOUNDS_CHECK(err, w + 1 < CAP, BOUNDS_PAD_INDEX, w, win_samples); a[I] = win[w]; bb[I] = win[w + 1]; } \
+        else if (ODDIO_DIAG & 1) { const float* p_ = win + ((tr & 0x800) + (int)(threadIdx.x & 31)); a[I] = p_[0]; bb[I] = p_[1]; } /* diagnostic build only: wrong samples, no bank conflicts */ \
         else { a[I] = wbase[w]; bb[I] = wbase[w + 1]; }         /* one ds_read2_b32 */   \
         x = x + ds;                                             /* frames.rs:194 */      \
     }

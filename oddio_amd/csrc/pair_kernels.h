@@ -60,6 +60,7 @@ __device__ __forceinline__ void pair_window_dma(uint32_t lds_dst, uint32_t d0, u
     if (nvec * 16 > PAIR_WIN_BYTES || (int)d2 > nvec * 16 + neg + 16) asm volatile("s_trap 2");
 #endif
     const int voff = neg + lane16 + 1024 * first;
+    if (ODDIO_DIAG & 8) return;
     const uint32_t m0v = (uint32_t)__builtin_amdgcn_readfirstlane((int)(lds_dst + 1024u * (uint32_t)first));   // (wave-uniform; M0 wants an SGPR)
     uint32_t keep;
     // (pieces 0-3 from every lane: lanes past the window write zeros inside the buffer, no traffic)
@@ -196,6 +197,7 @@ __global__ __launch_bounds__(128, MIX_WAVES_PER_SIMD) void spatial_mix_pair(Scen
 #pragma unroll 1
             for (int b = 0; b < 15; ++b) {
                 blk[b] = x;
+                if (ODDIO_DIAG & 4) { x = __builtin_fmaf(16.0f, ds, x); continue; }
 #pragma unroll
                 for (int i = 0; i < 16; ++i) x = x + ds;
             }
@@ -243,7 +245,8 @@ __global__ __launch_bounds__(128, MIX_WAVES_PER_SIMD) void spatial_mix_pair(Scen
             if (nm_) { PAIR_ISSUE_WINDOW_OF(pv, 31 - __builtin_clz(nm_), buf ^ 1) pre_issued = true; }                    \
         }                                                                                                                 \
         const int wrel4 = __float_as_int(ct.x);                                                                           \
-        if ((VAR) == 1) {                                                                                                 \
+        if (ODDIO_DIAG & 2) { acc[0] += cx0 + ct.y + ct.z + ct.w + __int_as_float(wrel4); }                              \
+        else if ((VAR) == 1) {                                                                                            \
             const float fg = (flags_j & SFLAG_FG) ? st[g * MIX_GROUP + (uint32_t)cur].fixed_gain : 1.0f;   /* v * 1.0 == v */ \
             const float frac0_ = reinterpret_cast<const float*>(blkB0 + cur * BLK_SRC)[0];   /* checkpoint 0 */           \
             const int fast_e = wv ? (flags_j & SFLAG_FAST_R) : (flags_j & SFLAG_FAST_L);                                  \
