@@ -831,8 +831,8 @@ __device__ __forceinline__ TileRec make_tile_rec(const SceneParams& P, const Src
     if (s.kind == KIND_CYCLE) { r.info = PATH_ROW; return r; }
     if (s.kind != KIND_FRAMES && s.kind != KIND_DOWNMIX) { r.info = PATH_GENERIC; return r; }
     // a per-source soft clip: Reinhard is rendered inline by the staged loops of the kernels that compile it in (P.dmx: the
-    // Downmix-capable instantiations; info bits 28-30 = SrcStatic::fx), Tanh by the exact per-lane path
-    if (s.fx && (!P.dmx || (s.fx & FX_TANH))) { r.info = PATH_GENERIC; return r; }
+    // Downmix-capable instantiations; info bits 28-30 = SrcStatic::fx), Tanh only by the fused (FAST-mode) ones, else by the exact per-lane path
+    if (s.fx && (!P.dmx || ((s.fx & FX_TANH) && !P.fused))) { r.info = PATH_GENERIC; return r; }
     // Downmix<FramesSignal<[f32;2]>> (downmix.rs:24-29 over frames.rs:176-201): the same cursor, the window holds interleaved
     // stereo frames -- `mul` floats per frame; always variant 2 of spatial_mix (sub-windows when the window is larger than the stage)
     const bool stereo = s.kind == KIND_DOWNMIX;
@@ -961,7 +961,7 @@ __device__ __forceinline__ PairRec make_pair_rec(const SceneParams& P, const Src
     if (s.kind == KIND_CONSTANT) { r.info = PATH_CONST; return r; }
     if (s.kind == KIND_CYCLE) { r.info = PATH_ROW; return r; }
     if (s.kind != KIND_FRAMES) { r.info = PATH_GENERIC; return r; }     // (Downmix: the exact per-lane path)
-    if (s.fx & FX_TANH) { r.info = PATH_GENERIC; return r; }            // (Reinhard is rendered inline: info bits 28-30 = SrcStatic::fx)
+    if ((s.fx & FX_TANH) && !P.fused) { r.info = PATH_GENERIC; return r; }   // (the soft clips are rendered inline: info bits 28-30 = SrcStatic::fx; Tanh by the fused kernel only)
     int lo = 0x7fffffff, hi = (int)0x80000000, generic = 0, fl = 0;
     int wbase[2][PAIR_CHUNKS];
     const double rate = (double)s.clip_rate;
@@ -1169,14 +1169,35 @@ __device__ __forceinline__ void window_repack_padded(unsigned char* win_bytes, i
     wave_sync();
 }
 
+// tanh for the FAST-mode kernels (contract: 1e-5 of the output's peak; the exact kernels keep the library's tanhf on the per-lane path):
+// |x| < 0.3: the odd Taylor polynomial to x^9 (next term 5e-8 relative); otherwise 1 - 2 / (exp(2|x|) + 1) from v_exp_f32 and
+// v_rcp_f32 (<= 4e-7 relative).  tanh.rs:22-29.
+__device__ __forceinline__ float tanh_fast(float x) {
+    const float a = fminf(fabsf(x), 10.0f);
+    const float x2 = a * a;
+    float p = 2.1869488536155203e-2f;                         // 62/2835
+    p = __builtin_fmaf(p, x2, -5.3968253968253968e-2f);       // -17/315
+    p = __builtin_fmaf(p, x2, 1.3333333333333333e-1f);        // 2/15
+    p = __builtin_fmaf(p, x2, -3.3333333333333333e-1f);       // -1/3
+    const float small = __builtin_fmaf(a * x2, p, a);
+    const float e = __builtin_amdgcn_exp2f(a * 2.8853900817779268f);
+    const float big = 1.0f - 2.0f * __builtin_amdgcn_rcpf(e + 1.0f);
+    return __builtin_copysignf(a < 0.3f ? small : big, x);
+}
+
 // A per-source soft clip (apply_fx) in the staged-window loops: FX instantiations (the Downmix-capable spatial_mix kernels, spatial_mix_pair) render Reinhard
-// sources inline -- `fxk` is wave-uniform -- (Tanh sources take the exact per-lane path: the library's tanhf does not fit the loop)
+// sources inline -- `fxk` is wave-uniform -- (Tanh sources: tanh_fast in the fused kernels; the exact kernels send them down the per-lane path with the library's tanhf)
 // FAST (the fused FAST-mode kernels, whose contract is the 1e-5 tolerance): the quotient from v_rcp_f32 and one Newton step -- within
 // an ulp of the correctly rounded divide the exact kernels keep, a third of its instructions.
 template <bool HAS_FG, bool FX, bool FAST = false>
 __device__ __forceinline__ float gain_or_fx(float v, float fixed_gain, int fxk) {
     if (FX && fxk) {
         if (!(fxk & FX_CLIP_FIRST)) v = v * fixed_gain;
+        if (FAST && (fxk & FX_TANH)) {                        // (only the fused kernels are handed Tanh sources: SceneParams::fused)
+            v = tanh_fast(v);
+            if (fxk & FX_CLIP_FIRST) v = v * fixed_gain;
+            return v;
+        }
         const float d = 1.0f + fabsf(v);
         if (FAST) {
             const float r = __builtin_amdgcn_rcpf(d);

@@ -60,6 +60,9 @@ def _sources(seed, n_src, with_sine, short_clip=5440):
                 src["gain_db"] = 6.0
             elif k == 0 and i % 24 == 12:
                 src["reinhard"] = True; vel[:] = 0.0            # ... on the constant-fract branch
+            elif k == 0 and with_sine:
+                src["tanh"] = True                              # per-source Tanh (tanh.rs:22-29): tanh_fast in the fused kernel (FAST-mode test only:
+                src["gain_db"] = 12.0 if i % 48 == 0 else -38.0  # the device's tanh is not libm's bit for bit); loud and very quiet
             src["clip"] = synth.noise_clip(seed, i, n)
         out.append(src)
     return out
@@ -76,6 +79,8 @@ def _oracle_signal(src):
         sig = oc.FixedGain(sig, src["gain_db"])
     if src.get("reinhard"):
         sig = oc.Reinhard(sig)
+    if src.get("tanh"):
+        sig = oc.Tanh(sig)
     return sig
 
 
@@ -90,6 +95,8 @@ def _hip_signal(oa, src):
         sig = oa.FixedGain(sig, src["gain_db"])
     if src.get("reinhard"):
         sig = oa.Reinhard(sig)
+    if src.get("tanh"):
+        sig = oa.Tanh(sig)
     return sig
 
 
