@@ -179,6 +179,12 @@ impl HipSpatialScene {
         check(unsafe { oddio_hip_scene_set_mode((self.0).0, 2) });
         self
     }
+    /// The reference's sequential sum to ~1e-6 of the peak at about twice the default mode's cost (ODDIO_HIP_MODE_TRACKED): large
+    /// scenes, where the tree sum is farther than 1e-5 from the reference's f32 sum.  Allocates like `bit_exact`.
+    pub fn tracked(self) -> Self {
+        check(unsafe { oddio_hip_scene_set_mode((self.0).0, 3) });
+        self
+    }
     /// One logical scene split by source index over `world` GPUs (BASELINE configs[4]): every rank
     /// builds its shard's scene, then joins the stereo-buffer reduce with an `ncclUniqueId` made by
     /// rank 0 (`oddio_hip_reduce_unique_id`) and handed to the others by the host program.

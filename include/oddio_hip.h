@@ -65,6 +65,18 @@ enum { /* oddio_hip_scene_set_mode */
                                    (a + t*(b-a), prev_gain + i*d_gain, o += s*gain: each operation rounded by itself,
                                    src/frame.rs:39-41, src/spatial.rs:459-460) -- what FAST was before round 3; ~3-6 %
                                    slower per callback at 262 144 sources.  Mixers treat it as FAST. */
+    ODDIO_HIP_MODE_TRACKED = 3, /* scenes: the reference's sequential sum (src/spatial.rs:204,460) to ~1e-6 of the output's peak
+                                   at a fraction of ORDERED's cost, for the scenes where the tree sum of FAST is farther than 1e-5
+                                   from it (at 262 144 sources the reference's f32 sum is itself 1-2e-5 from the exact sum, and
+                                   so is every other order).  The callback is mixed twice: a first pass leaves every
+                                   workgroup's partial sums; the second restarts each workgroup's running sums at the value
+                                   the reference's sum has when its walk reaches that workgroup's sources -- the prefix of
+                                   the partial sums -- and adds them in the reference's order with its roundings.  A
+                                   sequential f32 sum rounds each addend to the ulp of the running sum's binade, so the
+                                   restarted sums repeat the reference's rounding errors, not just its exact terms.
+                                   Applies to the callbacks spatial_mix_pair renders (513..1024 frames, >= 32 768 live
+                                   sources); every other callback is an ORDERED one (set_mode allocates as for ORDERED,
+                                   plus one buffer of start values).  Mixers treat it as ORDERED. */
 };
 
 typedef struct oddio_hip_frames oddio_hip_frames; /* == Arc<Frames<f32>>, src/frames.rs:19-22 */

@@ -27,7 +27,7 @@ import numpy as np
 from . import _lib
 
 POSTFX_NONE, POSTFX_REINHARD, POSTFX_TANH = 0, 1, 2
-MODE_FAST, MODE_ORDERED, MODE_FAST_UNFUSED = 0, 1, 2
+MODE_FAST, MODE_ORDERED, MODE_FAST_UNFUSED, MODE_TRACKED = 0, 1, 2, 3
 
 
 def _fp(a):

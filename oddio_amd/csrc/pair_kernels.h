@@ -103,7 +103,14 @@ __device__ __forceinline__ void pair_repack_padded(unsigned char* win_bytes, int
 // grid = workgroups; block = 128 (wave 0: left ear, wave 1: right ear).  Workgroup w walks groups [g_lo, g_hi) of 16 slots
 // in DESCENDING order (the reference's reverse set walk, spatial.rs:204) and leaves its partial sums in spatial_mix's
 // layout (kernels.h PART_BLOCK) for reduce_partials.
-template <bool FULL, bool FUSED>
+// TRACK (ODDIO_HIP_MODE_TRACKED, second pass): `init` holds, in the partial tiles' layout, the value the reference's running sum has --
+// to a few hundred ulps -- when its walk reaches this workgroup's sources (track_prefix over the first pass's partial sums).  The
+// wave restarts its running sums there, adds its sources in the reference's order with the reference's roundings (FUSED = false),
+// and leaves what they added: end - start.  A sequential f32 sum rounds every addend to the ulp of the running sum's binade -- the
+// rounding error of a step does not depend on the sum's lower bits -- so the restarted sums make the reference's rounding errors, and
+// the workgroups' differences add up to the reference's sequential sum to ~1e-6 of the peak (the plain tree sum: 1-2e-5 at 262 144
+// sources, which is the reference's own distance from the exact sum).
+template <bool FULL, bool FUSED, bool TRACK = false>
 __global__ __launch_bounds__(128, MIX_WAVES_PER_SIMD) void spatial_mix_pair(SceneParams P, const SrcStatic* __restrict__ st,
                                                                             const EarParams* __restrict__ ear, const PairRec* __restrict__ recs,
                                                                             float* __restrict__ partials, const float* __restrict__ init,
@@ -123,7 +130,18 @@ __global__ __launch_bounds__(128, MIX_WAVES_PER_SIMD) void spatial_mix_pair(Scen
     const float fbase = (float)frame0;
 #pragma unroll
     for (int k = 0; k < 16; ++k) { acc[k] = 0.0f; fi[k] = fbase + (float)k; }   // `i as f32` (spatial.rs:459)
-    if (init != nullptr && blockIdx.x == 0) {
+    static_assert(!TRACK || !FUSED, "the tracked sums carry the reference's roundings");
+    if (TRACK) {
+        if (frame0 < n_frames) {
+            const float* src = init + ((size_t)(2 * lane) * gridDim.x + blockIdx.x) * PART_BLOCK + (size_t)wv * PART_FRAMES;
+            const size_t step = (size_t)gridDim.x * PART_BLOCK;
+#pragma unroll
+            for (int q4 = 0; q4 < 4; ++q4) {
+                const float4 v = reinterpret_cast<const float4*>(src + (q4 >> 1) * step)[q4 & 1];
+                acc[4 * q4] = v.x; acc[4 * q4 + 1] = v.y; acc[4 * q4 + 2] = v.z; acc[4 * q4 + 3] = v.w;
+            }
+        }
+    } else if (init != nullptr && blockIdx.x == 0) {
         // the buffered set is walked before the seekable one (spatial.rs:395-438): its sum is what the first source is added to
 #pragma unroll
         for (int k = 0; k < 16; ++k)
@@ -320,8 +338,54 @@ __global__ __launch_bounds__(128, MIX_WAVES_PER_SIMD) void spatial_mix_pair(Scen
         // the lane's 16 frames are two blocks of PART_FRAMES frames (kernels.h: the partial sums' layout)
         float* dst = partials + ((size_t)(2 * le) * gridDim.x + blockIdx.x) * PART_BLOCK + (size_t)wv * PART_FRAMES;
         const size_t dst_step = (size_t)gridDim.x * PART_BLOCK;
+        if (TRACK && blockIdx.x + 1u != gridDim.x) {       // (the workgroup the reference's walk starts with keeps its start value: the buffered set's sum)
+            const float* src = init + ((size_t)(2 * le) * gridDim.x + blockIdx.x) * PART_BLOCK + (size_t)wv * PART_FRAMES;
+#pragma unroll
+            for (int q4 = 0; q4 < 4; ++q4) {
+                const float4 v = reinterpret_cast<const float4*>(src + (q4 >> 1) * dst_step)[q4 & 1];
+                acc[4 * q4] = acc[4 * q4] - v.x; acc[4 * q4 + 1] = acc[4 * q4 + 1] - v.y; acc[4 * q4 + 2] = acc[4 * q4 + 2] - v.z; acc[4 * q4 + 3] = acc[4 * q4 + 3] - v.w;
+            }
+        }
 #pragma unroll
         for (int q4 = 0; q4 < 4; ++q4) reinterpret_cast<float4*>(dst + (q4 >> 1) * dst_step)[q4 & 1] = make_float4(acc[4 * q4], acc[4 * q4 + 1], acc[4 * q4 + 2], acc[4 * q4 + 3]);
+    }
+}
+
+// ODDIO_HIP_MODE_TRACKED, between the two passes: prefix[w] = the buffered set's sum (`init`, or 0) + the partial sums of the workgroups
+// the reference's walk passes before workgroup w (w + 1 .. n_wgs - 1: it starts at the highest slot), in that order, for every output
+// of the callback; partial-tile layout in and out.  grid = blocks of PART_FRAMES frames; block = 16 outputs x TRK_SEGS segments of
+// the workgroup list: segment sums, their exclusive scan, then the running values.
+constexpr int TRK_SEGS = 32;
+constexpr int TRK_BATCH = 16;
+__global__ __launch_bounds__(PART_BLOCK * TRK_SEGS) void track_prefix(const float* __restrict__ partials, const float* __restrict__ init, float* __restrict__ prefix,
+                                                                       uint32_t n_wgs, uint32_t n_frames) {
+    __shared__ float tot[TRK_SEGS][PART_BLOCK];
+    const uint32_t ox = threadIdx.x & (PART_BLOCK - 1), seg = threadIdx.x / PART_BLOCK;
+    const int per = (int)((n_wgs + TRK_SEGS - 1) / TRK_SEGS);
+    const int hi = (int)n_wgs - 1 - (int)seg * per;                 // this segment: workgroups hi, hi - 1, .. lo
+    const int lo = hi - per + 1 > 0 ? hi - per + 1 : 0;
+    const float* p = partials + (size_t)blockIdx.x * n_wgs * PART_BLOCK + ox;
+    float* q = prefix + (size_t)blockIdx.x * n_wgs * PART_BLOCK + ox;
+    float sum = 0.0f;
+    for (int w = hi; w >= lo; w -= TRK_BATCH) {
+        float v[TRK_BATCH];
+#pragma unroll
+        for (int k = 0; k < TRK_BATCH; ++k) v[k] = (w - k >= lo) ? p[(size_t)(w - k) * PART_BLOCK] : 0.0f;
+#pragma unroll
+        for (int k = 0; k < TRK_BATCH; ++k) sum = sum + v[k];
+    }
+    tot[seg][ox] = sum;
+    __syncthreads();
+    const uint32_t f = blockIdx.x * PART_FRAMES + (ox % PART_FRAMES);
+    float run = (init != nullptr && f < n_frames) ? init[2 * f + ox / PART_FRAMES] : 0.0f;
+    for (uint32_t k = 0; k < seg; ++k) run = run + tot[k][ox];
+    for (int w = hi; w >= lo; w -= TRK_BATCH) {
+        float v[TRK_BATCH];
+#pragma unroll
+        for (int k = 0; k < TRK_BATCH; ++k) v[k] = (w - k >= lo) ? p[(size_t)(w - k) * PART_BLOCK] : 0.0f;
+#pragma unroll
+        for (int k = 0; k < TRK_BATCH; ++k)
+            if (w - k >= lo) { q[(size_t)(w - k) * PART_BLOCK] = run; run = run + v[k]; }
     }
 }
 

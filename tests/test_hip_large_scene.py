@@ -153,6 +153,42 @@ def test_config3_ordered_mode_is_bit_exact(big):
         np.testing.assert_array_equal(got, big["ref32"][cb])
 
 
+TRACKED_VS_REFERENCE_TOL = 3e-6      # ODDIO_HIP_MODE_TRACKED against the reference's sequential sum (measured ~1e-6): inside the north_star's 1e-5
+
+
+@pytest.mark.parametrize("n_src", [S_BIG, 65536])
+def test_tracked_mode_is_within_the_north_star_tolerance_of_the_reference(big, n_src):
+    """ODDIO_HIP_MODE_TRACKED (pair_kernels.h TRACK): two passes of the FAST-mode kernel whose second one restarts every workgroup's
+    running sums at the prefix of the first one's partial sums -- the reference's sequential f32 sum, rounding errors included, to
+    ~1e-6 of the peak, where the tree sum is 1-2e-5 from it.  Against the oracle's sequential sum (262 144 sources) and against
+    ORDERED mode, which is that sum bit for bit (65 536)."""
+    import oddio_amd as oa
+    control, scene, handles, frames = play_shard(big, 0, n_src, mode=oa.MODE_TRACKED)
+    if n_src == S_BIG:
+        refs = big["ref32"]
+    else:
+        c2, s2, h2, f2 = play_shard(big, 0, n_src, mode=oa.MODE_ORDERED)
+        refs = []
+        for cb in range(2):
+            if cb == 1:
+                apply_motion(big, c2, h2, 0, n_src)
+            refs.append(s2.sample_n(INTERVAL, N).copy())
+        s2.close()
+    report = []
+    for cb in range(2):
+        if cb == 1:
+            apply_motion(big, control, handles, 0, n_src)
+        got = scene.sample_n(INTERVAL, N)
+        scale = float(np.abs(refs[cb]).max())
+        d = float(np.abs(got - refs[cb]).max()) / scale
+        report.append(d)
+        assert d <= TRACKED_VS_REFERENCE_TOL, report
+        assert d <= NORTH_STAR_TOL
+    print(f"TRACKED, {n_src} sources: |gpu - reference| / max|reference| per callback:", report)
+    assert len(scene) == n_src
+    scene.close()
+
+
 def test_config4_per_gpu_scene_65536_vs_oracle(big):
     """BASELINE configs[3] runs one 65 536-source SpatialScene per GPU: that scene size (a different grid shape from
     configs[2]: fewer source groups per wavefront) against the oracle's sequential f32 and f64-accumulated sums."""
