@@ -37,8 +37,9 @@ def test_random_operations_bit_exact(seed):
     control, scene = oa.SpatialScene(max_sources=LIVE_MAX + 36, max_frames=1536)
     if LIVE_MAX > 200:
         scene.reserve_buffered(LIVE_MAX + 36)
-    fast = os.environ.get("ODDIO_FUZZ_MODE") == "fast"      # soak option: the multi-wavefront tree sum, compared with a tolerance
-    scene.set_mode(oa.MODE_FAST if fast else oa.MODE_ORDERED)
+    fuzz_mode = os.environ.get("ODDIO_FUZZ_MODE", "")      # soak options: the multi-wavefront tree sum (fast / unfused) or the tracked sum, compared with a tolerance
+    fast = fuzz_mode in ("fast", "unfused", "tracked")
+    scene.set_mode({"fast": oa.MODE_FAST, "unfused": oa.MODE_FAST_UNFUSED, "tracked": oa.MODE_TRACKED}.get(fuzz_mode, oa.MODE_ORDERED))
     scene.set_postfx((0, 1, 0)[seed % 3])
     ref_scene = oc.SpatialScene()
     ref = oc.Reinhard(ref_scene) if seed % 3 == 1 else ref_scene
