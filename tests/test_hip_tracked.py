@@ -14,9 +14,12 @@ from test_hip_pair_kernel import INTERVAL, _events, _hip_signal, _oracle_signal,
 pytestmark = pytest.mark.gpu
 
 
-def _render(monkeypatch, mode, sources, n_frames, n_cb, buffered=()):
+def _render(monkeypatch, mode, sources, n_frames, n_cb, buffered=(), min_groups="1"):
     import oddio_amd as oa
-    monkeypatch.setenv("ODDIO_HIP_PAIR_MIN_GROUPS", "1")
+    if min_groups is not None:
+        monkeypatch.setenv("ODDIO_HIP_PAIR_MIN_GROUPS", min_groups)
+    else:
+        monkeypatch.delenv("ODDIO_HIP_PAIR_MIN_GROUPS", raising=False)
     control, scene = oa.SpatialScene(max_sources=1024, max_frames=1024)
     scene.set_mode(mode)
     handles = [control.play(_hip_signal(oa, s), oa.SpatialOptions(s["pos"], s["vel"], s["radius"])) for s in sources]
@@ -42,7 +45,7 @@ def _render_oracle(sources, n_frames, n_cb, buffered=()):
     return outs
 
 
-@pytest.mark.parametrize("n_src,n_frames,with_buffered", [(900, 1024, False), (333, 700, False), (200, 1024, True)])
+@pytest.mark.parametrize("n_src,n_frames,with_buffered", [(900, 1024, False), (333, 700, False), (200, 1024, True), (500, 512, False), (260, 200, False)])
 def test_tracked_follows_the_sequential_sum(monkeypatch, n_src, n_frames, with_buffered):
     import oddio_amd as oa
     n_cb = 4
@@ -62,11 +65,11 @@ def test_tracked_follows_the_sequential_sum(monkeypatch, n_src, n_frames, with_b
     assert np.mean(e_t) < 0.5 * np.mean(e_f), (e_t, e_f)
 
 
-def test_tracked_falls_back_to_ordered_for_short_callbacks(monkeypatch):
-    """Callbacks the pair kernel does not render (<= 512 frames here) are ORDERED ones: the reference's bits."""
+def test_tracked_falls_back_to_ordered_for_small_scenes(monkeypatch):
+    """Scenes below the pair kernel's size (without the test override: 32 768 sources) are ORDERED ones: the reference's bits."""
     import oddio_amd as oa
     sources = _sources(31, 70, with_sine=False)
     ref = _render_oracle(sources, 480, 3)
-    got = _render(monkeypatch, oa.MODE_TRACKED, sources, 480, 3)
+    got = _render(monkeypatch, oa.MODE_TRACKED, sources, 480, 3, min_groups=None)
     for cb in range(3):
         np.testing.assert_array_equal(got[cb], ref[cb])
