@@ -74,8 +74,9 @@ enum { /* oddio_hip_scene_set_mode */
                                    the partial sums -- and adds them in the reference's order with its roundings.  A
                                    sequential f32 sum rounds each addend to the ulp of the running sum's binade, so the
                                    restarted sums repeat the reference's rounding errors, not just its exact terms.
-                                   Applies to callbacks of up to 1024 frames over >= 32 768 live sources (what
-                                   spatial_mix_pair renders); every other callback is an ORDERED one (set_mode allocates as for ORDERED,
+                                   Applies to callbacks of up to 1024 frames over >= 32 768 live sources (the TRACK
+                                   instantiations of spatial_mix_pair and, up to 512 frames, of spatial_mix: about 2.2x
+                                   a FAST callback); every other callback is an ORDERED one (set_mode allocates as for ORDERED,
                                    plus one buffer of start values).  Mixers treat it as ORDERED. */
 };
 

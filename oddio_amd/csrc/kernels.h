@@ -1577,7 +1577,12 @@ __device__ __forceinline__ void rows_store(const float4 (&o)[4], const float4 (&
 // [slot][frame][ear]).  The non-RING instantiations compile to what they were before the flag existed.
 // DMX: the instantiations a scene with Downmix sources runs (variant 2 can render interleaved stereo windows); kept apart because
 // the plain kernels have no register to spare (127 of 128: with the stereo loop compiled in they spill 48-80 bytes per lane).
-template <bool FULL, bool STORE = false, bool FUSED = false, bool RING = false, bool DMX = false>
+// TRACK (ODDIO_HIP_MODE_TRACKED for callbacks of up to 512 frames; pair_kernels.h has the mode's description and the kernel for longer
+// ones): every WAVE is a block of the tracked sum -- its sources are a contiguous stretch of the reference's walk -- and leaves its own
+// partial tile (index: the wave, gridDim.x * MIX_WG_WAVES of them per tile; no cross-wave sum).  1: first pass, sums from zero.
+// 2: second pass, `init` holds every wave's start value in the partial tiles' layout (track_prefix); the wave leaves end - start
+// (the wave the reference's walk starts with keeps its start: the buffered set's sum).
+template <bool FULL, bool STORE = false, bool FUSED = false, bool RING = false, bool DMX = false, int TRACK = 0>
 __global__ __launch_bounds__(64 * MIX_WG_WAVES, MIX_WAVES_PER_SIMD) void spatial_mix(SceneParams P, const SrcStatic* __restrict__ st,
                                                                                      const EarParams* __restrict__ ear,
                                                                                      const TileRec* __restrict__ recs, uint32_t rec_stride, uint32_t tile0,
@@ -1604,7 +1609,19 @@ __global__ __launch_bounds__(64 * MIX_WG_WAVES, MIX_WAVES_PER_SIMD) void spatial
     const float fbase = (float)frame0;
 #pragma unroll
     for (int k = 0; k < 16; ++k) { acc[k] = 0.0f; fi[k] = fbase + (float)k; }   // `i as f32` (spatial.rs:459)
-    if (!STORE && init != nullptr && wave == 0) {
+    static_assert(TRACK == 0 || (!STORE && !FUSED && !RING), "the tracked sums carry the reference's roundings; Seek set only");
+    if (TRACK == 2) {
+        if (frame0 < n_frames) {
+            const uint32_t n_part = gridDim.x * MIX_WG_WAVES;
+            const float* src = init + (((size_t)tile * (TILE_FRAMES / PART_FRAMES) + 2u * (uint32_t)(lane & 31)) * n_part + wave) * PART_BLOCK + (size_t)eB * PART_FRAMES;
+            const size_t step = (size_t)n_part * PART_BLOCK;
+#pragma unroll
+            for (int q4 = 0; q4 < 4; ++q4) {
+                const float4 v = reinterpret_cast<const float4*>(src + (q4 >> 1) * step)[q4 & 1];
+                acc[4 * q4] = v.x; acc[4 * q4 + 1] = v.y; acc[4 * q4 + 2] = v.z; acc[4 * q4 + 3] = v.w;
+            }
+        }
+    } else if (!STORE && TRACK == 0 && init != nullptr && wave == 0) {
         // the buffered set is walked before the seekable one (spatial.rs:395-438): its sum is the
         // value the first source of this walk is added to
 #pragma unroll
@@ -1913,6 +1930,22 @@ __global__ __launch_bounds__(64 * MIX_WG_WAVES, MIX_WAVES_PER_SIMD) void spatial
     // the lane's 16 frames are two blocks of PART_FRAMES frames: partials[(block * n_wgs + wg) * PART_BLOCK + ear * PART_FRAMES + k]
     float* dst = partials + (((size_t)tile * (TILE_FRAMES / PART_FRAMES) + 2u * (uint32_t)(le & 31)) * gridDim.x + blockIdx.x) * PART_BLOCK + (size_t)(le >> 5) * PART_FRAMES;
     const size_t dst_step = (size_t)gridDim.x * PART_BLOCK;      // to the lane's second block
+    if (TRACK) {   // one partial tile per wave
+        const uint32_t n_part = gridDim.x * MIX_WG_WAVES;
+        const size_t off = (((size_t)tile * (TILE_FRAMES / PART_FRAMES) + 2u * (uint32_t)(le & 31)) * n_part + wave) * PART_BLOCK + (size_t)(le >> 5) * PART_FRAMES;
+        const size_t step = (size_t)n_part * PART_BLOCK;
+        if (16u * (uint32_t)(le & 31) + tile * TILE_FRAMES >= n_frames && !FULL) return;
+        if (TRACK == 2 && wave + 1u != n_part) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float4 v = reinterpret_cast<const float4*>(init + off + (q >> 1) * step)[q & 1];
+                acc[4 * q] = acc[4 * q] - v.x; acc[4 * q + 1] = acc[4 * q + 1] - v.y; acc[4 * q + 2] = acc[4 * q + 2] - v.z; acc[4 * q + 3] = acc[4 * q + 3] - v.w;
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) reinterpret_cast<float4*>(partials + off + (q >> 1) * step)[q & 1] = make_float4(acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]);
+        return;
+    }
     if (MIX_WG_WAVES == 1) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) reinterpret_cast<float4*>(dst + (q >> 1) * dst_step)[q & 1] = make_float4(acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]);
