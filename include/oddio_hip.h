@@ -77,7 +77,10 @@ enum { /* oddio_hip_scene_set_mode */
                                    Applies to callbacks of up to 1024 frames over >= 32 768 live sources (the TRACK
                                    instantiations of spatial_mix_pair and, up to 512 frames, of spatial_mix: about 2.2x
                                    a FAST callback); every other callback is an ORDERED one (set_mode allocates as for ORDERED,
-                                   plus one buffer of start values).  Mixers treat it as ORDERED. */
+                                   plus one buffer of start values).  A scene in a reduce group (sharded): the same mode on
+                                   every rank -- between the passes the ranks exchange their totals (ncclAllGather / the p2p
+                                   slab) and each starts at the sum of the ranks above it, the reference's walk order
+                                   over contiguous index shards.  Mixers treat it as ORDERED. */
 };
 
 typedef struct oddio_hip_frames oddio_hip_frames; /* == Arc<Frames<f32>>, src/frames.rs:19-22 */

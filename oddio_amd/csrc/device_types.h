@@ -126,6 +126,7 @@ struct SceneParams {
     uint32_t dmx;           // the callback's mix kernels are the Downmix-capable ones (spatial_mix<.., DMX>): the walk may stage stereo windows
     uint32_t pair;          // the callback's mix kernel is spatial_mix_pair: the walk writes PairRecs instead of tile records
     uint32_t fused;         // the callback's mix kernel is a FAST-mode (fused) instantiation: its staged loops render Tanh sources too (tanh_fast)
+    uint32_t track_all;     // TRACK second pass of a sharded scene: every block leaves end - start (the start of the walk's first block is the ranks' prefix, not this rank's to keep)
     uint32_t* bounds_err;   // debug build (-DODDIO_HIP_BOUNDS): {count, first code, first value, first source}; null otherwise
 };
 

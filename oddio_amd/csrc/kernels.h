@@ -1935,7 +1935,7 @@ __global__ __launch_bounds__(64 * MIX_WG_WAVES, MIX_WAVES_PER_SIMD) void spatial
         const size_t off = (((size_t)tile * (TILE_FRAMES / PART_FRAMES) + 2u * (uint32_t)(le & 31)) * n_part + wave) * PART_BLOCK + (size_t)(le >> 5) * PART_FRAMES;
         const size_t step = (size_t)n_part * PART_BLOCK;
         if (16u * (uint32_t)(le & 31) + tile * TILE_FRAMES >= n_frames && !FULL) return;
-        if (TRACK == 2 && wave + 1u != n_part) {
+        if (TRACK == 2 && (P.track_all || wave + 1u != n_part)) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const float4 v = reinterpret_cast<const float4*>(init + off + (q >> 1) * step)[q & 1];

@@ -338,7 +338,7 @@ __global__ __launch_bounds__(128, MIX_WAVES_PER_SIMD) void spatial_mix_pair(Scen
         // the lane's 16 frames are two blocks of PART_FRAMES frames (kernels.h: the partial sums' layout)
         float* dst = partials + ((size_t)(2 * le) * gridDim.x + blockIdx.x) * PART_BLOCK + (size_t)wv * PART_FRAMES;
         const size_t dst_step = (size_t)gridDim.x * PART_BLOCK;
-        if (TRACK && blockIdx.x + 1u != gridDim.x) {       // (the workgroup the reference's walk starts with keeps its start value: the buffered set's sum)
+        if (TRACK && (P.track_all || blockIdx.x + 1u != gridDim.x)) {   // (the workgroup the reference's walk starts with keeps its start value: the buffered set's sum)
             const float* src = init + ((size_t)(2 * le) * gridDim.x + blockIdx.x) * PART_BLOCK + (size_t)wv * PART_FRAMES;
 #pragma unroll
             for (int q4 = 0; q4 < 4; ++q4) {
@@ -387,6 +387,22 @@ __global__ __launch_bounds__(PART_BLOCK * TRK_SEGS) void track_prefix(const floa
         for (int k = 0; k < TRK_BATCH; ++k)
             if (w - k >= lo) { q[(size_t)(w - k) * PART_BLOCK] = run; run = run + v[k]; }
     }
+}
+
+// Sharded scenes in TRACKED mode (scene_host.inc): the reference's walk passes the ranks in descending order (contiguous index shards:
+// rank world - 1 holds the highest slots), so rank r's running sums start at base_r = total_{world-1} + ... + total_{r+1}, the
+// totals being each rank's own sum of its first pass.  RCCL path: `gather` = ncclAllGather of the totals.
+__global__ void track_base(const float* __restrict__ gather, uint32_t rank, uint32_t world, uint32_t n_out, float* __restrict__ base) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_out) return;
+    float b = 0.0f;
+    bool first = true;
+    for (uint32_t r = world; r-- > rank + 1u;) { const float v = gather[(size_t)r * n_out + i]; b = first ? v : b + v; first = false; }
+    base[i] = b;
+}
+__global__ void add_stereo(float* __restrict__ out, const float* __restrict__ add, uint32_t n) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = out[i] + add[i];
 }
 
 }  // namespace oddio_hip

@@ -220,7 +220,7 @@ __global__ void apply_motion_dev(const uint32_t* __restrict__ ids, const float* 
 // and publishes the result, which every peer copies back.  One 8 KiB write, one 8 KiB read per peer and callback.
 // The slab is fine-grained memory; everything that crosses a process goes through system-scope atomics (the
 // per-XCD L2s and a peer's caches are not coherent for plain accesses inside a kernel).
-//   slab layout (floats after the header): [header 256 B: arrived[world] | done][result: stride][partial of rank 1..]
+//   slab layout (floats after the header): [header 256 B: arrived[world] | done][result: stride][partial of rank 1..][world rows: TRACKED mode's totals]
 // Waits are bounded (~2 s): a rank that never arrives must not hang the GPU; *err is set instead, and the host makes the
 // failure sticky for the scene (every later sample call returns ODDIO_HIP_ESTATE until the group is destroyed and re-made:
 // the ranks' source cursors are a callback apart by then, nothing inside the group can re-align them).  The ranks must
@@ -279,6 +279,37 @@ __global__ __launch_bounds__(1024) void p2p_fetch(float* __restrict__ buf, const
     __syncthreads();
     const float* res = reinterpret_cast<const float*>(slab + P2P_HEADER_WORDS);
     for (uint32_t i = threadIdx.x; i < n_out; i += blockDim.x) buf[i] = __hip_atomic_load(res + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+// TRACKED mode in a p2p group: every rank > 0 leaves its first pass's total in its row of the slab's SECOND block of rows
+// (rows world .. 2 world - 1: the first block is the final reduce's and is rewritten later in the same callback), then arrived[rank]
+// = epoch; every rank waits for the ranks above it and adds their totals in descending rank order -- the value the reference's
+// running sum has when its walk enters this rank's shard.  One block.  (The final reduce of the callback uses epoch + 1.)
+__global__ __launch_bounds__(1024) void p2p_gather_base(const float* __restrict__ total, uint32_t* slab, uint32_t stride, uint32_t rank, uint32_t world,
+                                                        uint32_t n_out, uint32_t epoch, float* __restrict__ base, uint32_t* __restrict__ err) {
+    float* rows = reinterpret_cast<float*>(slab + P2P_HEADER_WORDS) + (size_t)world * stride;
+    if (rank > 0) {
+        for (uint32_t i = threadIdx.x; i < n_out; i += blockDim.x) __hip_atomic_store(rows + (size_t)rank * stride + i, total[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __threadfence_system();
+        __syncthreads();
+        if (threadIdx.x == 0) __hip_atomic_store(slab + rank, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    if (base == nullptr) return;                       // (a rank whose callback is not a tracked one only contributes its total)
+    if (threadIdx.x == 0) {
+        bool all = true;
+        for (uint32_t r = rank + 1u; r < world; ++r) all = p2p_wait_equal(slab + r, epoch) && all;
+        if (!all) __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < n_out; i += blockDim.x) {
+        float b = 0.0f;
+        bool first = true;
+        for (uint32_t r = world; r-- > rank + 1u;) {
+            const float v = __hip_atomic_load(rows + (size_t)r * stride + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            b = first ? v : b + v; first = false;
+        }
+        base[i] = b;
+    }
 }
 
 // Seek::seek on every live source (signal.rs:48-51)

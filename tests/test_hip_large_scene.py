@@ -285,7 +285,9 @@ import oddio_amd as oa
 from oddio_amd import sharding, synth
 S, CLIP, N, RATE, START, SEED = 8192, 8192, 1024, 48000, 0.06, 99
 uid = sharding.exchange_unique_id(dist) if {reduce!r} == "rccl" else None
-sh = sharding.ShardedSpatialScene(device, S, N, rank, world, uid, postfx=oa.POSTFX_REINHARD, reduce={reduce!r}, dist=dist)
+sh = sharding.ShardedSpatialScene(device, S, N, rank, world, uid, postfx={postfx}, reduce={reduce!r}, dist=dist)
+if {mode}:
+    sh.scene.set_mode({mode})
 lo, hi = sh.shard
 sc = synth.make_scene(SEED, S, cube=10.0)
 frames = [oa.Frames.from_slice(RATE, synth.noise_clip(SEED, i, CLIP), device=device) for i in range(lo, hi)]
@@ -296,9 +298,9 @@ dist.barrier(); dist.destroy_process_group()
 """
 
 
-def _run_sharded_workers(tmp_path, world, own_gpu, reduce):
+def _run_sharded_workers(tmp_path, world, own_gpu, reduce, mode=0, postfx=1):
     script = tmp_path / "worker.py"
-    script.write_text(_WORKER.format(root=ROOT, tmp=str(tmp_path), own_gpu=own_gpu, reduce=reduce))
+    script.write_text(_WORKER.format(root=ROOT, tmp=str(tmp_path), own_gpu=own_gpu, reduce=reduce, mode=mode, postfx=postfx))
     import socket
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     procs = [subprocess.Popen([sys.executable, str(script)],
@@ -338,6 +340,35 @@ def test_sharded_scene_p2p_reduce_ranks_share_one_gpu(tmp_path, world):
             total = total + parts[r][cb]                      # ((p0 + p1) + p2): the reduce's order
         expect = (total / (np.float32(1.0) + np.abs(total))).astype(np.float32)   # Reinhard after the sum (reinhard.rs:32)
         np.testing.assert_array_equal(got[0][cb], expect)
+
+
+@pytest.mark.parametrize("world", [2, 8])
+def test_sharded_scene_tracked_mode_follows_the_unsharded_reference_sum(tmp_path, monkeypatch, world):
+    """ODDIO_HIP_MODE_TRACKED on a sharded scene: between its two passes every rank hands the ranks below it the total of its first
+    pass (p2p_gather_base) and starts its running sums at the sum of the ranks above it -- where the reference's reverse walk of the
+    WHOLE scene stands when it enters the shard.  Against the unsharded scene in ORDERED mode (the reference's sequential sum, bit
+    for bit)."""
+    import oddio_amd as oa
+    S, CLIP2, SEED2 = 8192, 8192, 99
+    monkeypatch.setenv("ODDIO_HIP_PAIR_MIN_GROUPS", "1")        # (shards of 1 024 .. 4 096 sources take the tracked path)
+    got = _run_sharded_workers(tmp_path, world, own_gpu=False, reduce="p2p", mode=oa.MODE_TRACKED, postfx=0)
+    plain = _run_sharded_workers(tmp_path, world, own_gpu=False, reduce="p2p", mode=oa.MODE_FAST_UNFUSED, postfx=0)     # (the tree sum, for scale)
+    for r in range(1, world):
+        np.testing.assert_array_equal(got[0], got[r])
+    sc = synth.make_scene(SEED2, S, cube=10.0)
+    control, scene = oa.SpatialScene(device=0, max_sources=S, max_frames=N)
+    scene.set_mode(oa.MODE_ORDERED)
+    frames = [oa.Frames.from_slice(RATE, synth.noise_clip(SEED2, i, CLIP2), device=0) for i in range(S)]
+    control.play_frames_batch(frames, np.full(S, START), sc["position"], sc["velocity"], sc["radius"])
+    errs, tree = [], []
+    for cb in range(2):
+        ref = scene.sample_n(INTERVAL, N)
+        errs.append(float(np.abs(got[0][cb] - ref).max() / np.abs(ref).max()))
+        tree.append(float(np.abs(plain[0][cb] - ref).max() / np.abs(ref).max()))
+    print(f"sharded TRACKED, world {world}: |gpu - reference| / max|reference| per callback:", errs, "the tree sum:", tree)
+    assert max(errs) <= 8e-7, (errs, tree)
+    assert np.mean(errs) < 0.5 * np.mean(tree), (errs, tree)
+    scene.close()
 
 
 def test_bench_self_launch_two_ranks_sharded():
