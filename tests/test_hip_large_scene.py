@@ -271,6 +271,31 @@ def test_rccl_reduce_world_1(big):
     scene2.reduce_destroy()
 
 
+def test_rccl_group_of_one_in_tracked_mode(big, monkeypatch):
+    """ODDIO_HIP_MODE_TRACKED in an RCCL reduce group: the exchange between the two passes is an ncclAllGather of the ranks' totals +
+    track_base.  With a world of one the base is zero and every block leaves end - start: the same bits as the mode without a group
+    (the only execution of that branch this image allows; the p2p branch runs with 2 and 8 ranks below)."""
+    import oddio_amd as oa
+    from oddio_amd import api
+    monkeypatch.setenv("ODDIO_HIP_PAIR_MIN_GROUPS", "1")
+    S = 4096
+    for n_frames in (N, 448):
+        control, scene, handles, frames = play_shard(big, 0, S, mode=oa.MODE_TRACKED)
+        alone = [scene.sample_n(INTERVAL, n_frames).copy() for _ in range(2)]
+        scene.close()
+        control2, scene2, handles2, frames2 = play_shard(big, 0, S, mode=oa.MODE_TRACKED)
+        scene2.reduce_init(0, 1, api.reduce_unique_id())
+        for cb in range(2):
+            np.testing.assert_array_equal(scene2.sample_n(INTERVAL, n_frames), alone[cb])
+        scene2.reduce_destroy()
+        scene2.close()
+        c3, s3, h3, f3 = play_shard(big, 0, S, mode=oa.MODE_ORDERED)
+        for cb in range(2):
+            ref = s3.sample_n(INTERVAL, n_frames)
+            assert np.abs(alone[cb] - ref).max() <= 6e-7 * np.abs(ref).max()
+        s3.close()
+
+
 _WORKER = r"""
 import os, sys
 import numpy as np
