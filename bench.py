@@ -513,10 +513,12 @@ def bench_mixer(device: int, frames_bank) -> dict:
     for i in range(S):
         control.play(oa.MonoToStereo(oa.FramesSignal(frames_bank[(i * 2654435761) % len(frames_bank)], 0.25)))
     fast = timed(mixer, 16, 8)
+    mixer.set_mode(oa.MODE_TRACKED)                    # the reference's sequential sum to ~1e-6 (tests/test_hip_mixer_tracked.py)
+    tracked = timed(mixer, 8, 3)
     mixer.set_mode(oa.MODE_ORDERED)
     ordered = timed(mixer, 8, 3)
     mixer.close()
-    out.update({"sources": S, "fast_ms_per_callback": fast, "ordered_ms_per_callback": ordered,
+    out.update({"sources": S, "fast_ms_per_callback": fast, "tracked_ms_per_callback": tracked, "ordered_ms_per_callback": ordered,
                 "fast_source_frames_per_s": float(S) * N_FRAMES / (fast * 1e-3), "ordered_source_frames_per_s": float(S) * N_FRAMES / (ordered * 1e-3)})
     # The Mixer at the headline size through its device-output entry (oddio_hip_mixer_sample_device: callbacks enqueued back to back,
     # one synchronisation), with a roofline of its own.  Algorithmic bytes per callback: S * (4 * N + P) + 8 * N -- every source reads
@@ -539,12 +541,21 @@ def bench_mixer(device: int, frames_bank) -> dict:
     dev_ms = (time.perf_counter() - t0) / reps * 1e3
     assert bool(torch.isfinite(dev_out).all()) and float(dev_out.abs().max()) > 0.0
     host_ms = timed(mixer, 8, 2)                       # the same mixer through the reference's own boundary (host slice)
+    mixer.set_mode(oa.MODE_TRACKED)
+    for _ in range(3):
+        mixer.sample_device(interval, dev_out.data_ptr(), N_FRAMES)
+    mixer.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(8):
+        mixer.sample_device(interval, dev_out.data_ptr(), N_FRAMES)
+    mixer.synchronize()
+    dev_tracked_ms = (time.perf_counter() - t0) / 8 * 1e3
     assert len(mixer) == S2, len(mixer)
     mixer.close()
     b_alg = float(S2) * (4.0 * N_FRAMES + 128.0) + 8.0 * N_FRAMES
     out["device_output"] = {
         "sources": S2, "boundary": "oddio_hip_mixer_sample_device (frames stay in HBM, callbacks enqueued back to back)",
-        "ms_per_callback": dev_ms, "host_output_ms_per_callback": host_ms,
+        "ms_per_callback": dev_ms, "host_output_ms_per_callback": host_ms, "tracked_ms_per_callback": dev_tracked_ms,
         "source_frames_per_s": float(S2) * N_FRAMES / (dev_ms * 1e-3),
         "roofline": {"bound": "hbm", "kernel": "mixer_prepass + mixer_mix + mixer_reduce (the whole callback)", "algorithmic_bytes_per_callback": b_alg,
                      "achieved": b_alg / (dev_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": b_alg / (dev_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,

@@ -80,7 +80,9 @@ enum { /* oddio_hip_scene_set_mode */
                                    plus one buffer of start values).  A scene in a reduce group (sharded): the same mode on
                                    every rank -- between the passes the ranks exchange their totals (ncclAllGather / the p2p
                                    slab) and each starts at the sum of the ranks above it, the reference's walk order
-                                   over contiguous index shards.  Mixers treat it as ORDERED. */
+                                   over contiguous index shards.  Mixers: the fast path (plain MonoToStereo / mono sources) of
+                                   mixers of >= 8 192 sources is mixed twice in the same way (mixer_kernels.h TRACK);
+                                   smaller mixers and the general path (Gain / Speed chains, ...) are ORDERED. */
 };
 
 typedef struct oddio_hip_frames oddio_hip_frames; /* == Arc<Frames<f32>>, src/frames.rs:19-22 */

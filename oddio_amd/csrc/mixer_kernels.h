@@ -63,17 +63,26 @@ struct MixerLds {
 // STORE (ORDERED mode above the serial threshold, round 4): instead of accumulating, every source's contribution is written to its
 // rows in the layout ordered_sum reads (kernels.h: [group of 16 sources][ear][16-frame column block][source][16 frames]; MonoToStereo:
 // the same row for both ears), and ordered_sum adds them in the reference's order (mixer.rs:100-117, reverse slot order).
-template <bool FULL, bool STORE = false>
+// TRACK (ODDIO_HIP_MODE_TRACKED, the scene's mode of pair_kernels.h on a Mixer): 2 = the second pass -- `track_start` holds, in the partial
+// tiles' layout, the value the reference's running sum has when its reverse walk (mixer.rs:100-117) reaches this wave's sources
+// (mixer_track_prefix over the first pass's partial tiles); the wave restarts there and leaves end - start (the wave the walk starts
+// with keeps its start: zero).  The first pass is the plain kernel.
+template <bool FULL, bool STORE = false, int TRACK = 0>
 __global__ __launch_bounds__(64) void mixer_mix(uint32_t n_sources, uint32_t n_frames, float interval,
                                                 const MixStatic* __restrict__ st, const MixParams* __restrict__ par,
                                                 float* __restrict__ partials, uint32_t groups_per_wave, uint32_t n_groups,
-                                                float* __restrict__ rows, uint32_t rows_ncb) {
+                                                float* __restrict__ rows, uint32_t rows_ncb, const float* __restrict__ track_start = nullptr) {
     __shared__ MixerLds L;
     const int lane = threadIdx.x;
     const uint32_t wave = blockIdx.x, tile = blockIdx.y;
     float acc[16];
 #pragma unroll
     for (int k = 0; k < 16; ++k) acc[k] = 0.0f;
+    if (TRACK == 2) {   // (the partial tiles hold interleaved stereo, both channels the mono sum: the left one)
+        const float4* src = reinterpret_cast<const float4*>(track_start + ((size_t)tile * gridDim.x + wave) * (2 * MIXER_TILE) + 32 * lane);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) { const float4 v = src[q]; acc[2 * q] = v.x; acc[2 * q + 1] = v.z; }
+    }
     const uint32_t frame0 = tile * MIXER_TILE + 16u * (uint32_t)lane;
     const uint32_t split_log2 = groups_per_wave >> 24;
     uint32_t g_lo = wave * (groups_per_wave & 0xffffffu);
@@ -321,6 +330,11 @@ __global__ __launch_bounds__(64) void mixer_mix(uint32_t n_sources, uint32_t n_f
     (void)len_tile;
     if (STORE) return;
     // MonoToStereo: duplicate (signal.rs:73-80); Mixer adds per channel (mixer.rs:114-116)
+    if (TRACK == 2 && wave + 1u != gridDim.x) {
+        const float4* src = reinterpret_cast<const float4*>(track_start + ((size_t)tile * gridDim.x + wave) * (2 * MIXER_TILE) + 32 * lane);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) { const float4 v = src[q]; acc[2 * q] = acc[2 * q] - v.x; acc[2 * q + 1] = acc[2 * q + 1] - v.z; }
+    }
     float4* dst = reinterpret_cast<float4*>(partials + ((size_t)tile * gridDim.x + wave) * (2 * MIXER_TILE) + 32 * lane);
 #pragma unroll
     for (int q = 0; q < 8; ++q) dst[q] = make_float4(acc[2 * q], acc[2 * q], acc[2 * q + 1], acc[2 * q + 1]);
@@ -338,14 +352,25 @@ __global__ __launch_bounds__(64) void mixer_mix(uint32_t n_sources, uint32_t n_f
 // Algorithmic bytes per callback: S * (4 * N + 64) + 8 * N; mixer_mix (cursor scan, window through LDS) reached 0.46-0.48 of the
 // 8 TB/s peak on it, this kernel is bound by HBM alone.
 typedef float mixf4 __attribute__((ext_vector_type(4)));
+template <int TRACK = 0>      // (TRACK: see mixer_mix)
 __global__ __launch_bounds__(64) void mixer_mix_unit(uint32_t n_sources, uint32_t n_frames, float interval,
                                                      const MixStatic* __restrict__ st, const MixParams* __restrict__ par,
-                                                     float* __restrict__ partials, uint32_t groups_per_wave, uint32_t n_groups) {
+                                                     float* __restrict__ partials, uint32_t groups_per_wave, uint32_t n_groups,
+                                                     const float* __restrict__ track_start = nullptr) {
     const int lane = threadIdx.x;
     const uint32_t wave = blockIdx.x, tile = blockIdx.y;
     mixf4 acc[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) acc[k] = mixf4{0.0f, 0.0f, 0.0f, 0.0f};
+    if (TRACK == 2) {
+        const float* src = track_start + ((size_t)tile * gridDim.x + wave) * (2 * MIXER_TILE);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float4* s4 = reinterpret_cast<const float4*>(src + 2 * (4 * lane + 256 * k));
+            const float4 a0 = s4[0], a1 = s4[1];
+            acc[k] = mixf4{a0.x, a0.z, a1.x, a1.z};
+        }
+    }
     const uint32_t split_log2 = groups_per_wave >> 24;
     uint32_t g_lo = wave * (groups_per_wave & 0xffffffu);
     uint32_t g_hi = g_lo + (groups_per_wave & 0xffffffu);
@@ -422,11 +447,53 @@ __global__ __launch_bounds__(64) void mixer_mix_unit(uint32_t n_sources, uint32_
     // MonoToStereo: duplicate (signal.rs:73-80); the partial tile is interleaved stereo like mixer_mix's
     float* dst = partials + ((size_t)tile * gridDim.x + wave) * (2 * MIXER_TILE);
     (void)n_frames;
+    if (TRACK == 2 && wave + 1u != gridDim.x) {
+        const float* src = track_start + ((size_t)tile * gridDim.x + wave) * (2 * MIXER_TILE);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float4* s4 = reinterpret_cast<const float4*>(src + 2 * (4 * lane + 256 * k));
+            const float4 a0 = s4[0], a1 = s4[1];
+            acc[k] = acc[k] - mixf4{a0.x, a0.z, a1.x, a1.z};
+        }
+    }
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         float4* d4 = reinterpret_cast<float4*>(dst + 2 * (4 * lane + 256 * k));
         d4[0] = make_float4(acc[k].x, acc[k].x, acc[k].y, acc[k].y);
         d4[1] = make_float4(acc[k].z, acc[k].z, acc[k].w, acc[k].w);
+    }
+}
+
+// ODDIO_HIP_MODE_TRACKED on a Mixer, between the passes: prefix[tile][w][o] = the partial tiles of the waves the reverse walk passes before
+// wave w (w + 1 .. n_waves - 1), added in that order -- the layout of the partial tiles in and out.  grid = (2 * MIXER_TILE / 64, tiles);
+// block = 64 outputs x 16 segments of the wave list (segment sums, their scan, the running values).
+__global__ __launch_bounds__(1024) void mixer_track_prefix(const float* __restrict__ partials, float* __restrict__ prefix, uint32_t n_waves) {
+    __shared__ float tot[16][64];
+    const uint32_t ox = threadIdx.x & 63, seg = threadIdx.x >> 6;
+    const size_t base = (size_t)blockIdx.y * n_waves * (2 * MIXER_TILE) + (size_t)blockIdx.x * 64 + ox;
+    const int per = (int)((n_waves + 15) / 16);
+    const int hi = (int)n_waves - 1 - (int)seg * per;
+    const int lo = hi - per + 1 > 0 ? hi - per + 1 : 0;
+    constexpr int BATCH = 16;
+    float sum = 0.0f;
+    for (int w = hi; w >= lo; w -= BATCH) {
+        float v[BATCH];
+#pragma unroll
+        for (int k = 0; k < BATCH; ++k) v[k] = (w - k >= lo) ? partials[base + (size_t)(w - k) * (2 * MIXER_TILE)] : 0.0f;
+#pragma unroll
+        for (int k = 0; k < BATCH; ++k) sum = sum + v[k];
+    }
+    tot[seg][ox] = sum;
+    __syncthreads();
+    float run = 0.0f;
+    for (uint32_t k = 0; k < seg; ++k) run = run + tot[k][ox];
+    for (int w = hi; w >= lo; w -= BATCH) {
+        float v[BATCH];
+#pragma unroll
+        for (int k = 0; k < BATCH; ++k) v[k] = (w - k >= lo) ? partials[base + (size_t)(w - k) * (2 * MIXER_TILE)] : 0.0f;
+#pragma unroll
+        for (int k = 0; k < BATCH; ++k)
+            if (w - k >= lo) { prefix[base + (size_t)(w - k) * (2 * MIXER_TILE)] = run; run = run + v[k]; }
     }
 }
 

@@ -41,6 +41,8 @@ def main():
         for i in range(S):
             control.play(oa.MonoToStereo(oa.FramesSignal(frames[int(pick[i])], 0.25)))
         fast = timed(mixer)
+        mixer.set_mode(oa.MODE_TRACKED)
+        tracked = timed(mixer, reps=6, warm=2)
         mixer.set_mode(oa.MODE_ORDERED)
         ordered = timed(mixer, reps=6, warm=2)
         mixer.close()
@@ -61,7 +63,7 @@ def main():
         scene.set_mode(oa.MODE_ORDERED)
         sp_ord = timed(scene, reps=6, warm=2)
         scene.close()
-        print(f"{S:7d} sources: Mixer FAST {fast:8.4f} ms  ORDERED {ordered:8.4f} ms | SpatialScene FAST {sp:8.4f} ms  ORDERED {sp_ord:8.4f} ms (host-output callbacks)", flush=True)
+        print(f"{S:7d} sources: Mixer FAST {fast:8.4f} ms  TRACKED {tracked:8.4f} ms  ORDERED {ordered:8.4f} ms | SpatialScene FAST {sp:8.4f} ms  ORDERED {sp_ord:8.4f} ms (host-output callbacks)", flush=True)
 
 
 if __name__ == "__main__":
