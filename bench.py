@@ -520,6 +520,21 @@ def bench_mixer(device: int, frames_bank) -> dict:
     mixer.close()
     out.update({"sources": S, "fast_ms_per_callback": fast, "tracked_ms_per_callback": tracked, "ordered_ms_per_callback": ordered,
                 "fast_source_frames_per_s": float(S) * N_FRAMES / (fast * 1e-3), "ordered_source_frames_per_s": float(S) * N_FRAMES / (ordered * 1e-3)})
+    # what each mode promises about a mixer's output at this size: three mixers with the same sources, one callback, against ORDERED
+    # (the reference's sequential f32 sum in its reverse slot order, bit-exact: tests/test_hip_mixer.py)
+    Sp = min(32768, S)
+    outs = {}
+    for mode, name in ((oa.MODE_ORDERED, "ordered"), (oa.MODE_FAST, "fast"), (oa.MODE_TRACKED, "tracked")):
+        control, mixer = oa.Mixer(device=device, max_sources=Sp, max_frames=N_FRAMES)
+        mixer.set_mode(mode)
+        for i in range(Sp):
+            control.play(oa.MonoToStereo(oa.FramesSignal(frames_bank[(i * 2654435761) % len(frames_bank)], 0.25)))
+        outs[name] = mixer.sample_n(interval, N_FRAMES).copy()
+        mixer.close()
+    scale = float(np.abs(outs["ordered"]).max())
+    out["parity"] = {"sources": Sp, "reference": "ORDERED mode (the reference's sum order, bit-exact against the oracle in the tests)",
+                     "fast_rel_err_vs_ordered": float(np.abs(outs["fast"] - outs["ordered"]).max()) / scale,
+                     "tracked_rel_err_vs_ordered": float(np.abs(outs["tracked"] - outs["ordered"]).max()) / scale, "tolerance": 1e-5}
     # The Mixer at the headline size through its device-output entry (oddio_hip_mixer_sample_device: callbacks enqueued back to back,
     # one synchronisation), with a roofline of its own.  Algorithmic bytes per callback: S * (4 * N + P) + 8 * N -- every source reads
     # N mono f32 samples once (the resample ratio of a Mixer source is 1: no Doppler) plus P = 128 bytes of per-source records, and

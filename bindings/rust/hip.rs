@@ -96,6 +96,7 @@ extern "C" {
     fn oddio_hip_mixer_source_release(m: *mut RawMixer, id: u32) -> c_int;
     fn oddio_hip_mixer_is_stopped(m: *mut RawMixer, id: u32, stopped: *mut c_int) -> c_int;
     fn oddio_hip_mixer_set_postfx(m: *mut RawMixer, postfx: c_int) -> c_int;
+    fn oddio_hip_mixer_set_mode(m: *mut RawMixer, mode: c_int) -> c_int;
     fn oddio_hip_mixer_sample(m: *mut RawMixer, interval: f32, out: *mut f32, n_frames: usize) -> c_int;
     fn oddio_hip_mixer_sample_device(m: *mut RawMixer, interval: f32, dev_out: *mut f32, n_frames: usize) -> c_int;
     fn oddio_hip_mixer_synchronize(m: *mut RawMixer) -> c_int;
@@ -374,6 +375,17 @@ impl HipMixer {
     }
     pub fn with_postfx(self, postfx: c_int) -> Self {
         check(unsafe { oddio_hip_mixer_set_postfx((self.0).0, postfx) });
+        self
+    }
+    /// The reference's sequential f32 sum over the sources (src/mixer.rs:100-117), bit for bit (ODDIO_HIP_MODE_ORDERED).
+    pub fn bit_exact(self) -> Self {
+        check(unsafe { oddio_hip_mixer_set_mode((self.0).0, 1) });
+        self
+    }
+    /// That sum to ~1e-6 of the peak at about twice the default mode's cost (ODDIO_HIP_MODE_TRACKED): mixers of thousands of sources,
+    /// coherent mixes above all, where the default tree sum is farther than 1e-5 from the reference's f32 sum.
+    pub fn tracked(self) -> Self {
+        check(unsafe { oddio_hip_mixer_set_mode((self.0).0, 3) });
         self
     }
 }
