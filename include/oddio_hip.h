@@ -76,7 +76,8 @@ enum { /* oddio_hip_scene_set_mode */
                                    restarted sums repeat the reference's rounding errors, not just its exact terms.
                                    Applies to callbacks of up to 1024 frames over >= 32 768 live sources (the TRACK
                                    instantiations of spatial_mix_pair and, up to 512 frames, of spatial_mix: about 2.2x
-                                   a FAST callback); every other callback is an ORDERED one (set_mode allocates as for ORDERED,
+                                   a FAST callback), and to the ring reads of a buffered set of that size; every other
+                                   callback (or set) is an ORDERED one (set_mode allocates as for ORDERED,
                                    plus one buffer of start values).  A scene in a reduce group (sharded): the same mode on
                                    every rank -- between the passes the ranks exchange their totals (ncclAllGather / the p2p
                                    slab) and each starts at the sum of the ranks above it, the reference's walk order
