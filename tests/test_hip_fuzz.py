@@ -139,6 +139,17 @@ def test_random_operations_bit_exact(seed):
     scene.close()
 
 
+@pytest.mark.parametrize("mode", ["fast", "unfused", "tracked"])
+@pytest.mark.parametrize("seed", [3, 11])
+def test_random_operations_in_the_tolerance_modes(monkeypatch, seed, mode):
+    """The same operation stream in the modes whose contract is the 1e-5 tolerance (tests/soak_fuzz.py runs them over thousands of
+    seeds): FAST, FAST_UNFUSED and TRACKED, with spatial_mix_pair and the TRACK instantiations taking these small scenes too
+    (ODDIO_HIP_PAIR_MIN_GROUPS=1)."""
+    monkeypatch.setenv("ODDIO_FUZZ_MODE", mode)
+    monkeypatch.setenv("ODDIO_HIP_PAIR_MIN_GROUPS", "1")
+    test_random_operations_bit_exact(seed)
+
+
 @pytest.mark.parametrize("exact", [False, True])
 @pytest.mark.parametrize("seed", range(6))
 def test_random_operations_unsynchronised(seed, exact):
