@@ -62,7 +62,7 @@ def test_tracked_follows_the_sequential_sum(monkeypatch, n_src, n_frames, with_b
         e_f.append(float(np.abs(fast[cb] - ref[cb]).max() / scale))
     print("tracked", e_t, "tree", e_f)
     assert max(e_t) <= 6e-7, (e_t, e_f)               # a few ulps of the peak
-    assert np.mean(e_t) < 0.5 * np.mean(e_f), (e_t, e_f)
+    assert np.mean(e_t) < 0.7 * np.mean(e_f), (e_t, e_f)
 
 
 def test_tracked_falls_back_to_ordered_for_small_scenes(monkeypatch):
