@@ -1609,7 +1609,7 @@ __global__ __launch_bounds__(64 * MIX_WG_WAVES, MIX_WAVES_PER_SIMD) void spatial
     const float fbase = (float)frame0;
 #pragma unroll
     for (int k = 0; k < 16; ++k) { acc[k] = 0.0f; fi[k] = fbase + (float)k; }   // `i as f32` (spatial.rs:459)
-    static_assert(TRACK == 0 || (!STORE && !FUSED), "the tracked sums carry the reference's roundings");
+    static_assert(TRACK == 0 || !STORE, "TRACK accumulates"); static_assert(TRACK != 2 || !FUSED, "the tracked sums carry the reference's roundings (the first pass only places their start values: fused or not)");
     if (TRACK == 2) {
         if (frame0 < n_frames) {
             const uint32_t n_part = gridDim.x * MIX_WG_WAVES;
