@@ -312,7 +312,13 @@ int oddio_hip_postfx_device(int device, int postfx, float* dev_buf, size_t n_fra
  * oddio_hip_scene_reduce_init every *_sample* call of that scene sums the ranks' partial stereo
  * buffers with ONE RCCL all-reduce (2*n_frames f32, sum) enqueued on the scene's stream between the
  * shard's own reduction and the post-mix filter (Reinhard/Tanh/Adapt wrap the *scene*, so they run
- * after the sum, on every rank).  All ranks must call *_sample* with the same n_frames.
+ * after the sum, on every rank).  All ranks must call *_sample* with the same n_frames AND THE SAME MODE: a TRACKED
+ * callback of a grouped scene issues one collective more than the other modes (the ranks' first-pass totals: ncclAllGather /
+ * the slab's second block of rows), so oddio_hip_scene_set_mode must take effect between the same two callbacks on every rank.
+ * Which collectives a callback issues depends on the mode and the group alone -- the exchange buffer is allocated by reduce_init
+ * for every group (ODDIO_HIP_ENOMEM instead of joining without it), and a TRACKED scene needs a librccl that exports
+ * ncclAllGather (reduce_init and set_mode return ODDIO_HIP_ENODEV otherwise) -- never on what one rank's allocations or live
+ * source count happen to be.  Ranks that disagree anyway: the peer-to-peer group times out (ODDIO_HIP_ESTATE, below); RCCL hangs.
  *   rank 0:    oddio_hip_reduce_unique_id(id)   (ncclGetUniqueId) -> hand `id` to the other ranks
  *   all ranks: oddio_hip_scene_reduce_init(scene, rank, world, id, ODDIO_HIP_UNIQUE_ID_BYTES)
  * RCCL (librccl.so.1) is loaded on first use; a process that never shards does not need it. */

@@ -401,8 +401,11 @@ __global__ __launch_bounds__(64) void mixer_mix_unit(uint32_t n_sources, uint32_
             const double s0 = t_c * (double)ss.clip_rate;
             const long long base = f64_as_isize(s0);
             frac0 = (float)(s0 - (double)base);
-            // (indices beyond +-2^30 samples lie outside every clip: clamped so that the 32-bit byte offsets below stay out of range)
-            base_i = (int)(base > (1ll << 30) ? (1ll << 30) : (base < -(1ll << 30) ? -(1ll << 30) : base));
+            // (indices beyond +-(2^29 - 8192) samples lie outside every clip this kernel is handed; clamped there so that the 32-bit byte
+            // offsets below -- 4 * base_i plus at most 4 * 1024 + 16 -- neither wrap nor land inside the descriptor's range: a source
+            // scheduled hours ahead reads zeros, frames.rs:105-123)
+            constexpr long long BASE_LIM = (1ll << 29) - 8192;
+            base_i = (int)(base > BASE_LIM ? BASE_LIM : (base < -BASE_LIM ? -BASE_LIM : base));
         }
         const unsigned long long live_mask = __ballot(live);
         const uint32_t clip_lo = (uint32_t)((uint64_t)ss.clip & 0xffffffffu), clip_hi = (uint32_t)((uint64_t)ss.clip >> 32) & 0xffffu;
