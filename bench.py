@@ -481,8 +481,35 @@ def multi_gpu_selfcheck(device: int, rank: int, world: int, dist, reduce_pref: s
     if max(errs) > 1e-5:
         raise SystemExit(f"multi-GPU self-check failed: the {world}-shard scene (reduce: {kind}) differs from the unsharded one by {max(errs):.3g} "
                          f"of its peak on some rank (per rank: {errs})")
+    # ... and the conforming mode: the same scene sharded in ODDIO_HIP_MODE_TRACKED (the ranks exchange the totals of their first
+    # pass between the passes: ncclAllGather / the slab's second block of rows) against the unsharded scene in ORDERED mode -- the
+    # reference's sequential sum bit for bit (tests/test_hip_large_scene.py).  ODDIO_HIP_PAIR_MIN_GROUPS=1 (read when a scene is
+    # created): shards of a few hundred sources take the two-pass kernels too, as the shards of a full-size scene do.
+    control, scene = oa.SpatialScene(device=device, max_sources=S, max_frames=N_FRAMES)
+    scene.set_mode(oa.MODE_ORDERED)
+    ordered = render(control, scene, 0, S)
+    scene.close()
+    saved = os.environ.get("ODDIO_HIP_PAIR_MIN_GROUPS")
+    os.environ["ODDIO_HIP_PAIR_MIN_GROUPS"] = "1"
+    try:
+        uid = sharding.exchange_unique_id(dist) if kind == "rccl" else None
+        sh = sharding.ShardedSpatialScene(device, S, N_FRAMES, rank, world, uid, reduce=kind, dist=dist)
+    finally:
+        if saved is None:
+            del os.environ["ODDIO_HIP_PAIR_MIN_GROUPS"]
+        else:
+            os.environ["ODDIO_HIP_PAIR_MIN_GROUPS"] = saved
+    sh.scene.set_mode(oa.MODE_TRACKED)
+    got = render(sh.control, sh.scene, lo, hi)
+    sh.scene.close()
+    err_t = max(float(np.abs(g - w).max()) / max(float(np.abs(w).max()), 1e-30) for g, w in zip(got, ordered))
+    errs_t = [None] * world
+    dist.all_gather_object(errs_t, err_t)
+    if max(errs_t) > 3e-6:
+        raise SystemExit(f"multi-GPU self-check failed: the {world}-shard scene in TRACKED mode (reduce: {kind}) is {max(errs_t):.3g} of the peak from the "
+                         f"unsharded scene's sequential sum on some rank (per rank: {errs_t}); the bound is 3e-6")
     del frames, clips
-    return {"sources": S, "reduce": kind, "rccl_error": rccl_error, "max_rel_err": max(errs)}
+    return {"sources": S, "reduce": kind, "rccl_error": rccl_error, "max_rel_err": max(errs), "tracked_max_rel_err_vs_ordered": max(errs_t)}
 
 
 def bench_mixer(device: int, frames_bank) -> dict:
@@ -1064,6 +1091,29 @@ def main():
         tracked_ms = (time.perf_counter() - tt0) / 16 * 1e3
         scene.set_mode(oa.MODE_FAST)
 
+    tracked_by_rank = None
+    if world > 1:
+        # The conforming figure of a multi-GPU run: ODDIO_HIP_MODE_TRACKED on every rank (scenes: each scene tracks its own sum;
+        # sharded: the ranks exchange their first pass's totals between the passes), the same protocol as the timed region --
+        # barrier + synchronize on both sides, the slowest rank counts.  (ORDERED is not timed here: a sharded scene's rank-ordered
+        # sum of per-shard ORDERED sums is not the reference's order across the shards.)
+        import oddio_amd as oa
+        scene.set_mode(oa.MODE_TRACKED)
+        n_warm, n_timed = 3, 16
+        for _ in range(n_warm):
+            one_step()
+        sync_all()
+        tt0 = time.perf_counter()
+        for _ in range(n_timed):
+            one_step()
+        sync_all()
+        t_tr = torch.tensor([time.perf_counter() - tt0], dtype=torch.float64)
+        tracked_by_rank = [None] * world
+        dist.all_gather_object(tracked_by_rank, float(t_tr.item()) / n_timed * 1e3)
+        dist.all_reduce(t_tr, op=dist.ReduceOp.MAX)
+        tracked_ms = float(t_tr.item()) / n_timed * 1e3
+        scene.set_mode(oa.MODE_FAST)
+
     ranks_seen = 1
     per_rank_ms = [elapsed / args.steps * 1e3]
     per_rank_mix_ms = [float(hist[:, 1].mean())]
@@ -1130,6 +1180,7 @@ def main():
                 "parallelism": ("single-gpu" if world == 1 else ((f"source-sharded scene + stereo-buffer reduce ({args.reduce})") if sharded else "scene-parallel")),
                 "ranks_seen": ranks_seen,
                 "ms_per_step_by_rank": per_rank_ms,
+                "tracked_ms_per_step_by_rank": tracked_by_rank,      # (N > 1) the conforming mode, every rank's own time
                 # every rank's own roofline fraction (its mix kernel's average over the timed callbacks against the 8 TB/s peak)
                 "roofline_frac_by_rank": [algorithmic_bytes(len(g["ids"]), N_FRAMES) / (m_ * 1e-3) / 1e9 / HBM_PEAK_GBPS for m_ in per_rank_mix_ms],
                 "multi_gpu_selfcheck": selfcheck,        # (N > 1) the sharded-vs-unsharded scene check that ran before the timed region, and the reduce it found working
@@ -1139,8 +1190,10 @@ def main():
             # reference at this size because the reference's own sequential f32 sum is that far from the exact one): the faster of
             # TRACKED (the reference's sum with its rounding errors, ~1e-6: parity.tracked_rel_err_vs_reference) and ORDERED (the
             # reference's sum order, bit-exact: value_bit_exact), callbacks enqueued back to back
-            "value_conforming": (float(S) * N_FRAMES / (min(tracked_ms or ordered_ms, ordered_ms) * 1e-3)) if ordered_ms else None,
-            "value_conforming_mode": (("TRACKED" if (tracked_ms and tracked_ms < ordered_ms) else "ORDERED") if ordered_ms else None),
+            # (N > 1: TRACKED on every rank, whole-job aggregate like `value`, the slowest rank's time)
+            "value_conforming": ((float(S) * N_FRAMES / (min(tracked_ms or ordered_ms, ordered_ms) * 1e-3)) if ordered_ms else
+                                 ((float(S) * N_FRAMES * world / (tracked_ms * 1e-3)) if tracked_ms else None)),
+            "value_conforming_mode": (("TRACKED" if (tracked_ms and tracked_ms < ordered_ms) else "ORDERED") if ordered_ms else ("TRACKED" if tracked_ms else None)),
             "value_bit_exact": (float(S) * N_FRAMES / (ordered_ms * 1e-3)) if ordered_ms else None,    # ORDERED: the reference's bits
             "tracked_mode_ms_per_step": tracked_ms,             # the reference's sum to ~1e-6 (two passes of the FAST-mode kernel), callbacks back to back
             "max_realtime_sources": value / RATE,

@@ -80,3 +80,44 @@ def noise_clip(seed: int, index: int, length: int) -> np.ndarray:
         z = z ^ (z >> np.uint64(31))
     out[:] = (z >> np.uint64(40)).astype(np.float32) * np.float32(2.0 ** -24) * np.float32(2.0) - np.float32(1.0)
     return out
+
+
+def adversarial_scene(kind: str, n_sources: int, seed: int = 7, clip_len: int = 8192) -> dict:
+    """Scenes built to stress a summation order rather than the resampler (tests, bench.py's parity block): the sources share a
+    small clip bank (`bank` [n_clips, clip_len], source i plays clip `clip_of[i]`), positions / velocities as in make_scene.
+
+    "cancelling": coherent sources that cancel in pairs -- 4 low sine tones and their negations, sources 2k / 2k + 1 on the same
+        tone with opposite signs, all inside a 10 cm cluster 3.6 m from the listener moving at <= 1 m/s: every addend is ~1e2 x
+        the residue it leaves, the reference's running sum (src/spatial.rs:459-460) hovers around zero.
+    "parked": the sources the reference's reverse walk (spatial.rs:204) meets first -- the highest slots -- are static DC clips that
+        lift the running sum of both ears to just under 16.0; the other ~260 000 are quiet noise sources whose random walk then
+        crosses that power of two (where the ulp of the sum, and with it every rounding error, doubles) again and again."""
+    st = SplitMixStreams(seed ^ 0xADFE, n_sources)
+    if kind == "cancelling":
+        tones = np.stack([sine_clip(110.0 * (k + 1), clip_len) for k in range(4)])
+        bank = np.concatenate([tones, -tones]).astype(np.float32)
+        i = np.arange(n_sources)
+        clip_of = ((i // 2) % 4 + 4 * (i % 2)).astype(np.uint32)
+        centre = np.array([3.0, 0.5, -2.0], dtype=np.float32)
+        pos = centre[None, :] + np.stack([st.uniform(-0.05, 0.05) for _ in range(3)], axis=1)
+        vel = np.stack([st.uniform(-1.0, 1.0) for _ in range(3)], axis=1)
+    elif kind == "parked":
+        n_noise_clips = 64
+        bank = np.concatenate([np.ones((1, clip_len), dtype=np.float32),
+                               np.stack([noise_clip(seed, k, clip_len) for k in range(n_noise_clips)])]).astype(np.float32)
+        # one DC source 1 m in front of the listener adds radius / |p - ear| * (0.5 + 0.5 / sqrt(17)) to each ear (spatial.rs:531-549)
+        g_dc = 0.1 / np.sqrt(1.0 + 0.1075 ** 2) * (0.5 + 0.5 / np.sqrt(17.0))
+        n_dc = min(int(np.floor(16.0 / g_dc)), n_sources // 2)
+        n_noise = n_sources - n_dc
+        pos = np.stack([st.uniform(-30.0, 30.0) for _ in range(3)], axis=1)
+        near = np.linalg.norm(pos.astype(np.float64), axis=1) < 4.0
+        pos[near] = pos[near] + np.float32(8.0)
+        vel = np.stack([st.uniform(-10.0, 10.0) for _ in range(3)], axis=1)
+        pos[n_noise:] = np.array([0.0, 0.0, -1.0], dtype=np.float32)
+        vel[n_noise:] = 0.0
+        clip_of = (1 + (np.arange(n_sources, dtype=np.uint64) * np.uint64(2654435761) >> np.uint64(7)) % np.uint64(n_noise_clips)).astype(np.uint32)
+        clip_of[n_noise:] = 0
+    else:
+        raise ValueError(kind)
+    return {"kind": kind, "n": n_sources, "bank": bank, "clip_of": clip_of, "position": pos.astype(np.float32),
+            "velocity": vel.astype(np.float32), "radius": np.full(n_sources, 0.1, dtype=np.float32)}

@@ -160,20 +160,29 @@ TRACKED_VS_REFERENCE_TOL = 3e-6      # ODDIO_HIP_MODE_TRACKED against the refere
 def test_tracked_mode_is_within_the_north_star_tolerance_of_the_reference(big, n_src, n_frames):
     """ODDIO_HIP_MODE_TRACKED (pair_kernels.h TRACK): two passes of the FAST-mode kernel whose second one restarts every workgroup's
     running sums at the prefix of the first one's partial sums -- the reference's sequential f32 sum, rounding errors included, to
-    ~1e-6 of the peak, where the tree sum is 1-2e-5 from it.  Against the oracle's sequential sum (262 144 sources) and against
-    ORDERED mode, which is that sum bit for bit (65 536; callbacks of up to 512 frames: the tile kernel's TRACK instantiations)."""
+    ~1e-6 of the peak, where the tree sum is 1-2e-5 from it.  Against the oracle's sequential sum at every size (65 536 sources and
+    callbacks of up to 512 frames: the tile kernel's TRACK instantiations)."""
     import oddio_amd as oa
     control, scene, handles, frames = play_shard(big, 0, n_src, mode=oa.MODE_TRACKED)
     if n_src == S_BIG and n_frames == N:
         refs = big["ref32"]
     else:
-        c2, s2, h2, f2 = play_shard(big, 0, n_src, mode=oa.MODE_ORDERED)
+        # the oracle itself (round 6; before: HIP ORDERED, which is the oracle's bits only transitively)
+        from oracle import oracle_c as oc
+        from oracle.oracle_c import _fp, _vec3, lib
+        sc = big["sc"]
+        o = oc.SpatialScene()
+        o.play_frames_bulk(RATE, big["host"][:n_src], START, sc["position"][:n_src], sc["velocity"][:n_src], sc["radius"][:n_src])
         refs = []
         for cb in range(2):
             if cb == 1:
-                apply_motion(big, c2, h2, 0, n_src)
-            refs.append(s2.sample_n(INTERVAL, n_frames).copy())
-        s2.close()
+                for k, i in enumerate(big["moved"]):
+                    if i < n_src:
+                        lib().oo_scene_set_motion(o._h, int(i), _fp(_vec3(big["new_pos"][k])), _fp(_vec3(big["new_vel"][k])), 0)
+            out = np.zeros((n_frames, 2), dtype=np.float32)
+            o.sample(INTERVAL, out)
+            refs.append(out)
+        del o
     report = []
     for cb in range(2):
         if cb == 1:
@@ -410,7 +419,11 @@ def test_bench_self_launch_two_ranks_sharded():
     assert "p2p" in d["config"]["parallelism"]
     chk = d["config"]["multi_gpu_selfcheck"]              # the sharded-vs-unsharded scene check that precedes the timed region
     assert chk["reduce"] == "p2p" and chk["max_rel_err"] <= 1e-5 and chk["sources"] == 4096
+    assert chk["tracked_max_rel_err_vs_ordered"] <= 3e-6          # the sharded scene in TRACKED mode against the unsharded ORDERED one
     assert len(d["config"]["roofline_frac_by_rank"]) == 2 and min(d["config"]["roofline_frac_by_rank"]) > 0
+    # the conforming figure of a multi-GPU line: TRACKED on every rank, whole-job aggregate
+    assert d["value_conforming_mode"] == "TRACKED" and d["value_conforming"] > 0      # (at 4 096 sources per rank a TRACKED callback is an ORDERED one: no slower than FAST)
+    assert d["tracked_mode_ms_per_step"] > 0 and len(d["config"]["tracked_ms_per_step_by_rank"]) == 2
 
 
 def test_sharded_scene_two_gpus_p2p(tmp_path):
@@ -459,4 +472,6 @@ def test_bench_self_launch_two_ranks():
     # the self-check falls back to the peer-to-peer reduce, says why, and still holds the sharded scene to the unsharded one
     chk = d["config"]["multi_gpu_selfcheck"]
     assert chk["reduce"] == "p2p" and chk["rccl_error"] and chk["max_rel_err"] <= 1e-5
+    assert chk["tracked_max_rel_err_vs_ordered"] <= 3e-6
     assert len(d["config"]["roofline_frac_by_rank"]) == 2
+    assert d["value_conforming_mode"] == "TRACKED" and d["value_conforming"] > 0 and len(d["config"]["tracked_ms_per_step_by_rank"]) == 2

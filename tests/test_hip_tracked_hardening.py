@@ -1,0 +1,110 @@
+"""ODDIO_HIP_MODE_TRACKED is the mode that conforms to the north_star's 1e-5 at the headline size, and what it claims is statistical
+(a restarted f32 sum makes the reference's rounding errors while it stays in the reference's binade).  So it is held
+against the ORACLE here -- the reference's sequential f32 sum, src/spatial.rs:204,459-460 / mixer.rs:100-117 -- on more than the one
+scene of test_hip_large_scene.py: further seeds at 262 144 sources, a 65 536-source Mixer, and two full-size scenes built to hurt
+a summation order (synth.adversarial_scene: coherent sources cancelling in pairs; a running sum parked at a power of two)."""
+import numpy as np
+import pytest
+
+import scenario  # noqa: F401
+from oddio_amd import synth
+from test_hip_large_scene import CLIP, INTERVAL, N, NORTH_STAR_TOL, RATE, S_BIG, SEED, START, gpu_noise_clips
+
+pytestmark = pytest.mark.gpu
+TRACKED_WORST_CASE_TOL = 5e-6     # |gpu - reference| / max|reference|, every scene of this file
+
+
+def _oracle(bank, clip_of, sc, n_frames, callbacks=1):
+    from oracle import oracle_c as oc
+    scene = oc.SpatialScene()
+    scene.play_frames_bulk(RATE, bank, START, sc["position"], sc["velocity"], sc["radius"], clip_of=clip_of)
+    outs = []
+    for _ in range(callbacks):
+        out = np.zeros((n_frames, 2), dtype=np.float32)
+        oc.run(scene, RATE, out)
+        outs.append(out)
+    return outs
+
+
+def _hip(frames_of, sc, mode, n_frames, callbacks=1):
+    import oddio_amd as oa
+    n = len(frames_of)
+    control, scene = oa.SpatialScene(device=0, max_sources=n, max_frames=N)
+    scene.set_mode(mode)
+    control.play_frames_batch(frames_of, np.full(n, START), sc["position"], sc["velocity"], sc["radius"])
+    outs = [scene.sample_n(INTERVAL, n_frames).copy() for _ in range(callbacks)]
+    assert len(scene) == n
+    scene.close()
+    return outs
+
+
+@pytest.fixture(scope="module")
+def clips():
+    import torch
+    dev = torch.device("cuda", 0)
+    c = gpu_noise_clips(SEED, S_BIG, CLIP, dev)
+    return {"dev": c, "host": c.cpu().numpy()}
+
+
+@pytest.mark.parametrize("scene_seed", [11, 2024, 777777])
+def test_tracked_at_262144_sources_further_seeds(clips, scene_seed):
+    """Other positions / velocities over the same 262 144 noise clips: other gains, delays and resample ratios, another sum."""
+    import oddio_amd as oa
+    sc = synth.make_scene(scene_seed, S_BIG, cube=10.0)
+    ref = _oracle(clips["host"], None, sc, N, callbacks=2)
+    base = clips["dev"].data_ptr()
+    frames = [oa.Frames.from_device_ptr(RATE, base + 4 * CLIP * i, CLIP, device=0, copy=False) for i in range(S_BIG)]
+    got = _hip(frames, sc, oa.MODE_TRACKED, N, callbacks=2)
+    errs = [float(np.abs(got[cb] - ref[cb]).max() / np.abs(ref[cb]).max()) for cb in range(2)]
+    print(f"TRACKED, 262 144 sources, scene seed {scene_seed}: |gpu - reference| / max|reference| per callback:", errs)
+    assert max(errs) <= TRACKED_WORST_CASE_TOL and max(errs) <= NORTH_STAR_TOL, errs
+
+
+@pytest.mark.parametrize("kind", ["cancelling", "parked"])
+def test_tracked_on_adversarial_full_size_scenes(kind):
+    """262 144 sources whose sum is built to be hard on a summation order; FAST's tree sum on the same scene for scale."""
+    import torch
+
+    import oddio_amd as oa
+    adv = synth.adversarial_scene(kind, S_BIG)
+    ref = _oracle(adv["bank"], adv["clip_of"], adv, N, callbacks=2)
+    dev_bank = torch.from_numpy(adv["bank"]).to(torch.device("cuda", 0))
+    bank_frames = [oa.Frames.from_device_ptr(RATE, dev_bank.data_ptr() + 4 * adv["bank"].shape[1] * k, adv["bank"].shape[1], device=0, copy=False)
+                   for k in range(adv["bank"].shape[0])]
+    frames = [bank_frames[int(k)] for k in adv["clip_of"]]
+    rep = {}
+    for name, mode in (("tracked", oa.MODE_TRACKED), ("fast", oa.MODE_FAST)):
+        got = _hip(frames, adv, mode, N, callbacks=2)
+        rep[name] = [float(np.abs(got[cb] - ref[cb]).max() / np.abs(ref[cb]).max()) for cb in range(2)]
+    rep["max_abs_reference"] = [float(np.abs(r).max()) for r in ref]
+    print(f"adversarial scene '{kind}', 262 144 sources: |gpu - reference| / max|reference| per callback:", rep)
+    assert max(rep["tracked"]) <= TRACKED_WORST_CASE_TOL and max(rep["tracked"]) <= NORTH_STAR_TOL, rep
+
+
+def test_tracked_mixer_of_65536_sources_against_the_oracle(clips):
+    """A 65 536-source Mixer of MonoToStereo<FramesSignal> (mixer.rs:92-119) against the oracle's Mixer, not against HIP ORDERED:
+    sources share 4 096 clips and start at four different offsets."""
+    import oddio_amd as oa
+    from oracle import oracle_c as oc
+    S, n_clips = 65536, 4096
+    host = clips["host"]
+    base = clips["dev"].data_ptr()
+    o_frames = [oc.Frames(RATE, host[k]) for k in range(n_clips)]
+    h_frames = [oa.Frames.from_device_ptr(RATE, base + 4 * CLIP * k, CLIP, device=0, copy=False) for k in range(n_clips)]
+    om = oc.Mixer(2)
+    control, hm = oa.Mixer(max_sources=S, max_frames=N)
+    hm.set_mode(oa.MODE_TRACKED)
+    for i in range(S):
+        k, t0 = (i * 2654435761) % n_clips, 0.01 * (i % 4)
+        om.play(oc.MonoToStereo(oc.FramesSignal(o_frames[k], t0)))
+        control.play(oa.MonoToStereo(oa.FramesSignal(h_frames[k], t0)))
+    errs = []
+    for cb in range(3):
+        ref = np.zeros((N, 2), dtype=np.float32)
+        oc.run(om, RATE, ref)
+        got = hm.sample_n(INTERVAL, N)
+        errs.append(float(np.abs(got - ref).max() / np.abs(ref).max()))
+    print("TRACKED Mixer, 65 536 sources: |gpu - reference| / max|reference| per callback:", errs)
+    assert max(errs) <= TRACKED_WORST_CASE_TOL, errs
+    assert len(hm) == len(om) == S
+    hm.close()
