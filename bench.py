@@ -169,11 +169,38 @@ def parity_check(oc, bank, seed: int, start: float, device: int, n_src: int) -> 
         del control, hscene
     scale = float(np.abs(ref).max())
     rel = lambda a, b: float(np.abs(a.astype(np.float64) - b.astype(np.float64)).max()) / scale   # noqa: E731
+    # TRACKED is a statistical statement, so it is also measured on the two scenes built against it
+    # (synth.adversarial_scene: coherent sources cancelling in pairs; a running sum parked at a power of two), same source count
+    adversarial = {}
+    for kind in ("cancelling", "parked"):
+        adv = synth.adversarial_scene(kind, n_src)
+        o = oc.SpatialScene()
+        a_start = 0.06                   # (inside the bank's 8 192-sample clips, behind the propagation delay)
+        o.play_frames_bulk(RATE, adv["bank"], a_start, adv["position"], adv["velocity"], adv["radius"], clip_of=adv["clip_of"])
+        aref = np.zeros((N_FRAMES, 2), dtype=np.float32)
+        oc.run(o, RATE, aref)
+        del o
+        abank = torch.from_numpy(adv["bank"]).to(torch.device("cuda", device))
+        al = adv["bank"].shape[1]
+        aframes = [oa.Frames.from_device_ptr(RATE, abank.data_ptr() + 4 * al * i, al, device=device, copy=False) for i in range(adv["bank"].shape[0])]
+        res = {"max_abs_reference": float(np.abs(aref).max())}
+        for mode, name in ((oa.MODE_TRACKED, "tracked"), (oa.MODE_FAST, "fast")):
+            control, hscene = oa.SpatialScene(device=device, max_sources=n_src, max_frames=N_FRAMES)
+            hscene.set_mode(mode)
+            control.play_frames_batch([aframes[int(k)] for k in adv["clip_of"]], np.full(n_src, a_start), adv["position"], adv["velocity"], adv["radius"])
+            res[f"{name}_rel_err_vs_reference"] = float(np.abs(hscene.sample_n(interval, N_FRAMES) - aref).max()) / res["max_abs_reference"]
+            del control, hscene
+        adversarial[kind] = res
+        del aframes, abank
+    tracked_worst = max([rel(got["tracked"], ref)] + [a["tracked_rel_err_vs_reference"] for a in adversarial.values()])
     return {
         "sources": n_src, "callbacks": 1, "max_abs_reference": scale,
         "ordered_bit_exact": bool(np.array_equal(got["ordered"], ref)),
         "fast_rel_err_vs_reference": rel(got["fast"], ref),
         "tracked_rel_err_vs_reference": rel(got["tracked"], ref),
+        "tracked_worst_case_rel_err_vs_reference": tracked_worst,      # over this scene and the two adversarial ones below
+        "tracked_conforms": bool(tracked_worst <= 1e-5),
+        "adversarial_scenes": adversarial,
         "fast_rel_err_vs_f64": rel(got["fast"], ref64),
         "reference_rel_err_vs_f64": rel(ref, ref64),
         "tolerance": 1e-5,

@@ -169,7 +169,8 @@ int oddio_hip_scene_play_frames_batch(oddio_hip_scene* scene, size_t n,
  * `Ring` (src/ring.rs) of ceil((max_distance / 343 + buffer_duration) * rate) + 1 samples per source
  * in HBM, allocated here (control thread) and sampled at `rate`. */
 enum { ODDIO_HIP_LEAF_FRAMES = 0, ODDIO_HIP_LEAF_SINE = 1, ODDIO_HIP_LEAF_CONSTANT = 2,
-       ODDIO_HIP_LEAF_CYCLE = 3 /* Cycle::new(frames), src/cycle.rs (buffered sources and Mixer chains) */ };
+       ODDIO_HIP_LEAF_CYCLE = 3 /* Cycle::new(frames), src/cycle.rs (buffered sources and Mixer chains) */,
+       ODDIO_HIP_LEAF_DOWNMIX = 4 /* Downmix::new(FramesSignal(stereo frames)), src/downmix.rs:18-47: oddio_hip_scene_play_filtered only */ };
 enum { ODDIO_HIP_FILTER_FIXED_GAIN = 1, ODDIO_HIP_FILTER_GAIN = 2, ODDIO_HIP_FILTER_SPEED = 3,
        /* per-source soft clips, `Reinhard<T>` (src/reinhard.rs:22-50) and `Tanh<T>` (src/tanh.rs:16-44): Signal + Seek
         * wrappers over any signal, param unused.  In buffered and Mixer chains anywhere among the filters; in
@@ -177,11 +178,14 @@ enum { ODDIO_HIP_FILTER_FIXED_GAIN = 1, ODDIO_HIP_FILTER_GAIN = 2, ODDIO_HIP_FIL
        ODDIO_HIP_FILTER_REINHARD = 4, ODDIO_HIP_FILTER_TANH = 5 };
 typedef struct oddio_hip_filter { int kind; float param; } oddio_hip_filter;
 /* play(filters(leaf), options) for the filters that keep a signal `Seek` -- FixedGain(db) (src/gain.rs:9-51,
- * :39-51 Seek), Reinhard (src/reinhard.rs:42-50) and Tanh (src/tanh.rs:36-44) -- innermost first: at most one
- * FixedGain and one soft clip, in either order (`Reinhard::new(FixedGain::new(x, db))` or
- * `FixedGain::new(Reinhard::new(x), db)`; ODDIO_HIP_EINVAL for other chains: play_buffered takes those).  The clip
- * is applied to every sample of the source before the distance gain and the sum (src/spatial.rs:457-462 samples
- * the wrapped signal).  leaf_kind: ODDIO_HIP_LEAF_FRAMES (mono clip) / _SINE / _CONSTANT / _CYCLE, arguments as in
+ * :39-51 Seek), Reinhard (src/reinhard.rs:42-50) and Tanh (src/tanh.rs:36-44), each `impl<T: Seek> Seek` -- innermost
+ * first, up to 4 of them in any order and multiplicity: `Reinhard::new(FixedGain::new(x, db))`,
+ * `Reinhard::new(Tanh::new(x))`, `FixedGain::new(FixedGain::new(x, a), b)` (two roundings, like the reference),
+ * `Reinhard::new(Downmix::new(x))`.  Every wrapper is applied to every sample of the source before the distance gain
+ * and the sum (src/spatial.rs:457-462 samples the wrapped signal).  At most one FixedGain and one soft clip: rendered
+ * inline by the staged kernels; longer nests: the exact per-lane path (correct and ORDERED-bit-exact, several times
+ * slower per source).  ODDIO_HIP_EINVAL for Gain / Speed (not Seek: oddio_hip_scene_play_buffered).
+ * leaf_kind: ODDIO_HIP_LEAF_FRAMES (mono clip) / _SINE / _CONSTANT / _CYCLE / _DOWNMIX (stereo clip), arguments as in
  * the play_* calls above. */
 int oddio_hip_scene_play_filtered(oddio_hip_scene* scene, int leaf_kind, oddio_hip_frames* frames,
                                   double start_seconds, float phase, float frequency_hz_or_value,

@@ -283,6 +283,9 @@ FILTER_FIXED_GAIN, FILTER_GAIN, FILTER_SPEED, FILTER_REINHARD, FILTER_TANH = 1, 
 
 def _leaf_args(leaf, keep):
     """-> (leaf_kind, frames handle, start_seconds, phase, frequency_hz_or_value)"""
+    if isinstance(leaf, Downmix):            # (oddio_hip_scene_play_filtered only)
+        keep.append(leaf.inner.frames)
+        return (4, leaf.inner.frames._h, leaf.inner.start_seconds, 0.0, 0.0)
     if isinstance(leaf, FramesSignal):
         keep.append(leaf.frames)
         return (0, leaf.frames._h, leaf.start_seconds, 0.0, 0.0)
@@ -345,10 +348,10 @@ def _is_postfx(signal):
 
 
 def _unwrap(signal):
-    """-> (leaf, fixed_gain_db or NaN, [(filter kind, param)] innermost first when the chain has a per-source soft clip, else None)
+    """-> (leaf, fixed_gain_db or NaN, [(filter kind, param)] innermost first when the nest needs play_filtered, else None)
 
-    A Seek chain: at most one FixedGain and one Reinhard / Tanh, in either order (src/gain.rs:39-51, src/reinhard.rs:42-50,
-    src/tanh.rs:36-44 are the Seek impls of the wrappers)."""
+    A Seek chain: FixedGain / Reinhard / Tanh in any order and multiplicity, up to 4 (src/gain.rs:39-51, src/reinhard.rs:42-50,
+    src/tanh.rs:36-44 are `impl<T: Seek> Seek` for the wrappers)."""
     db = math.nan
     chain = []
     while isinstance(signal, (FixedGain, Reinhard)) and not _is_postfx(signal):
@@ -359,9 +362,10 @@ def _unwrap(signal):
         signal = signal.inner
     chain = chain[::-1]
     kinds = [k for k, _ in chain]
-    if isinstance(signal, (Gain, Speed)) or kinds.count(FILTER_FIXED_GAIN) > 1 or len(kinds) - kinds.count(FILTER_FIXED_GAIN) > 1:
-        raise TypeError("Gain / Speed are not Seek (src/gain.rs:53-57, src/speed.rs): use play_buffered; "
-                        "chains with more than one FixedGain or soft clip need play_buffered too")
+    if isinstance(signal, (Gain, Speed)):
+        raise TypeError("Gain / Speed are not Seek (src/gain.rs:53-57, src/speed.rs): use play_buffered")
+    if len(chain) > 4:
+        raise TypeError("at most 4 wrappers around a played source on the device path")
     if not isinstance(signal, (FramesSignal, Sine, Constant, Cycle, Downmix)):
         raise TypeError(f"{type(signal).__name__} is not implemented on the device path "
                         "(supported: FramesSignal, Downmix of a stereo FramesSignal, Cycle, Sine, Constant; FixedGain, Reinhard, Tanh around them)")
@@ -370,8 +374,6 @@ def _unwrap(signal):
             db = chain[0][1]
         return signal, db, None
     # (FixedGain around a Constant goes through play_filtered as well: oddio_hip_scene_play_constant has no gain argument)
-    if isinstance(signal, Downmix):
-        raise TypeError("a soft clip around a Downmix needs play_buffered")
     return signal, db, chain
 
 

@@ -40,7 +40,24 @@ struct alignas(16) SrcStatic {
 static_assert(sizeof(SrcStatic) == 32, "SrcStatic layout");
 // `Reinhard<T>` / `Tanh<T>` wrapped around a Seek-set source, with the source's optional FixedGain inside the clip
 // (Reinhard(FixedGain(x)), the default) or outside it (FX_CLIP_FIRST: FixedGain(Reinhard(x)))
-enum : uint16_t { FX_REINHARD = 1, FX_TANH = 2, FX_CLIP_FIRST = 4 };
+enum : uint16_t { FX_REINHARD = 1, FX_TANH = 2, FX_CLIP_FIRST = 4, FX_CHAIN = 8 };
+// FX_CHAIN (round 6): any other nest of the Seek wrappers -- FixedGain (gain.rs:39-51), Reinhard (reinhard.rs:42-50), Tanh
+// (tanh.rs:36-44) are `impl<T: Seek> Seek`, so Reinhard(Tanh(x)), FixedGain(FixedGain(x)), Reinhard(FixedGain(Tanh(FixedGain(x)))) are
+// legal play()s.  Up to 4 wrappers, innermost first, each applied to every sample with its own rounding; the chain lives in a table
+// indexed by the source's handle id (StaticHeader::fx_chains, below), and SrcStatic::fixed_gain holds that id as raw bits.  Such sources are
+// rendered by the exact per-lane paths (mix_source_rare_body, cycle_render), never by the staged loops.
+enum : uint8_t { FXOP_FIXED_GAIN = 1, FXOP_REINHARD = 2, FXOP_TANH = 3 };
+struct alignas(8) FxChain {   // (8 + 16 bytes: the header and the gains are one load each)
+    uint32_t n;             // wrappers (1..4)
+    uint8_t op[4];          // FXOP_*, innermost first
+    float gain[4];          // FXOP_FIXED_GAIN: the linear factor (gain.rs:20)
+};
+static_assert(sizeof(FxChain) == 24, "FxChain layout");
+// The chain table is reached from the SrcStatic table itself: the scene allocates one 32-byte header IN FRONT of slot 0 (st[-1]) that
+// holds the table's pointer.  The kernels that can meet an FX_CHAIN source have the SrcStatic pointer anyway; a kernel argument of its
+// own stays live in two SGPRs through the mix kernels' hot loops, which run at the SGPR limit (measured: +1.4 % on spatial_mix_pair).
+struct alignas(16) StaticHeader { const FxChain* fx_chains; uint64_t pad[3]; };
+static_assert(sizeof(StaticHeader) == 32, "one SrcStatic slot");
 
 struct alignas(16) SrcDyn {
     double t;               // FramesSignal::t seconds (frames.rs:145)

@@ -138,7 +138,32 @@ __device__ __forceinline__ long long f64_as_isize(double x) {
 // A per-source soft clip around the signal (SrcStatic::fx): Reinhard<T>::sample `x / (1 + |x|)` (reinhard.rs:28-35) or
 // Tanh<T>::sample `tanh(x)` (tanh.rs:22-29) applied to every sample the inner signal produced, with the source's FixedGain
 // (gain.rs:32-37) inside the clip or, FX_CLIP_FIRST, outside it.  (x * 1.0 == x: a source without FixedGain carries 1.0.)
-__device__ __forceinline__ float apply_fx(float v, float fixed_gain, int fx) {
+// (registers only: the four ops packed in one word, the gains in four scalars, every index a literal -- a struct indexed by a loop
+// counter would live in scratch, and the mix kernels that call the rare paths have none)
+struct FxRegs { uint32_t n, ops; float g0, g1, g2, g3; };
+__device__ __forceinline__ FxRegs load_fx_chain(const SrcStatic& s, const SrcStatic* __restrict__ st) {
+    FxRegs r = {0u, 0u, 1.0f, 1.0f, 1.0f, 1.0f};
+    if (s.fx & FX_CHAIN) {
+        const FxChain* c = reinterpret_cast<const StaticHeader*>(st - 1)->fx_chains + __float_as_uint(s.fixed_gain);   // (device_types.h: the header before slot 0)
+        const uint2 h = *reinterpret_cast<const uint2*>(c);                 // {n, op[0..3]}
+        const float4 g = *reinterpret_cast<const float4*>(reinterpret_cast<const unsigned char*>(c) + 8);
+        r.n = h.x; r.ops = h.y; r.g0 = g.x; r.g1 = g.y; r.g2 = g.z; r.g3 = g.w;
+    }
+    return r;
+}
+__device__ __forceinline__ float fx_op(float v, uint32_t op, float g) {
+    if (op == FXOP_FIXED_GAIN) return v * g;                                // gain.rs:32-37
+    if (op == FXOP_REINHARD) return v / (1.0f + fabsf(v));                  // reinhard.rs:32
+    return tanhf(v);                                                        // tanh.rs:26
+}
+__device__ __forceinline__ float apply_fx(float v, float fixed_gain, int fx, const FxRegs& ch) {
+    if (fx & FX_CHAIN) {     // a general nest of Seek wrappers, innermost first (device_types.h)
+        if (ch.n > 0u) v = fx_op(v, ch.ops & 255u, ch.g0);
+        if (ch.n > 1u) v = fx_op(v, (ch.ops >> 8) & 255u, ch.g1);
+        if (ch.n > 2u) v = fx_op(v, (ch.ops >> 16) & 255u, ch.g2);
+        if (ch.n > 3u) v = fx_op(v, ch.ops >> 24, ch.g3);
+        return v;
+    }
     if (!(fx & FX_CLIP_FIRST)) v = v * fixed_gain;
     if (fx & FX_REINHARD) v = v / (1.0f + fabsf(v));
     else if (fx & FX_TANH) v = tanhf(v);
@@ -595,6 +620,7 @@ __global__ __launch_bounds__(64 * CYCLE_WAVES) void cycle_render(SceneParams P, 
     const uint32_t i = entry & 0x7fffffffu;
     const uint32_t first_pass = (entry >> 31) ? 0u : (uint32_t)(REC_TILES * TILE_FRAMES);    // (pass 0 = the record tiles: rows only if cycle_scan asked for them)
     const SrcStatic s = st[i];
+    const FxRegs fxch = load_fx_chain(s, st);
     const uint32_t len = s.clip_len;
     const uint32_t n = P.n_frames;
     const uint32_t rowi = __float_as_uint(s.freq_or_value);
@@ -676,7 +702,7 @@ __global__ __launch_bounds__(64 * CYCLE_WAVES) void cycle_render(SceneParams P, 
 #pragma unroll
                 for (int k = 0; k < 16; ++k) {
                     float vv = a[k] + fract[k] * (b[k] - a[k]);                   // frame::lerp
-                    vv = apply_fx(vv, s.fixed_gain, s.fx);                        // FixedGain, gain.rs:32-37 (and the source's soft clip)
+                    vv = apply_fx(vv, s.fixed_gain, s.fx, fxch);                  // FixedGain, gain.rs:32-37 (and the source's soft clip)
                     o[k] = vv * (ep.g0 + (float)(f0 + (uint32_t)k) * ep.dg);      // spatial.rs:459-460
                 }
                 if (cnt == 16u) {
@@ -832,7 +858,7 @@ __device__ __forceinline__ TileRec make_tile_rec(const SceneParams& P, const Src
     if (s.kind != KIND_FRAMES && s.kind != KIND_DOWNMIX) { r.info = PATH_GENERIC; return r; }
     // a per-source soft clip: Reinhard is rendered inline by the staged loops of the kernels that compile it in (P.dmx: the
     // Downmix-capable instantiations; info bits 28-30 = SrcStatic::fx), Tanh only by the fused (FAST-mode) ones, else by the exact per-lane path
-    if (s.fx && (!P.dmx || ((s.fx & FX_TANH) && !P.fused))) { r.info = PATH_GENERIC; return r; }
+    if (s.fx && (!P.dmx || ((s.fx & FX_TANH) && !P.fused) || (s.fx & FX_CHAIN))) { r.info = PATH_GENERIC; return r; }   // (FX_CHAIN: always the exact per-lane path)
     // Downmix<FramesSignal<[f32;2]>> (downmix.rs:24-29 over frames.rs:176-201): the same cursor, the window holds interleaved
     // stereo frames -- `mul` floats per frame; always variant 2 of spatial_mix (sub-windows when the window is larger than the stage)
     const bool stereo = s.kind == KIND_DOWNMIX;
@@ -961,7 +987,7 @@ __device__ __forceinline__ PairRec make_pair_rec(const SceneParams& P, const Src
     if (s.kind == KIND_CONSTANT) { r.info = PATH_CONST; return r; }
     if (s.kind == KIND_CYCLE) { r.info = PATH_ROW; return r; }
     if (s.kind != KIND_FRAMES) { r.info = PATH_GENERIC; return r; }     // (Downmix: the exact per-lane path)
-    if ((s.fx & FX_TANH) && !P.fused) { r.info = PATH_GENERIC; return r; }   // (the soft clips are rendered inline: info bits 28-30 = SrcStatic::fx; Tanh by the fused kernel only)
+    if (((s.fx & FX_TANH) && !P.fused) || (s.fx & FX_CHAIN)) { r.info = PATH_GENERIC; return r; }   // (the soft clips are rendered inline: info bits 28-30 = SrcStatic::fx; Tanh by the fused kernel only)
     int lo = 0x7fffffff, hi = (int)0x80000000, generic = 0, fl = 0;
     int wbase[2][PAIR_CHUNKS];
     const double rate = (double)s.clip_rate;
@@ -1401,6 +1427,7 @@ __device__ __forceinline__ void mix_source_rare_body(float* acc_lds, int lane, u
                                                      const float* cycle_rows, uint32_t cycle_plane, const int eB) {
     const int b = lane & 15;
     const SrcStatic s = st[src];
+    const FxRegs fxch = load_fx_chain(s, st);
     const EarParams ep = ear[2 * src + eB];
     const float fbase = (float)frame0;
     const float g0 = ep.g0, dg = ep.dg, dt = ep.dt, fixed_gain = s.fixed_gain;
@@ -1434,7 +1461,7 @@ __device__ __forceinline__ void mix_source_rare_body(float* acc_lds, int lane, u
             } else {
                 v = s.freq_or_value;
             }
-            v = apply_fx(v, fixed_gain, s.fx);
+            v = apply_fx(v, fixed_gain, s.fx, fxch);
             const float p = v * (g0 + (fbase + (float)i) * dg);
             if (frame0 + (uint32_t)i < n_frames) acc_lds[i * PARK_STRIDE + lane] = acc_lds[i * PARK_STRIDE + lane] + p;
         }
@@ -1500,7 +1527,7 @@ __device__ __forceinline__ void mix_source_rare_body(float* acc_lds, int lane, u
         for (int k = 0; k < GEN_BATCH; ++k) {
             const int i = i0 + k;
             const uint32_t f = chunk0 + 16u * (uint32_t)i + (uint32_t)b;
-            const float vg = apply_fx(v[k], fixed_gain, s.fx);
+            const float vg = apply_fx(v[k], fixed_gain, s.fx, fxch);
             const float p = vg * (g0 + (float)f * dg);
             float* slot = acc_lds + b * PARK_STRIDE + ((lane & ~15) | i);
             if (f < n_frames) *slot = *slot + p;
