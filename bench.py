@@ -836,6 +836,16 @@ def bench_buffered(args, device: int, shared=None) -> dict:
 
 
 # ---------------------------------------------------------------------------------------------------
+def _smi_clocks() -> str | None:
+    """One `rocm-smi` reading (shader / memory clocks, package power, performance level); None when the tool is not there."""
+    try:
+        r = subprocess.run(["rocm-smi", "--showclocks", "--showpower", "--showperflevel"], capture_output=True, text=True, timeout=20)
+        keep = [" ".join(ln.split()) for ln in r.stdout.splitlines() if any(k in ln for k in ("sclk", "mclk", "Power", "Performance Level"))]
+        return " | ".join(keep) if keep else None
+    except Exception:      # noqa: BLE001
+        return None
+
+
 def _free_port() -> int:
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -892,6 +902,9 @@ def main():
     ap.add_argument("--workload", choices=["seek", "buffered"], default="seek",
                     help="'seek' (default): BASELINE's FramesSignal sources played with play(); 'buffered': the same number of "
                          "Gain<Speed<FramesSignal>> sources played with play_buffered (single GPU)")
+    ap.add_argument("--sustained", type=int, default=4096,
+                    help="callbacks of the nested `sustained` leg (single GPU): the timed region's workload held for this many callbacks "
+                         "(~0.25 ms each), with rocm-smi's clocks and power read while it runs; 0 skips it")
     ap.add_argument("--no-buffered", action="store_true", help="skip the nested buffered_path and mixer_path objects of the default (seek) workload")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-worker", default=None, help=argparse.SUPPRESS)
@@ -1028,6 +1041,48 @@ def main():
     elapsed = time.perf_counter() - t0
     hist = scene.kernel_ms_history(min(n_samples, 512))
     assert len(hist) == min(n_samples, 512), (len(hist), n_samples)
+    # ---- `sustained`: the same workload for 4 096 callbacks (~1 s of GPU time: 200 x the timed region), clocks read while it runs ----
+    sustained = None
+    if world == 1 and args.sustained > 0:
+        scene.set_profiling(False)
+        dev_t = torch.device("cuda", device)
+        d_ids = torch.from_numpy(np.ascontiguousarray(g["ids"], dtype=np.uint32).view(np.int32)).to(dev_t)
+        d_pos = torch.from_numpy(np.ascontiguousarray(g["spec"]["position"], dtype=np.float32)).to(dev_t)
+        d_vel = torch.from_numpy(np.ascontiguousarray(g["spec"]["velocity"], dtype=np.float32)).to(dev_t)
+        hold = 32                      # every source back to BASELINE's start every 32 callbacks, by ONE message (device arrays): the host never falls behind
+        smi_before = _smi_clocks()
+        # one reading while the callbacks run: a thread that waits a third of the expected duration (the launch calls release the GIL)
+        import threading
+        during = {}
+        expect_s = args.sustained * (elapsed / args.steps)
+
+        def _read_during():
+            time.sleep(0.3 * expect_s)
+            during["t0"] = time.perf_counter()
+            during["smi"] = _smi_clocks()
+            during["t1"] = time.perf_counter()
+        th = threading.Thread(target=_read_during)
+        sync_all()
+        ts0 = time.perf_counter()
+        th.start()
+        for k in range(args.sustained):
+            if step_no and step_no % span == 0:
+                scene.seek_all(rewind_seconds)              # (the clips last `span` callbacks: as in one_step)
+            scene.sample_device(interval, out.data_ptr(), N_FRAMES)
+            step_no += 1
+            if k % hold == hold - 1:
+                control.set_motion_device(len(g["ids"]), d_ids.data_ptr(), d_pos.data_ptr(), d_vel.data_ptr(), True)
+        t_enq = time.perf_counter() - ts0
+        sync_all()
+        t_sus = time.perf_counter() - ts0
+        th.join()
+        # (kept only if the reading began and ended inside the run)
+        smi_during = during.get("smi") if during.get("t1", 1e30) - ts0 <= t_sus else None
+        sustained = {"callbacks": args.sustained, "ms_per_step": t_sus / args.sustained * 1e3, "value": float(S) * N_FRAMES * args.sustained / t_sus,
+                     "frac_callback": algorithmic_bytes(len(g["ids"]), N_FRAMES) / (t_sus / args.sustained) / 1e9 / HBM_PEAK_GBPS,
+                     "host_enqueue_s": t_enq, "gpu_s": t_sus, "rocm_smi_during_window_s": ([during["t0"] - ts0, during["t1"] - ts0] if "t1" in during else None), "rocm_smi_before": smi_before, "rocm_smi_during": smi_during,
+                     "workload": f"the timed region's, every source's Motion put back to its start every {hold} callbacks (oddio_hip_scene_set_motion_device), clips rewound every {span}"}
+        scene.set_profiling(2)
     # the other stages of a callback (walk, reduce): a few untimed callbacks with events around every stage
     # (four per callback cost 3-6 us of command-processor time, tools/event_overhead.py; not inside `value`)
     scene.set_profiling(1)
@@ -1166,7 +1221,7 @@ def main():
         mix_ms = float(hist[:, 1].mean())
         b_alg = algorithmic_bytes(len(g["ids"]), N_FRAMES)
         achieved = b_alg / (mix_ms * 1e-3) / 1e9
-        traffic, traffic_source, ordered_traffic = None, None, None
+        traffic, traffic_source, ordered_traffic, traffic_stale = None, None, None, None
         pmc = os.path.join(ROOT, "profiles", "pmc_latest.json")
         if os.path.exists(pmc):
             try:
@@ -1175,6 +1230,9 @@ def main():
                     traffic = j.get("hbm_bytes_per_launch")
                     traffic_source = "profiles/pmc_latest.json (rocprofv3 --pmc passes of this kernel, not measured in this run)"
                     ordered_traffic = j.get("ordered_hbm_bytes_per_callback")
+                    # the counters were collected on the kernels whose source hash the file carries (tools/make_pmc_json.py)
+                    from oddio_amd import _lib as _l
+                    traffic_stale = j.get("mix_kernel_source_hash") != _l.mix_kernel_source_hash()
             except Exception:
                 traffic = None
         if world == 1:
@@ -1228,11 +1286,13 @@ def main():
             "host_output_ms_per_step": host_ms,
             "ordered_mode_ms_per_step": ordered_ms,             # bit-exact (reference sum order) mode, same scene: callbacks enqueued back to back
             "ordered_mode_latency_ms": ordered_latency_ms,      # ... and one callback at a time
+            "sustained": sustained,                             # the same workload held for thousands of callbacks (see --sustained)
             "precondition_ms": args.precondition_ms,
             "precondition_hold": args.precondition_hold,
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
                 "traffic": traffic, "traffic_source": traffic_source,
+                "traffic_stale": traffic_stale,      # true: the mix kernels' sources have changed since the PMC passes (re-run tools/profile_pmc.sh)
                 # (callbacks of 513..1024 frames over >= 32 768 sources run spatial_mix_pair -- csrc/pair_kernels.h, ODDIO_HIP_PAIR=0 keeps the
                 # 512-frame-tile kernel spatial_mix; smaller scenes always run spatial_mix)
                 "kernel": ("spatial_mix_pair" if (os.environ.get("ODDIO_HIP_PAIR", "1") != "0" and len(g["ids"]) >= 32768) else "spatial_mix"),

@@ -251,8 +251,10 @@ impl HipSpatialSceneControl {
         self.spatial(id)
     }
     /// play(Reinhard::new(FramesSignal::new(frames, start_seconds)), options) and the other Seek chains around a clip: `filters`
-    /// innermost first, at most one FixedGain and one soft clip (`RawFilter { kind: 4 /* Reinhard */ | 5 /* Tanh */, .. }`) in
-    /// either order (src/reinhard.rs:42-50, src/tanh.rs:36-44, src/gain.rs:39-51 are the Seek impls that make such a signal playable).
+    /// innermost first, up to four of FixedGain and the soft clips (`RawFilter { kind: 4 /* Reinhard */ | 5 /* Tanh */, .. }`) in any
+    /// order and multiplicity -- `Reinhard::new(Tanh::new(x))`, `FixedGain::new(FixedGain::new(x, a), b)` -- (src/reinhard.rs:42-50,
+    /// src/tanh.rs:36-44, src/gain.rs:39-51 are the `impl<T: Seek> Seek` that make such a signal playable).  One FixedGain and one
+    /// clip at most: rendered inline by the staged kernels; longer nests: the exact per-lane path (include/oddio_hip.h).
     pub fn play_frames_filtered(&mut self, frames: &Arc<HipFrames>, start_seconds: f64, filters: &[RawFilter], options: SpatialOptions) -> HipSpatial {
         let (p, v) = pv(&options);
         let mut id = 0u32;

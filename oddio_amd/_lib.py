@@ -25,6 +25,17 @@ def build(force: bool = False) -> str:
     return SO_PATH
 
 
+def mix_kernel_source_hash() -> str:
+    """sha256 (first 16 hex digits) of the sources the scene's mix kernels are compiled from -- what profiles/pmc_latest.json is
+    stamped with by tools/make_pmc_json.py, so that bench.py can tell when the counters it quotes were measured on other kernels."""
+    import hashlib
+    h = hashlib.sha256()
+    for name in ("device_types.h", "kernels.h", "pair_kernels.h"):
+        with open(os.path.join(_HERE, "csrc", name), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
 DEBUG_SO_PATH = os.path.join(_HERE, "libodd_hip_debug.so")
 
 

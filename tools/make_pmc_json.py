@@ -12,6 +12,10 @@ def _targs(k):     # spatial_mix<FULL, STORE, FUSED, RING, DMX> -> its template 
     return [a.strip() for a in k[k.index("<") + 1:k.rindex(">")].split(",")] if "<" in k else []
 
 
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from oddio_amd import _lib  # noqa: E402  (the source hash only; nothing is loaded)
+
 summary, sources, out = sys.argv[1], int(sys.argv[2]), sys.argv[3]
 d = json.load(open(summary))
 if len(sys.argv) > 4 and sys.argv[4] == "buffered":
@@ -53,6 +57,8 @@ res = {
     "hbm_bytes_per_launch": (2.0 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0,
     "correction": "read side x2 (gfx950 FETCH_SIZE counts 64 B per 128 B request on wide coalesced loads)",
     "counters": {n: v for n, v in c.items() if not n.startswith("_")},
+    # the kernels these counters were measured on (bench.py prints roofline.traffic_stale when the tree's differ)
+    "mix_kernel_source_hash": _lib.mix_kernel_source_hash(),
 }
 # ORDERED mode: the row render (spatial_mix<.., true, ..>) + ordered_sum of one callback
 rows = [k for k in d if k.startswith("spatial_mix<true, true") or k.startswith("spatial_mix<false, true")]
