@@ -110,19 +110,67 @@ __device__ __forceinline__ void pair_repack_padded(unsigned char* win_bytes, int
 // rounding error of a step does not depend on the sum's lower bits -- so the restarted sums make the reference's rounding errors, and
 // the workgroups' differences add up to the reference's sequential sum to ~1e-6 of the peak (the plain tree sum: 1-2e-5 at 262 144
 // sources, which is the reference's own distance from the exact sum).
-template <bool FULL, bool FUSED, bool TRACK = false>
+// WALK (round 6): the set walk of the callback -- spatial_prepass's work for this workgroup's own sources (walk_set, both EarStates, the
+// clock bookkeeping, the PairRecs: prepass_source + make_pair_rec, one source per lane, the two waves on alternate blocks of 64) -- runs
+// at the top of the kernel instead of in a launch of its own: 19 us of launch + a 96-byte record round trip per source through HBM
+// become ~8 us inside the kernel (the records are read back through L2 by the workgroup that wrote them).  `ear_in` / `recs_in` /
+// `n_sources_ptr` are then unused: the walk's own tables (PairWalk) are read back.  For scenes without Cycle rows (their scan sits
+// between the walk and the mix) and callbacks the pair kernel renders; the TRACK second pass reads what the first pass's walk left.
+struct PairWalk {
+    SrcDyn* dyn; SrcPending* pend; EarParams* ear; PairRec* recs; uint32_t* stopped_hdr; const uint32_t* d_len; uint32_t* len_snap;
+    uint32_t stopped_cap; int check_pending;
+};
+static_assert(64 * (sizeof(PairRec) / 4 + 1) * 4 <= PAIR_LDS_STREAM && 64 * (sizeof(PairRec) / 4 + 1) * 4 <= 2 * PAIR_STREAM_BYTES,
+              "the walk's transposition stage fits the window buffers (wave 0) and the stream blocks (wave 1)");
+
+template <bool FULL, bool FUSED, bool TRACK = false, bool WALK = false>
 __global__ __launch_bounds__(128, MIX_WAVES_PER_SIMD) void spatial_mix_pair(SceneParams P, const SrcStatic* __restrict__ st,
-                                                                            const EarParams* __restrict__ ear, const PairRec* __restrict__ recs,
+                                                                            const EarParams* __restrict__ ear_in, const PairRec* __restrict__ recs_in,
                                                                             float* __restrict__ partials, const float* __restrict__ init,
                                                                             uint32_t groups_per_wg, uint32_t n_groups,
-                                                                            const uint32_t* __restrict__ n_sources_ptr) {
+                                                                            const uint32_t* __restrict__ n_sources_ptr, PairWalk W) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[PAIR_LDS_TOTAL];
-    const uint32_t n_sources = *n_sources_ptr;
+    static_assert(!WALK || !TRACK, "the second pass of a tracked callback reads the records of the first pass's walk");
+    const uint32_t n_sources = WALK ? W.d_len[0] : *n_sources_ptr;
+    // (WALK: the tables this workgroup has just written are read through the pointers they were written through)
+    const EarParams* ear = WALK ? W.ear : ear_in;
+    const PairRec* recs = WALK ? W.recs : recs_in;
     const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));       // this wave's ear
     const uint32_t lds_base = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uintptr_t)smem);
     const int lane = threadIdx.x & 63;
     const int lane16 = 16 * lane;
     const uint32_t n_frames = P.n_frames;
+    // n_groups = gridDim.x * groups_per_wg + rem: the first `rem` workgroups walk one group more
+    const uint32_t rem = n_groups - gridDim.x * groups_per_wg;
+    const uint32_t g_lo = blockIdx.x * groups_per_wg + (blockIdx.x < rem ? blockIdx.x : rem);
+    const uint32_t g_hi = g_lo + groups_per_wg + (blockIdx.x < rem ? 1u : 0u);
+
+    if (WALK) {
+        if (blockIdx.x == 0 && threadIdx.x == 0) *W.len_snap = n_sources;      // (the reduce's set compaction and a TRACK second pass read it)
+        uint32_t* stage = reinterpret_cast<uint32_t*>(smem + (wv ? PAIR_LDS_STREAM : 0));
+        const uint32_t s_end = g_hi * MIX_GROUP < n_sources ? g_hi * MIX_GROUP : n_sources;
+        int lw = threadIdx.x & 63;
+        asm volatile("" : "+v"(lw));
+#pragma unroll 1
+        for (uint32_t first = g_lo * MIX_GROUP + 64u * (uint32_t)wv; first < s_end; first += 128u) {
+            const uint32_t n_valid = (s_end - first) < 64u ? (s_end - first) : 64u;
+            const uint32_t i = first + (uint32_t)lw;
+            SrcDyn d = {};
+            SrcStatic s = {};
+            wave_aos_load2(d, W.dyn, s, st, first, n_valid, lw, stage);
+            EarPair ep = {};
+            ep.e[0].flags = EAR_SKIP; ep.e[1].flags = EAR_SKIP;
+            if (i < s_end) prepass_source(P, i, d, s, W.pend, ep.e[0], ep.e[1], W.stopped_hdr, W.stopped_cap, W.check_pending);
+            const PairRec r = make_pair_rec(P, s, ep.e[0], ep.e[1]);
+            const uint32_t path = r.info & 7u;
+            const bool needs_ear = path != PATH_LDS && path != PATH_SKIP;      // (the out-of-line paths read the EarParams)
+            wave_aos_store(r, W.recs, first, n_valid, lw, stage);
+            if (__any(needs_ear)) wave_aos_store(ep, reinterpret_cast<EarPair*>(W.ear), first, n_valid, lw, stage);
+            wave_aos_store(d, W.dyn, first, n_valid, lw, stage);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's records have left ...
+        pair_barrier();                                       // ... and the other wave's: both read all of them below
+    }
     float acc[16], fi[16];
     // phase-B role: chunk c, block b -> the 16 consecutive frames 256 c + 16 b ..
     const int cB = lane >> 4, bB = lane & 15;
@@ -151,11 +199,6 @@ __global__ __launch_bounds__(128, MIX_WAVES_PER_SIMD) void spatial_mix_pair(Scen
     // the walk that touches the accumulators)
 #pragma unroll
     for (int k = 0; k < 16; ++k) asm volatile("" : "+v"(acc[k]));
-    // n_groups = gridDim.x * groups_per_wg + rem: the first `rem` workgroups walk one group more
-    const uint32_t rem = n_groups - gridDim.x * groups_per_wg;
-    const uint32_t g_lo = blockIdx.x * groups_per_wg + (blockIdx.x < rem ? blockIdx.x : rem);
-    const uint32_t g_hi = g_lo + groups_per_wg + (blockIdx.x < rem ? 1u : 0u);
-
     unsigned char* const sbase = smem + PAIR_LDS_STREAM + wv * PAIR_STREAM_BYTES;   // this wave's stream blocks: block 4 j + c
     unsigned char* const blkB0 = sbase + cB * (STREAM_WORDS * 4);
     constexpr int BLK_SRC = 4 * STREAM_WORDS * 4;
