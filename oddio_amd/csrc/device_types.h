@@ -38,6 +38,13 @@ struct alignas(16) SrcStatic {
     uint16_t fx;            // FX_*: a per-source soft clip around the signal (reinhard.rs:22-50, tanh.rs:16-44 are Signal + Seek wrappers)
 };
 static_assert(sizeof(SrcStatic) == 32, "SrcStatic layout");
+// Downmix<FramesSignal<[f32;2]>> in FAST mode (round 6): a stereo clip the library owns (oddio_hip_frames_from_slice_stereo) carries,
+// behind its interleaved frames, the mono clip M[i] = L[i] + R[i] (one f32 add per frame, made when the clip is uploaded).  The
+// fused (FAST-mode, 1e-5 tolerance) kernels render a Downmix source as a plain clip over M: lerp(M) is lerp(L) + lerp(R)
+// (downmix.rs:27-29 over frame.rs:39-41) to a rounding or two -- ~1e-7 of |L| + |R| -- at the cost of a mono source instead of 3.2 x.
+// The exact kernels (ORDERED, single-wave callbacks, FAST_UNFUSED, the contribution rows) keep the two interpolations and the sum.
+// SrcStatic::freq_or_value == bits 1: the clip has the mono sum (KIND_DOWNMIX sources only).
+__host__ __device__ inline uint32_t downmix_presum_offset(uint32_t stereo_frames) { return ((2u * stereo_frames + 3u) & ~3u) + 4u; }   // floats from the clip's start, 16-byte aligned
 // `Reinhard<T>` / `Tanh<T>` wrapped around a Seek-set source, with the source's optional FixedGain inside the clip
 // (Reinhard(FixedGain(x)), the default) or outside it (FX_CLIP_FIRST: FixedGain(Reinhard(x)))
 enum : uint16_t { FX_REINHARD = 1, FX_TANH = 2, FX_CLIP_FIRST = 4, FX_CHAIN = 8 };

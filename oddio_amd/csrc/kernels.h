@@ -826,7 +826,17 @@ __device__ __forceinline__ int4 window_desc(const float* clip, int clip_len4, in
 //   the window = every sample index the tile's four streams can touch.  Its upper end only has to be an upper bound:
 //   the cursor after 255 sequentially rounded `offset += ds` steps is below frac0 + 255 * ds by at most
 //   255 half-ulps of its own magnitude (1.6e-5 relative), so the f32 closed form plus a 1e-4 relative margin covers it.
-__device__ __forceinline__ TileRec make_tile_rec(const SceneParams& P, const SrcStatic& s, const EarParams& e0, const EarParams& e1, uint32_t tile) {
+// (device_types.h: a Downmix source over a clip that carries its mono sum is a plain clip source to the fused kernels)
+__device__ __forceinline__ SrcStatic downmix_as_mono(const SceneParams& P, const SrcStatic& s) {
+    SrcStatic r = s;
+    if (s.kind == KIND_DOWNMIX && P.fused && __float_as_uint(s.freq_or_value) == 1u) {
+        r.kind = KIND_FRAMES;
+        r.clip = s.clip + downmix_presum_offset(s.clip_len);
+    }
+    return r;
+}
+__device__ __forceinline__ TileRec make_tile_rec(const SceneParams& P, const SrcStatic& s_in, const EarParams& e0, const EarParams& e1, uint32_t tile) {
+    const SrcStatic s = downmix_as_mono(P, s_in);
     TileRec r = {};                                  // info == 0: PATH_SKIP
     if (e0.flags & EAR_SKIP) return r;
     if (s.kind == KIND_SINE) {
@@ -962,7 +972,8 @@ __device__ __forceinline__ TileRec make_tile_rec(const SceneParams& P, const Src
 // kernel has no staged variant for (windows larger than its stage, stereo clips, absurd cursors) take its exact per-lane path.
 constexpr int PAIR_WIN_CAP = 1184;               // samples staged per source (ds <= ~1.11 over 1024 frames)
 constexpr int PAIR_CHUNKS = 4;
-__device__ __forceinline__ PairRec make_pair_rec(const SceneParams& P, const SrcStatic& s, const EarParams& e0, const EarParams& e1) {
+__device__ __forceinline__ PairRec make_pair_rec(const SceneParams& P, const SrcStatic& s_in, const EarParams& e0, const EarParams& e1) {
+    const SrcStatic s = downmix_as_mono(P, s_in);
     PairRec r = {};                                  // info == 0: PATH_SKIP
     if (e0.flags & EAR_SKIP) return r;
     if (s.kind == KIND_SINE) {                       // (see make_tile_rec: the record carries what the inline Sine needs)

@@ -106,6 +106,7 @@ struct oddio_hip_frames {
     uint32_t channels = 1;   // 1: Frames<f32>; 2: Frames<[f32;2]> (interleaved), Mixer general path only
     float* dev = nullptr;
     bool owned = true;
+    bool has_mono_sum = false;      // stereo clips: L + R sits behind the frames (device_types.h downmix_presum_offset)
     void* pinned_block = nullptr;   // Stream rings: the hipHostMalloc'ed block `dev` points into
     std::atomic<int> refs{1};
 };
@@ -118,11 +119,15 @@ static int frames_alloc(int device, uint32_t rate, size_t len, uint32_t channels
     auto* f = new oddio_hip_frames();
     f->device = device; f->rate = rate; f->len = len; f->channels = channels;
     const size_t padded = (len * channels + 3) & ~size_t(3);
+    // a stereo clip: + the mono sum L + R behind the frames (device_types.h downmix_presum_offset), for Downmix sources in FAST mode
+    const size_t mono_off = channels == 2 ? (size_t)oddio_hip::downmix_presum_offset((uint32_t)len) : 0;
+    const size_t mono_padded = channels == 2 ? ((len + 3) & ~size_t(3)) + 4 : 0;
+    const size_t total = channels == 2 ? mono_off + mono_padded : padded;
     DeviceGuard g(device);
     if (!g.ok) { delete f; return fail(ODDIO_HIP_ENODEV, "hipSetDevice(%d) failed", device); }
-    hipError_t e = hipMalloc(&f->dev, padded * sizeof(float));
-    if (e != hipSuccess) { delete f; return fail(ODDIO_HIP_ENOMEM, "hipMalloc(%zu floats): %s", padded, hipGetErrorString(e)); }
-    e = hipMemset(f->dev + (padded - 4), 0, 4 * sizeof(float));   // zero tail pad: S(i) = 0 for i >= len
+    hipError_t e = hipMalloc(&f->dev, total * sizeof(float));
+    if (e != hipSuccess) { delete f; return fail(ODDIO_HIP_ENOMEM, "hipMalloc(%zu floats): %s", total, hipGetErrorString(e)); }
+    e = hipMemset(f->dev + (padded - 4), 0, (total - (padded - 4)) * sizeof(float));   // zero tail pad: S(i) = 0 for i >= len (and the mono sum's pads)
     if (e != hipSuccess) { (void)hipFree(f->dev); delete f; return fail((int)e, "hipMemset: %s", hipGetErrorString(e)); }
     *out = f;
     return 0;
@@ -147,6 +152,13 @@ extern "C" int oddio_hip_frames_from_slice_stereo(int device, uint32_t rate, con
     if (rc) return rc;
     DeviceGuard g(device);
     hipError_t e = hipMemcpy(f->dev, interleaved, 2 * n_frames * sizeof(float), hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        // the mono sum (0.0 + L) + R, downmix.rs:27-29's channels().sum() on the frames themselves
+        std::vector<float> mono(n_frames);
+        for (size_t i = 0; i < n_frames; ++i) mono[i] = (0.0f + interleaved[2 * i]) + interleaved[2 * i + 1];
+        e = hipMemcpy(f->dev + oddio_hip::downmix_presum_offset((uint32_t)n_frames), mono.data(), n_frames * sizeof(float), hipMemcpyHostToDevice);
+        f->has_mono_sum = e == hipSuccess;
+    }
     if (e != hipSuccess) { (void)hipFree(f->dev); delete f; return fail((int)e, "hipMemcpy H2D: %s", hipGetErrorString(e)); }
     *out = f;
     return 0;

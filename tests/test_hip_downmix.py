@@ -80,3 +80,46 @@ def test_downmix_rejects_mono_clip():
     clip = oa.Frames.from_slice(48000, np.zeros(16, np.float32))
     with pytest.raises(TypeError):
         oa.Downmix(oa.FramesSignal(clip, 0.0))
+
+
+def test_downmix_fast_mode_renders_the_mono_sum_of_the_clip():
+    """Round 6: in FAST mode (fused kernels, 1e-5 contract) a Downmix source over a library-owned stereo clip is rendered as a plain
+    clip source over L + R, which the clip carries behind its frames (device_types.h downmix_presum_offset): lerp(L + R) against the
+    reference's lerp(L) + lerp(R).  Anti-correlated channels (R = -0.9 L + ..: the sum is a sixth of either channel) are the hard
+    case for that identity; 300 sources, three rates, clips that begin and end inside the run; ORDERED stays the oracle's bits."""
+    import oddio_amd as oa
+    from oracle import oracle_c as oc
+    from oddio_amd import synth
+    rng = np.random.default_rng(7)
+    sc = synth.make_scene(77, 300, cube=10.0)
+    interval = np.float32(1.0) / np.float32(48000)
+    scenes = {}
+    for name, mode in (("fast", oa.MODE_FAST), ("ordered", oa.MODE_ORDERED)):
+        control, scene = oa.SpatialScene(max_sources=512, max_frames=1024)
+        scene.set_mode(mode)
+        scenes[name] = (control, scene)
+    ref = oc.SpatialScene()
+    for i in range(300):
+        n = 6000 + 37 * i
+        left = synth.noise_clip(5, i, n)
+        right = (-0.9 * left + 0.1 * synth.noise_clip(6, i, n)).astype(np.float32) if i % 3 else synth.noise_clip(8, i, n)
+        st = np.stack([left, right], axis=1)
+        rate = (48000, 44100, 32000)[i % 3]
+        start = -0.01 if i % 5 == 0 else 0.04
+        for control, _ in scenes.values():
+            sig = oa.Downmix(oa.FramesSignal(oa.Frames.from_slice(rate, st), start))
+            control.play(oa.FixedGain(sig, -2.0) if i % 4 == 0 else sig, oa.SpatialOptions(sc["position"][i], sc["velocity"][i], 0.1))
+        sig = oc.Downmix(oc.FramesSignal(oc.Frames.from_slice(rate, st), start))
+        ref.play(oc.FixedGain(sig, -2.0) if i % 4 == 0 else sig, oc.SpatialOptions(sc["position"][i], sc["velocity"][i], 0.1))
+    worst = 0.0
+    for cb in range(8):
+        n = 1024 if cb != 5 else 700
+        want = ref.sample_n(interval, n)
+        np.testing.assert_array_equal(scenes["ordered"][1].sample_n(interval, n), want)
+        got = scenes["fast"][1].sample_n(interval, n)
+        worst = max(worst, float(np.abs(got - want).max() / np.abs(want).max()))
+    assert len(scenes["fast"][1]) == len(scenes["ordered"][1]) == len(ref)
+    print("Downmix through the mono sum, FAST: worst |gpu - reference| / max|reference| =", worst)
+    assert worst <= 1e-5
+    for _, scene in scenes.values():
+        scene.close()

@@ -9,7 +9,8 @@ Every scene has `--sources` moving sources of ONE kind (positions / velocities o
                                     4096 distinct clips, scattered
   reinhard / tanh                   Reinhard<FramesSignal> / Tanh<FramesSignal>: a per-source soft clip around a 48 kHz clip source
   sine                              Sine (closed form, sinf per sample)
-  downmix                           Downmix<FramesSignal<[f32;2]>> over 48 kHz stereo clips
+  downmix                           Downmix<FramesSignal<[f32;2]>> over 48 kHz stereo clips (round 6: FAST mode renders the clips' mono sums,
+                                    device_types.h; ODDIO_HIP_DOWNMIX_PRESUM=0: the interleaved stereo windows)
   cycle / cycle48k                  Cycle over 5000-sample loops (0.1 s: a tenth of all tiles touches the loop's end and takes the
                                     row path) / 48000-sample loops (ODDIO_HIP_MAX_CYCLE raised to the source count)
 """
