@@ -102,7 +102,11 @@ int oddio_hip_device_count(int* count);
  * rejected (the reference panics on them in get_pair, src/frames.rs:111). */
 int oddio_hip_frames_from_slice(int device, uint32_t rate, const float* samples, size_t len,
                                 oddio_hip_frames** out);
-/* Frames<[f32; 2]> (interleaved stereo, e.g. examples/wav.rs:45-70); playable in a Mixer only. */
+/* Frames<[f32; 2]> (interleaved stereo, e.g. examples/wav.rs:45-70): playable in a Mixer, or in a scene under Downmix
+ * (oddio_hip_scene_play_frames_downmix).  The upload also stores the mono clip L[i] + R[i] behind the frames (+ 50 % device memory):
+ * what FAST-mode scenes render a Downmix source from -- lerp(L + R) for the reference's lerp(L) + lerp(R) (src/downmix.rs:27-29),
+ * ~1e-7 of |L| + |R| apart, inside FAST's 1e-5 contract; ORDERED / FAST_UNFUSED interpolate both channels and stay bit-exact.
+ * ODDIO_HIP_DOWNMIX_PRESUM=0 in the environment keeps the stereo windows in every mode. */
 int oddio_hip_frames_from_slice_stereo(int device, uint32_t rate, const float* interleaved,
                                        size_t n_frames, oddio_hip_frames** out);
 /* Same, but `dev_samples` is already a device pointer on `device`.  copy != 0: D2D copy;

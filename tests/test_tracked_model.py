@@ -7,7 +7,7 @@ scheme: block sums, their prefixes in walk order, restarted blocks, the sum of t
 import numpy as np
 
 
-def _model(n_sources, n_out, block, seed):
+def _model(n_sources, n_out, block, seed, perturb=0.0):
     rng = np.random.default_rng(seed)
     c = (rng.standard_normal((n_sources, n_out)) * 0.2).astype(np.float32)
     ref = np.zeros(n_out, np.float32)
@@ -22,6 +22,9 @@ def _model(n_sources, n_out, block, seed):
     for b in range(nb):                                          # track_prefix: where the walk stands when it reaches block b
         prefix[b] = run
         run = run + t[b]
+    if perturb:                                                  # start values off by `perturb` x the output's peak, independently per block and output
+        peak_ = float(np.abs(exact).max())
+        prefix = (prefix + (rng.standard_normal(prefix.shape) * perturb * peak_).astype(np.float32)).astype(np.float32)
     acc = prefix.copy()
     for i in range(block):                                       # second pass: every block restarted at its prefix, all blocks at once
         acc = acc + cb[:, i, :]
@@ -47,3 +50,13 @@ def test_restarted_blocks_repeat_the_sequential_sums_rounding_errors():
 def test_small_blocks_and_ragged_block_counts():
     e_tracked, e_tree, _ = _model(16 * 1000, 16, 16, 11)        # 1000 blocks of one group of 16 sources
     assert e_tracked < 1e-6 and e_tracked < 0.5 * e_tree, (e_tracked, e_tree)
+
+
+def test_start_values_only_have_to_place_the_binade():
+    """What the first pass has to deliver: the restarted sums repeat the reference's rounding errors as long as
+    they sit in the reference's binade, so start values off by 1e-3 of the output's peak -- four orders of magnitude more than the
+    first pass's own error -- cost nothing; at 1e-2 the mismatched steps begin to show."""
+    base = _model(65536, 48, 128, 7)[0]
+    for perturb, bound in ((1e-5, 1e-6), (1e-4, 1e-6), (1e-3, 1e-6), (1e-2, 3e-6)):
+        e = _model(65536, 48, 128, 7, perturb)[0]
+        assert e < bound, (perturb, e, base)
