@@ -516,27 +516,95 @@ def multi_gpu_selfcheck(device: int, rank: int, world: int, dist, reduce_pref: s
     scene.set_mode(oa.MODE_ORDERED)
     ordered = render(control, scene, 0, S)
     scene.close()
+    fast_result = {"sources": S, "reduce": kind, "rccl_error": rccl_error, "max_rel_err": max(errs)}
     saved = os.environ.get("ODDIO_HIP_PAIR_MIN_GROUPS")
     os.environ["ODDIO_HIP_PAIR_MIN_GROUPS"] = "1"
+    err_t, exc_t = None, None
     try:
         uid = sharding.exchange_unique_id(dist) if kind == "rccl" else None
         sh = sharding.ShardedSpatialScene(device, S, N_FRAMES, rank, world, uid, reduce=kind, dist=dist)
+        sh.scene.set_mode(oa.MODE_TRACKED)
+        got = render(sh.control, sh.scene, lo, hi)
+        sh.scene.close()
+        err_t = max(float(np.abs(g - w).max()) / max(float(np.abs(w).max()), 1e-30) for g, w in zip(got, ordered))
+    except Exception as e:           # noqa: BLE001  (reported: the FAST check above stands by itself)
+        exc_t = f"{type(e).__name__}: {e}"[:300]
     finally:
         if saved is None:
             del os.environ["ODDIO_HIP_PAIR_MIN_GROUPS"]
         else:
             os.environ["ODDIO_HIP_PAIR_MIN_GROUPS"] = saved
-    sh.scene.set_mode(oa.MODE_TRACKED)
-    got = render(sh.control, sh.scene, lo, hi)
-    sh.scene.close()
-    err_t = max(float(np.abs(g - w).max()) / max(float(np.abs(w).max()), 1e-30) for g, w in zip(got, ordered))
     errs_t = [None] * world
-    dist.all_gather_object(errs_t, err_t)
-    if max(errs_t) > 3e-6:
-        raise SystemExit(f"multi-GPU self-check failed: the {world}-shard scene in TRACKED mode (reduce: {kind}) is {max(errs_t):.3g} of the peak from the "
-                         f"unsharded scene's sequential sum on some rank (per rank: {errs_t}); the bound is 3e-6")
+    dist.all_gather_object(errs_t, (err_t, exc_t))
+    if any(e_[1] for e_ in errs_t):
+        fast_result["tracked_error"] = next(e_[1] for e_ in errs_t if e_[1])
+        fast_result["tracked_max_rel_err_vs_ordered"] = None
+        return fast_result
+    errs_t = [e_[0] for e_ in errs_t]
+    if max(errs_t) > 3e-6:       # (the conforming figure is then not reported; the FAST figures stand)
+        fast_result["tracked_error"] = (f"the {world}-shard scene in TRACKED mode (reduce: {kind}) is {max(errs_t):.3g} of the peak from the unsharded scene's "
+                                        f"sequential sum on some rank (per rank: {errs_t}); the bound is 3e-6")
+        fast_result["tracked_max_rel_err_vs_ordered"] = None
+        return fast_result
     del frames, clips
     return {"sources": S, "reduce": kind, "rccl_error": rccl_error, "max_rel_err": max(errs), "tracked_max_rel_err_vs_ordered": max(errs_t)}
+
+
+def selfcheck_worker(args) -> None:
+    """`bench.py --selfcheck-worker` (spawned by every rank of a multi-GPU run, see run_selfcheck): the sharded-scene self-check in a
+    process of its own -- RCCL with more than one rank has never run on the boxes this was developed on, and a collective that hangs
+    or crashes there must cost the run its self-check, not its JSON line.  Prints one JSON object."""
+    fault = os.environ.get("ODDIO_BENCH_SELFCHECK_FAULT")        # (tests: what the parent does with a worker that dies or never returns)
+    if fault == "crash" and os.environ.get("RANK") == "1":
+        os._exit(3)
+    if fault == "hang":
+        time.sleep(3600)
+    import torch
+    import torch.distributed as dist
+    rank, world, local_rank = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"]), int(os.environ.get("LOCAL_RANK", "0"))
+    device = local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(device)
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
+    dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+    try:
+        res = multi_gpu_selfcheck(device, rank, world, dist, args.reduce)
+    except SystemExit as e:          # a sharded scene that does not reproduce the unsharded one
+        res = {"error": str(e)}
+    except Exception as e:           # noqa: BLE001
+        res = {"error": f"{type(e).__name__}: {e}"[:500]}
+    print(json.dumps({"selfcheck": res}), flush=True)
+    try:
+        dist.barrier()
+        dist.destroy_process_group()
+    except Exception:                # noqa: BLE001
+        pass
+
+
+def run_selfcheck(args, rank: int, world: int, dist) -> dict:
+    """Every rank runs the self-check in a child process (its own rendezvous port, a timeout) and the ranks compare notes.
+    -> multi_gpu_selfcheck's dict, or {"error": ...} when any rank's child failed, mismatched or did not finish."""
+    box = [_free_port() if rank == 0 else None]
+    dist.broadcast_object_list(box, src=0)
+    env = dict(os.environ, MASTER_PORT=str(box[0]), MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, os.path.abspath(__file__), "--selfcheck-worker", "--gpus", str(world), "--reduce", args.reduce]
+    if args.share_devices:
+        cmd.append("--share-devices")
+    res = None
+    try:
+        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=args.selfcheck_timeout)
+        lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+        res = json.loads(lines[-1])["selfcheck"] if lines else {"error": f"self-check worker exited with {r.returncode}: {r.stderr[-300:]}"}
+    except subprocess.TimeoutExpired:
+        res = {"error": f"self-check worker did not finish within {args.selfcheck_timeout:.0f} s (killed)"}
+    except Exception as e:           # noqa: BLE001
+        res = {"error": f"{type(e).__name__}: {e}"[:300]}
+    allres = [None] * world
+    dist.all_gather_object(allres, res)
+    bad = [(r_, a["error"]) for r_, a in enumerate(allres) if "error" in a]
+    if bad:
+        return {"error": f"rank {bad[0][0]}: {bad[0][1]}", "ranks_failed": [b[0] for b in bad]}
+    return allres[0]
 
 
 def bench_mixer(device: int, frames_bank) -> dict:
@@ -887,6 +955,8 @@ def main():
     ap.add_argument("--reduce", choices=["rccl", "p2p"], default="rccl",
                     help="--mode sharded: the cross-rank sum of the stereo buffer -- RCCL all-reduce, or the library's deterministic "
                          "peer-to-peer reduce (rank-ordered sum on rank 0; works with several ranks on one GPU)")
+    ap.add_argument("--selfcheck-worker", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--selfcheck-timeout", type=float, default=300.0, help="seconds the multi-GPU self-check's child processes get before they are killed")
     ap.add_argument("--no-selfcheck", action="store_true", help="--gpus N > 1: skip the sharded-vs-unsharded scene check that precedes the timed run")
     ap.add_argument("--share-devices", action="store_true", help="smoke-testing on a box with fewer GPUs than ranks: rank r uses device r %% count")
     ap.add_argument("--reset-every", type=int, default=320, help="callbacks between host-side motion resets of all sources")
@@ -913,6 +983,9 @@ def main():
 
     if args.cpu_worker:
         cpu_worker(args.cpu_worker)
+        return
+    if args.selfcheck_worker:
+        selfcheck_worker(args)
         return
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(self_launch(args.gpus))
@@ -948,13 +1021,20 @@ def main():
         return
     S, L = args.sources, args.clip_len
     selfcheck = None
+    sharded = args.mode == "sharded" and world > 1
     if world > 1 and not args.no_selfcheck:
-        selfcheck = multi_gpu_selfcheck(device, rank, world, dist, args.reduce)
-        if selfcheck["reduce"] != args.reduce:
+        # in a child process per rank, with a timeout: a collective that hangs or crashes costs the self-check, not the line
+        selfcheck = run_selfcheck(args, rank, world, dist)
+        if "error" in selfcheck:
+            if rank == 0:
+                print(f"[bench] multi-GPU self-check FAILED: {selfcheck['error']}", file=sys.stderr)
+            if sharded:      # the sharded scene's own data path is what failed: no number can be trusted
+                raise SystemExit(f"multi-GPU self-check failed: {selfcheck['error']}")
+            # (--mode scenes has no data-path collective: the independent scenes are timed anyway, the failure is in the line)
+        elif selfcheck["reduce"] != args.reduce:
             if rank == 0:
                 print(f"[bench] RCCL reduce group unavailable ({selfcheck['rccl_error']}); the sharded scene uses the peer-to-peer reduce", file=sys.stderr)
             args.reduce = selfcheck["reduce"]
-    sharded = args.mode == "sharded" and world > 1
     # clips start 1.0 s in: the propagation delay (<= 0.25 s at set-up) may grow by the drift of the
     # constant-velocity sources (<= 34.6 m/s) for `reset_every` callbacks without reading before the clip
     start_seconds = 1.0
@@ -1180,21 +1260,25 @@ def main():
         # barrier + synchronize on both sides, the slowest rank counts.  (ORDERED is not timed here: a sharded scene's rank-ordered
         # sum of per-shard ORDERED sums is not the reference's order across the shards.)
         import oddio_amd as oa
-        scene.set_mode(oa.MODE_TRACKED)
-        n_warm, n_timed = 3, 16
-        for _ in range(n_warm):
-            one_step()
-        sync_all()
-        tt0 = time.perf_counter()
-        for _ in range(n_timed):
-            one_step()
-        sync_all()
-        t_tr = torch.tensor([time.perf_counter() - tt0], dtype=torch.float64)
-        tracked_by_rank = [None] * world
-        dist.all_gather_object(tracked_by_rank, float(t_tr.item()) / n_timed * 1e3)
-        dist.all_reduce(t_tr, op=dist.ReduceOp.MAX)
-        tracked_ms = float(t_tr.item()) / n_timed * 1e3
-        scene.set_mode(oa.MODE_FAST)
+        # (a sharded scene's TRACKED callbacks issue a collective more -- ncclAllGather / the slab's second block: timed only when the
+        # self-check has just run exactly that; independent scenes track on their own)
+        tracked_verified = (not sharded) or args.no_selfcheck or bool(selfcheck and selfcheck.get("tracked_max_rel_err_vs_ordered") is not None)
+        if tracked_verified:
+            scene.set_mode(oa.MODE_TRACKED)
+            n_warm, n_timed = 3, 16
+            for _ in range(n_warm):
+                one_step()
+            sync_all()
+            tt0 = time.perf_counter()
+            for _ in range(n_timed):
+                one_step()
+            sync_all()
+            t_tr = torch.tensor([time.perf_counter() - tt0], dtype=torch.float64)
+            tracked_by_rank = [None] * world
+            dist.all_gather_object(tracked_by_rank, float(t_tr.item()) / n_timed * 1e3)
+            dist.all_reduce(t_tr, op=dist.ReduceOp.MAX)
+            tracked_ms = float(t_tr.item()) / n_timed * 1e3
+            scene.set_mode(oa.MODE_FAST)
 
     ranks_seen = 1
     per_rank_ms = [elapsed / args.steps * 1e3]

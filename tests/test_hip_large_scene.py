@@ -475,3 +475,24 @@ def test_bench_self_launch_two_ranks():
     assert chk["tracked_max_rel_err_vs_ordered"] <= 3e-6
     assert len(d["config"]["roofline_frac_by_rank"]) == 2
     assert d["value_conforming_mode"] == "TRACKED" and d["value_conforming"] > 0 and len(d["config"]["tracked_ms_per_step_by_rank"]) == 2
+
+
+@pytest.mark.parametrize("fault,mode,expect_line", [("hang", "scenes", True), ("crash", "scenes", True), ("hang", "sharded", False)])
+def test_bench_survives_a_selfcheck_that_hangs_or_dies(fault, mode, expect_line):
+    """RCCL with more than one rank has never run on the boxes this was developed on.  The multi-GPU self-check therefore runs in a
+    child process per rank with a timeout: in --mode scenes (no data-path collective) a self-check that hangs or dies costs the run
+    its self-check -- the line is printed, the failure is in it; in --mode sharded (the self-check IS the data path) the run ends
+    with a message instead of a number."""
+    import json
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--share-devices", "--mode", mode, "--reduce", "p2p", "--sources", "4096",
+                        "--clip-len", "65536", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--precondition-ms", "0", "--selfcheck-timeout", "25"],
+                       capture_output=True, text=True, timeout=600, env=dict(os.environ, ODDIO_BENCH_SELFCHECK_FAULT=fault))
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    if expect_line:
+        assert r.returncode == 0, r.stderr[-2000:]
+        assert len(lines) == 1
+        d = json.loads(lines[0])
+        assert d["value"] > 0 and "error" in d["config"]["multi_gpu_selfcheck"]
+        assert d["value_conforming"] > 0            # independent scenes track on their own: no collective, timed anyway
+    else:
+        assert r.returncode != 0 and not lines and "self-check failed" in r.stderr
