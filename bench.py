@@ -587,6 +587,8 @@ def run_selfcheck(args, rank: int, world: int, dist) -> dict:
     box = [_free_port() if rank == 0 else None]
     dist.broadcast_object_list(box, src=0)
     env = dict(os.environ, MASTER_PORT=str(box[0]), MASTER_ADDR="127.0.0.1")
+    for k in [k for k in env if k.startswith("TORCHELASTIC_")]:      # (under torchrun: the children rendezvous on their own store, not the agent's)
+        del env[k]
     cmd = [sys.executable, os.path.abspath(__file__), "--selfcheck-worker", "--gpus", str(world), "--reduce", args.reduce]
     if args.share_devices:
         cmd.append("--share-devices")

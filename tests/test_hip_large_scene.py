@@ -496,3 +496,22 @@ def test_bench_survives_a_selfcheck_that_hangs_or_dies(fault, mode, expect_line)
         assert d["value_conforming"] > 0            # independent scenes track on their own: no collective, timed anyway
     else:
         assert r.returncode != 0 and not lines and "self-check failed" in r.stderr
+
+
+def test_bench_under_torchrun_two_ranks():
+    """The driver's launch line for N > 1: `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1
+    --master-port P bench.py --gpus N ...` (here two ranks on the one device)."""
+    import json
+    import socket
+    s_ = socket.socket(); s_.bind(("127.0.0.1", 0)); port = s_.getsockname()[1]; s_.close()
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+                        os.path.join(ROOT, "bench.py"), "--gpus", "2", "--share-devices", "--sources", "4096", "--clip-len", "65536", "--steps", "4", "--warmup", "2",
+                        "--no-cpu-baseline"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["ranks_seen"] == 2 and d["value"] > 0 and d["scaling"] == "weak"
+    chk = d["config"]["multi_gpu_selfcheck"]
+    assert "error" not in chk and chk["max_rel_err"] <= 1e-5 and chk["tracked_max_rel_err_vs_ordered"] <= 3e-6
+    assert d["value_conforming"] > 0
