@@ -1398,6 +1398,9 @@ def main():
                 # sequential sum); ordered_traffic: what it really moves (every row crosses HBM twice), from the PMC passes
                 "ordered_ms_per_step": ordered_ms,
                 "ordered_frac": (b_alg / (ordered_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS) if ordered_ms else None,
+                # TRACKED (the conforming mode at this size): the same algorithmic bytes over its two-pass callback; it moves them twice
+                "tracked_ms_per_step": tracked_ms,
+                "tracked_frac": (b_alg / (tracked_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS) if tracked_ms else None,
                 "ordered_traffic": ordered_traffic,
             },
         }

@@ -21,6 +21,7 @@ INTERVAL = np.float32(1.0) / np.float32(48000)
 # soak options (tests/soak_fuzz.py): more live sources / operations per callback than the default 60 / 0-4
 LIVE_MAX = int(os.environ.get("ODDIO_FUZZ_LIVE", "60"))
 OPS_MAX = int(os.environ.get("ODDIO_FUZZ_OPS", "5"))
+ODDIO_FUZZ_CHAINS = os.environ.get("ODDIO_FUZZ_CHAINS", "1") != "0"    # random nests of FixedGain / Reinhard (/ Tanh) around played sources
 
 
 def _vec(rng, scale):
@@ -34,6 +35,7 @@ def _vec(rng, scale):
 def test_random_operations_bit_exact(seed):
     import oddio_amd as oa
     rng = np.random.default_rng(9000 + seed)
+    rng_chain = np.random.default_rng(424242 + seed)
     control, scene = oa.SpatialScene(max_sources=LIVE_MAX + 36, max_frames=1536)
     if LIVE_MAX > 200:
         scene.reserve_buffered(LIVE_MAX + 36)
@@ -79,6 +81,18 @@ def test_random_operations_bit_exact(seed):
                 if rng.random() < 0.4 and kind != "constant":
                     db = float(rng.uniform(-12, 6))
                     sh, so = oa.FixedGain(sh, db), oc.FixedGain(so, db)
+                if op == "play" and ODDIO_FUZZ_CHAINS and rng_chain.random() < 0.3:
+                    # round 6: nests of the Seek wrappers around a played source (FX_CHAIN, and the compact one-gain-one-clip form); drawn
+                    # from a stream of their own so that the seeds pinned above keep their scenes.  Tanh only where the compare is a tolerance.
+                    for _ in range(int(rng_chain.integers(1, 4))):
+                        w = rng_chain.choice(["fixed", "reinhard", "tanh"] if fast else ["fixed", "reinhard"])
+                        if w == "fixed":
+                            db2 = float(rng_chain.uniform(-9, 9))
+                            sh, so = oa.FixedGain(sh, db2), oc.FixedGain(so, db2)
+                        elif w == "reinhard":
+                            sh, so = oa.Reinhard(sh), oc.Reinhard(so)
+                        else:
+                            sh, so = oa.Tanh(sh), oc.Tanh(so)
                 if op == "buffered":
                     for _ in range(int(rng.integers(0, 3))):
                         if rng.random() < 0.5:
@@ -163,6 +177,7 @@ def test_random_operations_unsynchronised(seed, exact):
     import torch
     import oddio_amd as oa
     rng = np.random.default_rng(19000 + seed)
+    rng_chain = np.random.default_rng(525252 + seed)
     control, scene = oa.SpatialScene(max_sources=LIVE_MAX + 36, max_frames=1536)
     if LIVE_MAX > 200:
         scene.reserve_buffered(LIVE_MAX + 36)
@@ -210,6 +225,18 @@ def test_random_operations_unsynchronised(seed, exact):
                 if rng.random() < 0.4 and kind != "constant":
                     db = float(rng.uniform(-12, 6))
                     sh, so = oa.FixedGain(sh, db), oc.FixedGain(so, db)
+                if op == "play" and ODDIO_FUZZ_CHAINS and rng_chain.random() < 0.3:
+                    # round 6: nests of the Seek wrappers around a played source (FX_CHAIN, and the compact one-gain-one-clip form); drawn
+                    # from a stream of their own so that the seeds pinned above keep their scenes.  Tanh only where the compare is a tolerance.
+                    for _ in range(int(rng_chain.integers(1, 4))):
+                        w = rng_chain.choice(["fixed", "reinhard", "tanh"] if fast else ["fixed", "reinhard"])
+                        if w == "fixed":
+                            db2 = float(rng_chain.uniform(-9, 9))
+                            sh, so = oa.FixedGain(sh, db2), oc.FixedGain(so, db2)
+                        elif w == "reinhard":
+                            sh, so = oa.Reinhard(sh), oc.Reinhard(so)
+                        else:
+                            sh, so = oa.Tanh(sh), oc.Tanh(so)
                 if op == "buffered":
                     for _ in range(int(rng.integers(0, 3))):
                         if rng.random() < 0.5:
