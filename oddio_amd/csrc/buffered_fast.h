@@ -32,6 +32,9 @@ static_assert(RING_MIRROR >= WIN_CAP + 4 && RING_MIRROR % 4 == 0, "a mix window 
 constexpr uint32_t BUF_FAST_OK = 1u;             // BufStatic::flags: the shape is one buffered_write renders
 constexpr uint32_t RING_FAST_MIN = 2048, RING_FAST_MAX = 1u << 24;   // ring lengths the fast path takes ((float)len exact; one wrap per chunk at most)
 constexpr uint32_t BW_FRAMES = 1024;             // frames per Ring::write the fast path takes (64 lanes x 16)
+#ifndef ODDIO_BW_NT_STORE
+#define ODDIO_BW_NT_STORE 0      // 1: the ring stores are streaming (nt) stores -- measured in round 6, see DESIGN 4.4
+#endif
 #ifndef ODDIO_BW_GROUP_LOG2
 #define ODDIO_BW_GROUP_LOG2 4
 #endif
@@ -882,7 +885,11 @@ __global__ __launch_bounds__(64) void buffered_write(const WriteRec* __restrict_
                 for (int q = 0; q < 4; ++q) {
                     const float4 v = *reinterpret_cast<const float4*>(win_bytes + 1024 * q + 16 * lane + 16 * (4 * q + (lane >> 4)));
                     f4u v4 = {v.x, v.y, v.z, v.w};
+#if ODDIO_BW_NT_STORE
+                    __builtin_nontemporal_store(v4, reinterpret_cast<f4u*>(dst + 256 * q));
+#else
                     *reinterpret_cast<f4u*>(dst + 256 * q) = v4;
+#endif
                 }
             } else {
 #pragma unroll 1
