@@ -33,7 +33,9 @@ constexpr uint32_t BUF_FAST_OK = 1u;             // BufStatic::flags: the shape 
 constexpr uint32_t RING_FAST_MIN = 2048, RING_FAST_MAX = 1u << 24;   // ring lengths the fast path takes ((float)len exact; one wrap per chunk at most)
 constexpr uint32_t BW_FRAMES = 1024;             // frames per Ring::write the fast path takes (64 lanes x 16)
 #ifndef ODDIO_BW_NT_STORE
-#define ODDIO_BW_NT_STORE 0      // 1: the ring stores are streaming (nt) stores -- measured in round 6, see DESIGN 4.4
+#define ODDIO_BW_NT_STORE 1      // the ring stores are streaming (nt) stores: a callback writes 1 GB of ring that nothing reads before the next one;
+                                 // left to the L2's write-back they disturb the walk and the ring reads too (round 6: write 0.60 -> 0.52 ms with 9 waves per CU,
+                                 // walk 0.047 -> 0.039, reads 0.241 -> 0.225; 0: plain stores)
 #endif
 #ifndef ODDIO_BW_GROUP_LOG2
 #define ODDIO_BW_GROUP_LOG2 4
@@ -47,7 +49,17 @@ constexpr int BW_WIN_CAP = 1216;                 // leaf samples staged per sour
 constexpr int BW_WIN_BYTES = BW_WIN_CAP * 4;
 constexpr int BW_WIN_PIECES = (BW_WIN_BYTES + 1023) / 1024;
 constexpr int BW_LDS_WIN0 = 0, BW_LDS_WIN1 = BW_WIN_BYTES, BW_LDS_CK = 2 * BW_WIN_BYTES;
-constexpr int BW_LDS_TOTAL = BW_LDS_CK + 64 * BW_CK_STRIDE * 4;
+// Checkpoints of the running sums every BW_CK_FRAMES frames (round 6: 32, was 16): a lane whose 16 frames start in the middle of a
+// checkpoint interval replays the 16 steps before them with the scan's own operations -- 16 issue slots per stream -- and the block
+// shrinks from 12.5 to 6.3 KB: 10 resident waves per CU instead of 7, in a kernel whose time follows its occupancy
+// (ODDIO_HIP_WRITE_WAVES_PER_CU 4 / 5 / 6 / 7: 0.80 / 0.68 / 0.60 / 0.57 ms, profiles/r06_ab_buffered_write.txt).
+#ifndef ODDIO_BW_CK_SHIFT
+#define ODDIO_BW_CK_SHIFT 1      // 0: a checkpoint per 16-frame block (one per lane); 1: per 32 frames
+#endif
+constexpr int BW_CK_SHIFT = ODDIO_BW_CK_SHIFT;
+constexpr int BW_CK_ROWS = 64 >> BW_CK_SHIFT;
+static_assert(BW_CK_SHIFT == 0 || BW_CK_SHIFT == 1, "a lane replays at most one 16-frame block");
+constexpr int BW_LDS_TOTAL = BW_LDS_CK + BW_CK_ROWS * BW_CK_STRIDE * 4;
 static_assert(BW_WIN_BYTES % 16 == 0 && BW_WIN_PIECES == 5, "leaf window buffer: five 1-KiB DMA pieces, the last one partial");
 
 enum : uint32_t { BW_SKIP = 0, BW_FAST = 1, BW_SLOW = 2 };
@@ -638,8 +650,10 @@ __global__ __launch_bounds__(64) void buffered_write(const WriteRec* __restrict_
             float* row = ck + lane;
 #pragma unroll 1
             for (int b = 0; b < 64; ++b) {
-                if (own_row) row[b * BW_CK_STRIDE] = x;
-                if (is_cyc) row[b * BW_CK_STRIDE + 2 * BW_GROUP] = __uint_as_float(cb);
+                if ((b & ((1 << BW_CK_SHIFT) - 1)) == 0) {
+                    if (own_row) row[(b >> BW_CK_SHIFT) * BW_CK_STRIDE] = x;
+                    if (is_cyc) row[(b >> BW_CK_SHIFT) * BW_CK_STRIDE + 2 * BW_GROUP] = __uint_as_float(cb);
+                }
                 // a block in which a Cycle's cursor may reach its clip's end, or restarts: cycle.rs:37-42 / :28-29 step by step
                 if (any_cyc && __any(is_cyc && (cb + f32_as_index(x + 17.0f * inc) + 2u >= clen || ((uint32_t)b == (n1 >> 4) && n1 < BW_FRAMES)))) {
 #pragma unroll 1
@@ -714,7 +728,8 @@ __global__ __launch_bounds__(64) void buffered_write(const WriteRec* __restrict_
             float out[16];
             const int win_slots = pad ? 4 * nvec + (4 * nvec >> 4) + 1 : 4 * nvec;    // (debug build: what a stored frame may read)
             (void)win_slots;
-            const float* ckl = ck + lane * BW_CK_STRIDE;
+            const float* ckl = ck + (lane >> BW_CK_SHIFT) * BW_CK_STRIDE;
+            const bool ck_replay = BW_CK_SHIFT && (lane & 1);     // this lane's frames start 16 steps behind its checkpoint
             // ---- the leaf: FramesSignal::sample (frames.rs:176-201) for this lane's 16 frames ----
             bool cyc_store = false;                       // (a Cycle: this lane holds the cursor after the callback's last frame)
             uint32_t cyc_cb = 0u; float cyc_off = 0.0f;
@@ -734,6 +749,16 @@ __global__ __launch_bounds__(64) void buffered_write(const WriteRec* __restrict_
                 wave_sync();
                 float off = ckl[j];
                 uint32_t cbv = __float_as_uint(ckl[2 * BW_GROUP + j]);
+                if (ck_replay) {      // the scan's steps of the 16 frames before this lane's (cycle.rs:28-29, :37-42, :50: no sample is read)
+#pragma unroll 1
+                    for (int k = 0; k < 16; ++k) {
+                        const uint32_t f = f0 - 16u + (uint32_t)k;
+                        if (seg2 && f == cnt1) { const double cur_ = (double)cbv + (double)off; cbv = (uint32_t)cur_; off = (float)(cur_ - (double)cbv); }
+                        const uint32_t tr = f32_as_index(off);
+                        if (cbv + tr >= clen_) { const float fr = off - (float)tr; off = (float)((cbv + tr) % clen_) + fr; cbv = 0u; }
+                        off = off + ds;
+                    }
+                }
 #pragma unroll 1
                 for (int k = 0; k < 16; ++k) {
                     const uint32_t f = f0 + (uint32_t)k;
@@ -783,6 +808,10 @@ __global__ __launch_bounds__(64) void buffered_write(const WriteRec* __restrict_
                     }
                 } else {
                     float xx = ckl[j];
+                    if (ck_replay) {
+#pragma unroll
+                        for (int k = 0; k < 16; ++k) xx = xx + ds;          // frames.rs:194, the scan's own adds
+                    }
                     if (pad) {
 #pragma unroll
                         for (int k = 0; k < 16; ++k) {
@@ -811,6 +840,13 @@ __global__ __launch_bounds__(64) void buffered_write(const WriteRec* __restrict_
                 // the Ring::write wraps: frames >= cnt1 belong to a second inner.sample call, which restarts the cursor
                 // from the f64 clock (frames.rs:176-181).  A few percent of the sources of a callback.
                 float xx = leaf_fast ? 0.0f : ckl[j];
+                if (ck_replay && !leaf_fast) {
+#pragma unroll 1
+                    for (int k = 0; k < 16; ++k) {
+                        if (f0 - 16u + (uint32_t)k == cnt1) xx = fr1;       // the second call's restart (frames.rs:176-181), as in the scan
+                        xx = xx + ds;
+                    }
+                }
 #pragma unroll 1
                 for (int k = 0; k < 16; ++k) {
                     const uint32_t f = f0 + (uint32_t)k;
@@ -847,6 +883,10 @@ __global__ __launch_bounds__(64) void buffered_write(const WriteRec* __restrict_
                     const float next = ri ? ODDIO_RF(21, j) : ODDIO_RF(20, j);
                     const float step = ri ? ODDIO_RF(25, j) : ODDIO_RF(24, j);
                     float p = ckl[BW_GROUP * (int)kind + j];
+                    if (ck_replay) {
+#pragma unroll
+                        for (int k = 0; k < 16; ++k) p = fminf(p + step, 1.0f);   // smooth.rs:47-49, the scan's own steps
+                    }
                     float pfin = p;
 #pragma unroll
                     for (int k = 0; k < 16; ++k) {

@@ -313,6 +313,9 @@ __device__ __forceinline__ double f64_rem_euclid(double a, double b) {   // core
 
 constexpr int MIX_WG_WAVES = ODDIO_MIX_WG_WAVES;       // waves per workgroup
 #ifndef ODDIO_DIAG
+#ifndef ODDIO_ROWS_NT
+#define ODDIO_ROWS_NT 0      // 1: ORDERED's contribution rows leave as streaming (nt) stores -- measured in round 6
+#endif
 #define ODDIO_DIAG 0   // diagnostic builds only (tools/ubench, profiles/r05_exp_*): 1 conflict-free (wrong) LDS addresses, 2 no sample loop, 4 no cursor scan, 8 no window DMA
 #endif
 constexpr int MIX_WAVES_PER_SIMD = ODDIO_MIX_WAVES;    // register budget: 512 / this
@@ -1593,8 +1596,15 @@ __device__ __forceinline__ void rows_transpose(const float (&acc)[16], float4 (&
 __device__ __forceinline__ void rows_store(const float4 (&o)[4], const float4 (&o1)[4], unsigned char* p) {
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
+#if ODDIO_ROWS_NT
+        typedef float v4f_ __attribute__((ext_vector_type(4)));
+        v4f_ a_ = {o[k].x, o[k].y, o[k].z, o[k].w}, b_ = {o1[k].x, o1[k].y, o1[k].z, o1[k].w};
+        __builtin_nontemporal_store(a_, reinterpret_cast<v4f_*>(p + k * (MIX_GROUP * 64)));
+        __builtin_nontemporal_store(b_, reinterpret_cast<v4f_*>(p + k * (MIX_GROUP * 64) + 64));
+#else
         *reinterpret_cast<float4*>(p + k * (MIX_GROUP * 64)) = o[k];
         *reinterpret_cast<float4*>(p + k * (MIX_GROUP * 64) + 64) = o1[k];
+#endif
     }
 }
 
