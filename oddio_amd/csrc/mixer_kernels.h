@@ -6,6 +6,9 @@
 #include "buffered_kernels.h"
 #include "buffered_fast.h"
 
+#ifndef ODDIO_MIXU_POLICY
+#define ODDIO_MIXU_POLICY 0      // cache policy of mixer_mix_unit's clip loads (buffer-load aux bits: 2 = nt); measured in round 6
+#endif
 namespace oddio_hip {
 
 // one thread per slot: stop / finished scan (mixer.rs:100-106) and cursor bookkeeping
@@ -418,8 +421,8 @@ __global__ __launch_bounds__(64) void mixer_mix_unit(uint32_t n_sources, uint32_
             (int)(4u * (uint32_t)rl_i((int)ss.clip_len, (J))), 0x00020000);                                               \
         const int vo_ = 4 * rl_i(base_i, (J)) + voff_lane;                                                                \
         _Pragma("unroll") for (int k = 0; k < 4; ++k) {                                                                   \
-            a[SLOT][k] = __builtin_bit_cast(mixf4, __builtin_amdgcn_raw_buffer_load_b128(r_, vo_ + 1024 * k, 0, 0));       \
-            b[SLOT][k] = __builtin_bit_cast(mixf4, __builtin_amdgcn_raw_buffer_load_b128(r_, vo_ + 1024 * k + 4, 0, 0));   \
+            a[SLOT][k] = __builtin_bit_cast(mixf4, __builtin_amdgcn_raw_buffer_load_b128(r_, vo_ + 1024 * k, 0, ODDIO_MIXU_POLICY));       \
+            b[SLOT][k] = __builtin_bit_cast(mixf4, __builtin_amdgcn_raw_buffer_load_b128(r_, vo_ + 1024 * k + 4, 0, ODDIO_MIXU_POLICY));   \
         }                                                                                                                 \
     }
         unsigned long long todo = live_mask;
