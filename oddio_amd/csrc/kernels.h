@@ -313,6 +313,9 @@ __device__ __forceinline__ double f64_rem_euclid(double a, double b) {   // core
 
 constexpr int MIX_WG_WAVES = ODDIO_MIX_WG_WAVES;       // waves per workgroup
 #ifndef ODDIO_DIAG
+#ifndef ODDIO_ORD_POLICY
+#define ODDIO_ORD_POLICY ""     // cache policy of ordered_sum's row loads (" nt": streaming); measured in round 6
+#endif
 #ifndef ODDIO_ROWS_NT
 #define ODDIO_ROWS_NT 0      // 1: ORDERED's contribution rows leave as streaming (nt) stores -- measured in round 6
 #endif
@@ -2158,19 +2161,19 @@ __global__ __launch_bounds__(64 * (1 + ORD_LOADERS)) void ordered_sum(const floa
             const uint32_t so0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)so);
             uint32_t keep;
             asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t"
-                         "buffer_load_dwordx4 %1, %2, 0 offen lds\n\t"
-                         "buffer_load_dwordx4 %1, %2, %4 offen offset:1024 lds\n\t"
-                         "buffer_load_dwordx4 %1, %2, %5 offen offset:2048 lds\n\t"
-                         "buffer_load_dwordx4 %1, %2, %6 offen offset:3072 lds\n\t"
+                         "buffer_load_dwordx4 %1, %2, 0 offen" ODDIO_ORD_POLICY " lds\n\t"
+                         "buffer_load_dwordx4 %1, %2, %4 offen offset:1024" ODDIO_ORD_POLICY " lds\n\t"
+                         "buffer_load_dwordx4 %1, %2, %5 offen offset:2048" ODDIO_ORD_POLICY " lds\n\t"
+                         "buffer_load_dwordx4 %1, %2, %6 offen offset:3072" ODDIO_ORD_POLICY " lds\n\t"
                          "s_mov_b32 m0, %0"
                          : "=&s"(keep) : "v"(voff), "s"(rsrc), "s"(dst), "s"(so0), "s"(2u * so0), "s"(3u * so0) : "memory");
             const uint32_t dst2 = dst + 4096u;
             const int voff2 = voff + (int)(4u * group_stride);      // chunk 4 (8 * 128 KiB fits the 32-bit offset)
             asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t"
-                         "buffer_load_dwordx4 %1, %2, 0 offen lds\n\t"
-                         "buffer_load_dwordx4 %1, %2, %4 offen offset:1024 lds\n\t"
-                         "buffer_load_dwordx4 %1, %2, %5 offen offset:2048 lds\n\t"
-                         "buffer_load_dwordx4 %1, %2, %6 offen offset:3072 lds\n\t"
+                         "buffer_load_dwordx4 %1, %2, 0 offen" ODDIO_ORD_POLICY " lds\n\t"
+                         "buffer_load_dwordx4 %1, %2, %4 offen offset:1024" ODDIO_ORD_POLICY " lds\n\t"
+                         "buffer_load_dwordx4 %1, %2, %5 offen offset:2048" ODDIO_ORD_POLICY " lds\n\t"
+                         "buffer_load_dwordx4 %1, %2, %6 offen offset:3072" ODDIO_ORD_POLICY " lds\n\t"
                          "s_mov_b32 m0, %0"
                          : "=&s"(keep) : "v"(voff2), "s"(rsrc), "s"(dst2), "s"(so0), "s"(2u * so0), "s"(3u * so0) : "memory");
             if (mine >= (uint32_t)IN_FLIGHT) {
