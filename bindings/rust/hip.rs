@@ -47,6 +47,7 @@ pub const LEAF_FRAMES: c_int = 0;
 pub const LEAF_SINE: c_int = 1;
 pub const LEAF_CONSTANT: c_int = 2;
 pub const LEAF_CYCLE: c_int = 3;
+pub const LEAF_DOWNMIX: c_int = 4; // Downmix::new(FramesSignal::new(stereo frames, ..)): oddio_hip_scene_play_filtered only
 pub const POSTFX_NONE: c_int = 0;
 pub const POSTFX_REINHARD: c_int = 1;
 pub const POSTFX_TANH: c_int = 2;
@@ -260,6 +261,16 @@ impl HipSpatialSceneControl {
         let mut id = 0u32;
         check(unsafe {
             oddio_hip_scene_play_filtered((self.0).0, LEAF_FRAMES, frames.0, start_seconds, 0.0, 0.0, filters.as_ptr(), filters.len() as c_int, p.as_ptr(), v.as_ptr(), options.radius, &mut id)
+        });
+        self.spatial(id)
+    }
+    /// play(filters(Downmix::new(FramesSignal::new(stereo_frames, start_seconds))), options): the same wrapper nests around a Downmix
+    /// of a stereo clip (src/downmix.rs:18-47 is Seek when its inner signal is), e.g. `Reinhard::new(Downmix::new(x))`.
+    pub fn play_downmix_filtered(&mut self, stereo_frames: &Arc<HipFrames>, start_seconds: f64, filters: &[RawFilter], options: SpatialOptions) -> HipSpatial {
+        let (p, v) = pv(&options);
+        let mut id = 0u32;
+        check(unsafe {
+            oddio_hip_scene_play_filtered((self.0).0, LEAF_DOWNMIX, stereo_frames.0, start_seconds, 0.0, 0.0, filters.as_ptr(), filters.len() as c_int, p.as_ptr(), v.as_ptr(), options.radius, &mut id)
         });
         self.spatial(id)
     }
