@@ -48,6 +48,7 @@ def test_random_operations_bit_exact(seed):
     live = []          # [hip handle, oracle handle, hip controls, oracle controls]
     clip_no = 0
     peak_len, removed_seen = 0, False
+    sig_scale = 0.0
     for cb in range(60):
         n_ops = int(rng.integers(0, OPS_MAX))
         for _ in range(n_ops):
@@ -142,7 +143,11 @@ def test_random_operations_bit_exact(seed):
         a = ref.sample_n(INTERVAL, n)
         b = scene.sample_n(INTERVAL, n)
         if fast:
-            np.testing.assert_allclose(b, a, rtol=0, atol=1e-5 * max(float(np.abs(a).max()), 1e-3), err_msg=f"seed {seed} callback {cb} n {n}")
+            # 1e-5 of the signal's scale: the largest |reference| seen so far, not of this callback alone -- a one-frame callback whose
+            # sources happen to cancel has a "peak" far below the running sums that set every mode's rounding (soak seed 43071, round 6:
+            # TRACKED, n = 1, |out| = 0.0029, off by one ulp of its running sum: 3.4e-8)
+            sig_scale = max(sig_scale, float(np.abs(a).max()))
+            np.testing.assert_allclose(b, a, rtol=0, atol=1e-5 * max(sig_scale, 1e-3), err_msg=f"seed {seed} callback {cb} n {n}")
         else:
             np.testing.assert_array_equal(b, a, err_msg=f"seed {seed} callback {cb} n {n}")
         assert (len(scene), scene.len_buffered()) == (len(ref_scene), ref_scene.len_buffered())
