@@ -181,3 +181,20 @@ def test_pair_kernel_fast_mode_within_tolerance_and_close_to_spatial_mix(monkeyp
         scale = np.abs(ref[cb]).max()
         assert np.abs(pair[cb] - ref[cb]).max() <= 1e-5 * scale, cb      # the north_star's tolerance
         assert np.abs(pair[cb] - tile[cb]).max() <= 2e-6 * scale, cb     # the two kernels differ by their sum trees only
+
+
+@pytest.mark.parametrize("mode_name,n_src,n_frames", [("FAST", 100, 1024), ("FAST_UNFUSED", 57, 700), ("TRACKED", 100, 1024)])
+def test_walk_inside_the_mix_kernel_leaves_the_same_bits(monkeypatch, mode_name, n_src, n_frames):
+    """ODDIO_HIP_FUSED_WALK=1 (pair_kernels.h WALK): the set walk at the top of spatial_mix_pair instead of a spatial_prepass launch --
+    the same records from the same code, so the same output bits, through a listener rotation, motion updates and sources that finish
+    and are removed (the walk's other products: clocks, finished flags, the stopped list the reduce compacts from)."""
+    import oddio_amd as oa
+    n_cb = 5
+    sources = _sources(900 + n_src, n_src, with_sine=mode_name == "FAST", short_clip=1800)
+    monkeypatch.setenv("ODDIO_HIP_FUSED_WALK", "0")
+    plain, live0 = _render_hip(monkeypatch, getattr(oa, "MODE_" + mode_name), sources, n_frames, n_cb, pair=True)
+    monkeypatch.setenv("ODDIO_HIP_FUSED_WALK", "1")
+    fused, live1 = _render_hip(monkeypatch, getattr(oa, "MODE_" + mode_name), sources, n_frames, n_cb, pair=True)
+    assert live0 == live1 < n_src            # sources were removed on the way
+    for cb in range(n_cb):
+        np.testing.assert_array_equal(fused[cb], plain[cb], err_msg=f"callback {cb}")
