@@ -312,13 +312,13 @@ __device__ __forceinline__ double f64_rem_euclid(double a, double b) {   // core
 #endif
 
 constexpr int MIX_WG_WAVES = ODDIO_MIX_WG_WAVES;       // waves per workgroup
-#ifndef ODDIO_DIAG
 #ifndef ODDIO_ORD_POLICY
 #define ODDIO_ORD_POLICY ""     // cache policy of ordered_sum's row loads (" nt": streaming); measured in round 6
 #endif
 #ifndef ODDIO_ROWS_NT
 #define ODDIO_ROWS_NT 0      // 1: ORDERED's contribution rows leave as streaming (nt) stores -- measured in round 6
 #endif
+#ifndef ODDIO_DIAG
 #define ODDIO_DIAG 0   // diagnostic builds only (tools/ubench, profiles/r05_exp_*): 1 conflict-free (wrong) LDS addresses, 2 no sample loop, 4 no cursor scan, 8 no window DMA
 #endif
 constexpr int MIX_WAVES_PER_SIMD = ODDIO_MIX_WAVES;    // register budget: 512 / this

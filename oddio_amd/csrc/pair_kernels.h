@@ -28,14 +28,33 @@
 namespace oddio_hip {
 
 constexpr int PAIR_GROUP = MIX_GROUP;                                     // sources per cursor-scan step (16 sources x 4 chunks = 64 lanes)
+// PAIR_DEPTH windows in flight behind the one being mixed (round 6 experiment, default 1).  The question: is the kernel's fetch side
+// bound by concurrency -- one window in flight per workgroup = 2 048 x 4.3 KB = 8.8 MB outstanding, and 8.8 MB per 1.5 us of loaded
+// memory latency would be exactly the 6.0 TB/s the fetch-only diagnostic build reaches -- or by the rate HBM gives random 4.3-KB reads?
+// Round 5's three-buffer variant could not tell: its third buffer cost two workgroups per CU.  ODDIO_PAIR_DEPTH=2 pays for the third
+// buffer with the stream blocks instead: a cursor checkpoint per 32 frames (a lane whose 16 frames start mid-interval replays the 16
+// steps before them with the scan's own adds), 12 words per stream instead of 20 -- 3 x 4 736 + 2 x 3 072 = 20 352 B per workgroup,
+// still 8 workgroups per CU, 109 VGPRs, no scratch; the younger window's DMA stays in flight across the per-source hand-over
+// (`s_waitcnt vmcnt(2)`, a barrier without hipcc's fences).  Parity-green (every pair-kernel, TRACKED and bounds-build test).
+// Measured, same box, alternating runs (profiles/r06_ab_pair_depth2.txt): the kernel 0.2325 against 0.2312 ms, its fetch alone
+// (no sample loop) 0.2098 against 0.2023 -- more windows in flight do NOT raise the fetch rate: it is the rate of this access
+// pattern, not a latency x concurrency product.  Kept as a build option; the default stays the two-buffer layout.
+#ifndef ODDIO_PAIR_DEPTH
+#define ODDIO_PAIR_DEPTH 1
+#endif
+constexpr int PAIR_DEPTH = ODDIO_PAIR_DEPTH;
+static_assert(PAIR_DEPTH == 1 || PAIR_DEPTH == 2, "one or two windows in flight");
+constexpr int PAIR_NBUF = PAIR_DEPTH + 1;
+constexpr int PAIR_CK_SHIFT = PAIR_DEPTH == 2 ? 1 : 0;                    // checkpoints every 16 << shift frames
+constexpr int PAIR_CK = 16 >> PAIR_CK_SHIFT;                              // checkpoints per stream (a 256-frame chunk)
+constexpr int PAIR_STREAM_WORDS = PAIR_CK + 4;                            // + {4 * wrel, g0, dg, ds}
 constexpr int PAIR_WIN_BYTES = PAIR_WIN_CAP * 4;
 constexpr int PAIR_LDS_WIN0 = 0;
-constexpr int PAIR_LDS_WIN1 = PAIR_WIN_BYTES;
-constexpr int PAIR_LDS_STREAM = 2 * PAIR_WIN_BYTES;
-constexpr int PAIR_STREAM_BYTES = 64 * STREAM_WORDS * 4;                  // one wave's 64 stream blocks
+constexpr int PAIR_LDS_STREAM = PAIR_NBUF * PAIR_WIN_BYTES;
+constexpr int PAIR_STREAM_BYTES = 64 * PAIR_STREAM_WORDS * 4;             // one wave's 64 stream blocks
 constexpr int PAIR_LDS_TOTAL = PAIR_LDS_STREAM + 2 * PAIR_STREAM_BYTES;
 constexpr int PAIR_TAIL_LANES = (PAIR_WIN_BYTES - 4096) / 16;             // lanes of the fifth 1 KiB piece that stay inside the window buffer
-static_assert(PAIR_WIN_BYTES % 16 == 0 && PAIR_LDS_TOTAL % 16 == 0, "16-byte aligned window buffers and stream blocks");
+static_assert(PAIR_WIN_BYTES % 16 == 0 && PAIR_LDS_TOTAL % 16 == 0 && (PAIR_STREAM_WORDS * 4) % 16 == 0, "16-byte aligned window buffers and stream blocks");
 static_assert(PAIR_LDS_TOTAL * 8 <= 160 * 1024, "8 workgroups (16 waves) per CU");
 static_assert(16 * PARK_STRIDE * 4 <= PAIR_WIN_BYTES, "a wave parks its accumulators in one window buffer");
 static_assert(PAIR_WIN_BYTES > 4096 && PAIR_WIN_BYTES <= 5120 && PAIR_TAIL_LANES > 0 && PAIR_TAIL_LANES <= 64, "five 1 KiB pieces cover a window buffer");
@@ -45,6 +64,14 @@ __device__ __forceinline__ void pair_barrier() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
+// The per-source hand-over with two windows in flight (PAIR_DEPTH == 2): the same barrier without the fences, which hipcc lowers to
+// `s_waitcnt vmcnt(0)` on both sides -- that would drain the younger window's DMA at every source.  What crosses the barrier here is
+// LDS only: each wave has waited for its own half of the window (vmcnt, by hand) and for its own LDS accesses (lgkmcnt) before it
+// arrives; the "memory" clobber keeps the compiler from moving accesses across.
+__device__ __forceinline__ void pair_barrier_lds() {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
 // HBM -> LDS, this wave's half of a source's window: the 1 KiB pieces first, first + 2 (and 4 when first == 0) through the
@@ -120,8 +147,8 @@ struct PairWalk {
     SrcDyn* dyn; SrcPending* pend; EarParams* ear; PairRec* recs; uint32_t* stopped_hdr; const uint32_t* d_len; uint32_t* len_snap;
     uint32_t stopped_cap; int check_pending;
 };
-static_assert(64 * (sizeof(PairRec) / 4 + 1) * 4 <= PAIR_LDS_STREAM && 64 * (sizeof(PairRec) / 4 + 1) * 4 <= 2 * PAIR_STREAM_BYTES,
-              "the walk's transposition stage fits the window buffers (wave 0) and the stream blocks (wave 1)");
+constexpr int PAIR_WALK_STAGE = 64 * (sizeof(PairRec) / 4 + 1) * 4;      // bytes of a wave's transposition stage (wave_aos_*)
+static_assert(2 * PAIR_WALK_STAGE <= PAIR_LDS_TOTAL, "the walk's two transposition stages fit the workgroup's LDS");
 
 template <bool FULL, bool FUSED, bool TRACK = false, bool WALK = false>
 __global__ __launch_bounds__(128, MIX_WAVES_PER_SIMD) void spatial_mix_pair(SceneParams P, const SrcStatic* __restrict__ st,
@@ -147,7 +174,7 @@ __global__ __launch_bounds__(128, MIX_WAVES_PER_SIMD) void spatial_mix_pair(Scen
 
     if (WALK) {
         if (blockIdx.x == 0 && threadIdx.x == 0) *W.len_snap = n_sources;      // (the reduce's set compaction and a TRACK second pass read it)
-        uint32_t* stage = reinterpret_cast<uint32_t*>(smem + (wv ? PAIR_LDS_STREAM : 0));
+        uint32_t* stage = reinterpret_cast<uint32_t*>(smem + (wv ? PAIR_WALK_STAGE : 0));
         const uint32_t s_end = g_hi * MIX_GROUP < n_sources ? g_hi * MIX_GROUP : n_sources;
         int lw = threadIdx.x & 63;
         asm volatile("" : "+v"(lw));
@@ -200,8 +227,8 @@ __global__ __launch_bounds__(128, MIX_WAVES_PER_SIMD) void spatial_mix_pair(Scen
 #pragma unroll
     for (int k = 0; k < 16; ++k) asm volatile("" : "+v"(acc[k]));
     unsigned char* const sbase = smem + PAIR_LDS_STREAM + wv * PAIR_STREAM_BYTES;   // this wave's stream blocks: block 4 j + c
-    unsigned char* const blkB0 = sbase + cB * (STREAM_WORDS * 4);
-    constexpr int BLK_SRC = 4 * STREAM_WORDS * 4;
+    unsigned char* const blkB0 = sbase + cB * (PAIR_STREAM_WORDS * 4);
+    constexpr int BLK_SRC = 4 * PAIR_STREAM_WORDS * 4;
 
     // The records of a group -- lanes 0-15: {descriptor words, info} of source `lane`; lane (j, c): {ds, g0, dg} of this
     // wave's ear, the chunk's frac0 and wrel -- are fetched one group ahead (see spatial_mix).
@@ -224,8 +251,18 @@ __global__ __launch_bounds__(128, MIX_WAVES_PER_SIMD) void spatial_mix_pair(Scen
     float pf = 0.0f;
     uint32_t pw = 0u;
     if (g_hi > g_lo) PAIR_LOAD_GROUP(g_hi - 1u, pv, pq, pf, pw)
-    int buf = 0;
+    int buf = 0;                 // the window buffer of the staged source being mixed (`cur`); its successors' follow cyclically
+    int ahead = 0;               // PAIR_DEPTH == 2: the window of the staged source after `cur` is already in flight
     bool pre_issued = false;     // the last source of the previous group already started this group's first window
+#define PAIR_WIN_OFF(B) ((uint32_t)(B) * (uint32_t)PAIR_WIN_BYTES)
+#define PAIR_NEXT_BUF(B, K) (((B) + (K)) % PAIR_NBUF)
+    // this wave's half of window `cur` has landed; with a younger window's DMA instructions behind it (`ahead`: always at least two,
+    // pair_window_dma) those may stay in flight -- vmcnt counts in issue order, and anything issued between the two windows is older
+#define PAIR_WINDOW_WAIT()                                                                                                \
+    {                                                                                                                     \
+        if (PAIR_DEPTH == 2 && ahead && !(ODDIO_DIAG & 8)) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");               \
+        else window_wait();                                                                                               \
+    }
     for (uint32_t g = g_hi; g-- > g_lo;) {
         // ------------------------------ phase A ------------------------------
         const uint4 vdesc = pv;
@@ -241,7 +278,7 @@ __global__ __launch_bounds__(128, MIX_WAVES_PER_SIMD) void spatial_mix_pair(Scen
         int cur = lds_mask ? 31 - __builtin_clz(lds_mask) : -1;
         uint32_t cur_info = 0;
 #define PAIR_ISSUE_WINDOW_OF(VD, JN, BUF)                                                                                 \
-    pair_window_dma(lds_base + (uint32_t)((BUF) ? PAIR_LDS_WIN1 : PAIR_LDS_WIN0), (uint32_t)__builtin_amdgcn_readlane((int)(VD).x, (JN)), \
+    pair_window_dma(lds_base + PAIR_WIN_OFF(BUF), (uint32_t)__builtin_amdgcn_readlane((int)(VD).x, (JN)),                \
                     (uint32_t)__builtin_amdgcn_readlane((int)(VD).y, (JN)), (uint32_t)__builtin_amdgcn_readlane((int)(VD).z, (JN)), \
                     (uint32_t)__builtin_amdgcn_readlane((int)(VD).w, (JN)), lane16, wv ^ ((JN) & 1));
 #define PAIR_ISSUE_WINDOW(JN, BUF) PAIR_ISSUE_WINDOW_OF(vdesc, JN, BUF)
@@ -250,31 +287,37 @@ __global__ __launch_bounds__(128, MIX_WAVES_PER_SIMD) void spatial_mix_pair(Scen
             if (!pre_issued) PAIR_ISSUE_WINDOW(cur, buf)
         }
         pre_issued = false;
+        ahead = 0;
         {
             // exact f32 cursor scan (frames.rs:189-196) of stream (source j = lane >> 2, chunk c = lane & 3) of this wave's ear
-            float* blk = reinterpret_cast<float*>(sbase + laneA * (STREAM_WORDS * 4));
+            float* blk = reinterpret_cast<float*>(sbase + laneA * (PAIR_STREAM_WORDS * 4));
             const float ds = q.x;
             float x = frac0;
 #pragma unroll 1
             for (int b = 0; b < 15; ++b) {
-                blk[b] = x;
+                if ((b & ((1 << PAIR_CK_SHIFT) - 1)) == 0) blk[b >> PAIR_CK_SHIFT] = x;
                 if (ODDIO_DIAG & 4) { x = __builtin_fmaf(16.0f, ds, x); continue; }
 #pragma unroll
                 for (int i = 0; i < 16; ++i) x = x + ds;
             }
-            blk[15] = x;
-            *reinterpret_cast<float4*>(blk + 16) = make_float4(__uint_as_float(4u * wr0), q.y, q.z, q.x);
+            if (PAIR_CK_SHIFT == 0) blk[15] = x;
+            *reinterpret_cast<float4*>(blk + PAIR_CK) = make_float4(__uint_as_float(4u * wr0), q.y, q.z, q.x);
         }
         wave_sync();
 
         // ------------------------------ phase B ------------------------------
         float cx0 = 0.0f;
         float4 ct = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        // lane data of staged source J: the cursor at this lane's first frame -- its checkpoint, or (32-frame checkpoints, odd block) the
+        // checkpoint before it advanced by the scan's own 16 adds -- and {4 * wrel, g0, dg, ds}
 #define PAIR_LANE_DATA(J, X0, T)                                                                                          \
     {                                                                                                                     \
         const unsigned char* blk_ = blkB0 + (J) * BLK_SRC;                                                                \
-        X0 = reinterpret_cast<const float*>(blk_)[bB];                                                                    \
-        T = *reinterpret_cast<const float4*>(blk_ + 64);                                                                  \
+        X0 = reinterpret_cast<const float*>(blk_)[bB >> PAIR_CK_SHIFT];                                                   \
+        T = *reinterpret_cast<const float4*>(blk_ + 4 * PAIR_CK);                                                         \
+        if (PAIR_CK_SHIFT && (bB & 1) && !(ODDIO_DIAG & 4)) {                                                             \
+            _Pragma("unroll") for (int i_ = 0; i_ < 16; ++i_) X0 = X0 + T.w;          /* frames.rs:194 */                 \
+        }                                                                                                                 \
     }
         if (cur >= 0) PAIR_LANE_DATA(cur, cx0, ct)
         // VAR: 0 the common source, 1 padded layout (resample ratio within PAD_EPS of 1), 2 FixedGain and/or a cursor that starts negative
@@ -282,11 +325,15 @@ __global__ __launch_bounds__(128, MIX_WAVES_PER_SIMD) void spatial_mix_pair(Scen
 #define PAIR_STAGED_SOURCE(VAR, PRE)                                                                                      \
     {                                                                                                                     \
         const int flags_j = (int)((cur_info >> 3) & 31u);                                                                 \
-        unsigned char* win_bytes = smem + (buf ? PAIR_LDS_WIN1 : PAIR_LDS_WIN0);                                          \
+        unsigned char* win_bytes = smem + PAIR_WIN_OFF(buf);                                                              \
         const int nvec_j = (int)((cur_info >> 8) & 511u);                                                                 \
-        window_wait();                                    /* this wave's half of the window has landed */                 \
-        pair_barrier();                                   /* ... and the other wave's; both are done with the other buffer */ \
-        asm volatile("" : "+v"(pv.x), "+v"(pv.y), "+v"(pv.z), "+v"(pv.w), "+v"(pq.x), "+v"(pq.y), "+v"(pq.z), "+v"(pq.w), "+v"(pf), "+v"(pw)); \
+        PAIR_WINDOW_WAIT()                                /* this wave's half of the window has landed */                 \
+        /* ... and the other wave's; both are done with the buffer of the source before */                               \
+        if (PAIR_DEPTH == 2) pair_barrier_lds();                                                                          \
+        else {                                                                                                            \
+            pair_barrier();                                                                                               \
+            asm volatile("" : "+v"(pv.x), "+v"(pv.y), "+v"(pv.z), "+v"(pv.w), "+v"(pq.x), "+v"(pq.y), "+v"(pq.z), "+v"(pq.w), "+v"(pf), "+v"(pw)); \
+        }                                                                                                                 \
         const bool fetched_before = !need_prefetch;                                                                       \
         if (need_prefetch) { PAIR_LOAD_GROUP(g - 1u, pv, pq, pf, pw) need_prefetch = false; }                             \
         const unsigned below = lds_mask & ((1u << cur) - 1u);                                                             \
@@ -294,16 +341,24 @@ __global__ __launch_bounds__(128, MIX_WAVES_PER_SIMD) void spatial_mix_pair(Scen
         uint32_t nxt_info = 0;                                                                                            \
         float nx0 = 0.0f;                                                                                                 \
         float4 nt = make_float4(0.0f, 0.0f, 0.0f, 0.0f);                                                                  \
-        if (nxt >= 0) {          /* start the next staged source of this group; lands while we compute */                \
+        int ahead_next = 0;                                                                                               \
+        if (nxt >= 0) {          /* the staged sources behind this one: their windows land while we compute */            \
             nxt_info = (uint32_t)__builtin_amdgcn_readlane((int)vdesc.w, nxt);                                            \
-            PAIR_ISSUE_WINDOW(nxt, buf ^ 1)                                                                               \
+            if (PAIR_DEPTH == 1 || !ahead) PAIR_ISSUE_WINDOW(nxt, PAIR_NEXT_BUF(buf, 1))                                  \
+            if (PAIR_DEPTH == 2) {                                                                                        \
+                const unsigned below2 = below & ((1u << nxt) - 1u);                                                       \
+                if (below2) {    /* (its buffer is the one the source before this one was mixed from) */                  \
+                    PAIR_ISSUE_WINDOW(31 - __builtin_clz(below2), PAIR_NEXT_BUF(buf, 2))                                  \
+                    ahead_next = 1;                                                                                       \
+                }                                                                                                         \
+            }                                                                                                             \
             PAIR_LANE_DATA(nxt, nx0, nt)                                                                                  \
         } else if ((PRE) && g > g_lo && fetched_before) {                                                                 \
-            /* last staged source of the group: the other window buffer is free for the next group's first window */     \
+            /* last staged source of the group: the next window buffer is free for the next group's first window */      \
             int lb_ = lane;                                                                                               \
             asm volatile("" : "+v"(lb_));                                                                                 \
             const unsigned nm_ = (unsigned)__ballot(lb_ < MIX_GROUP && (int)(pv.w & 7u) == PATH_LDS) & 0xffffu;           \
-            if (nm_) { PAIR_ISSUE_WINDOW_OF(pv, 31 - __builtin_clz(nm_), buf ^ 1) pre_issued = true; }                    \
+            if (nm_) { PAIR_ISSUE_WINDOW_OF(pv, 31 - __builtin_clz(nm_), PAIR_NEXT_BUF(buf, 1)) pre_issued = true; }      \
         }                                                                                                                 \
         const int wrel4 = __float_as_int(ct.x);                                                                           \
         if (ODDIO_DIAG & 2) { acc[0] += cx0 + ct.y + ct.z + ct.w + __int_as_float(wrel4); }                              \
@@ -321,11 +376,13 @@ __global__ __launch_bounds__(128, MIX_WAVES_PER_SIMD) void spatial_mix_pair(Scen
             mix_source_lds<FULL, true, false, false, FUSED, false, false, PAIR_WIN_CAP, true, FUSED>(win_bytes, wrel4, cx0, bB, 0, 0.0f, acc, fi, frame0, n_frames, fg, ct.y, ct.z, ct.w, 4 * nvec_j, P.bounds_err, \
                                                                                               0, 0, (int)((cur_info >> 28) & 7u)); \
         }                                                                                                                 \
-        buf ^= 1;                                                                                                         \
+        buf = PAIR_NEXT_BUF(buf, 1);                                                                                      \
+        ahead = ahead_next;                                                                                               \
         cur = nxt; cur_info = nxt_info; cx0 = nx0; ct = nt;                                                               \
     }
-        // rare path: both waves park their accumulators (wave w over window buffer w: a window in flight is awaited first and
-        // fetched again afterwards), run out of line, fetch them back
+        // rare path: both waves park their accumulators (wave w over window buffer w: every window in flight is awaited first, and the
+        // current one is fetched again afterwards; a second one in flight is simply issued again by the next staged source), run out of
+        // line, fetch them back
 #define PAIR_RARE_SOURCE(J)                                                                                               \
     {                                                                                                                     \
         const int path_j = __builtin_amdgcn_readlane((int)vdesc.w, (J)) & 7;                                              \
@@ -344,6 +401,7 @@ __global__ __launch_bounds__(128, MIX_WAVES_PER_SIMD) void spatial_mix_pair(Scen
         wave_sync();                                                                                                      \
         _Pragma("unroll") for (int k = 0; k < 16; ++k) acc[k] = park[k * PARK_STRIDE + lane];                             \
         pair_barrier();                                   /* both park areas are free again */                            \
+        ahead = 0;                                                                                                        \
         if (cur >= 0) PAIR_ISSUE_WINDOW(cur, buf)                                                                         \
     }
         {
@@ -372,6 +430,9 @@ __global__ __launch_bounds__(128, MIX_WAVES_PER_SIMD) void spatial_mix_pair(Scen
         if (need_prefetch) PAIR_LOAD_GROUP(g - 1u, pv, pq, pf, pw)   // a group without a staged source
         wave_sync();   // before the next group's phase A overwrites the stream blocks
     }
+#undef PAIR_WINDOW_WAIT
+#undef PAIR_NEXT_BUF
+#undef PAIR_WIN_OFF
 #undef PAIR_LOAD_GROUP
 
     // ---- this wave's half of the workgroup's partial tiles: ear wv, frames 16 lane .. (tile = lane >> 5) ----
