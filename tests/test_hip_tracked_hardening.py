@@ -108,3 +108,35 @@ def test_tracked_mixer_of_65536_sources_against_the_oracle(clips):
     assert max(errs) <= TRACKED_WORST_CASE_TOL, errs
     assert len(hm) == len(om) == S
     hm.close()
+
+
+def test_tracked_and_fast_on_one_scene_of_1048576_sources():
+    """The north_star's scale in ONE scene: 2^20 moving sources (32 groups of 16 per workgroup instead of the headline scene's 8), drawn
+    from a bank of 16 384 noise clips; TRACKED against the oracle's sequential f32 sum, FAST against the f64-accumulated sum of the
+    same contributions (its tree cannot follow a 2^20-term sequential sum's rounding: that is what TRACKED is for)."""
+    import torch
+
+    import oddio_amd as oa
+    from oracle import oracle_c as oc
+    S, n_bank = 1 << 20, 16384
+    dev = torch.device("cuda", 0)
+    bank_dev = gpu_noise_clips(SEED + 1, n_bank, CLIP, dev)
+    bank = bank_dev.cpu().numpy()
+    sc = synth.make_scene(31337, S, cube=10.0)
+    idx = (((np.arange(S, dtype=np.uint64) * np.uint64(0x9E3779B97F4A7C15)) >> np.uint64(20)) % np.uint64(n_bank)).astype(np.uint32)
+    ref = _oracle(bank, idx, sc, N, callbacks=1)[0]
+    o = oc.SpatialScene()
+    o.play_frames_bulk(RATE, bank, START, sc["position"], sc["velocity"], sc["radius"], clip_of=idx)
+    ref64 = o.sample_f64acc(INTERVAL, N)
+    del o
+    bank_frames = [oa.Frames.from_device_ptr(RATE, bank_dev.data_ptr() + 4 * CLIP * k, CLIP, device=0, copy=False) for k in range(n_bank)]
+    frames = [bank_frames[int(k)] for k in idx]
+    scale = float(np.abs(ref).max())
+    tracked = _hip(frames, sc, oa.MODE_TRACKED, N, callbacks=1)[0]
+    fast = _hip(frames, sc, oa.MODE_FAST, N, callbacks=1)[0]
+    e_tracked = float(np.abs(tracked - ref).max()) / scale
+    e_fast64 = float(np.abs(fast.astype(np.float64) - ref64).max()) / scale
+    e_ref64 = float(np.abs(ref.astype(np.float64) - ref64).max()) / scale
+    print(f"1 048 576 sources in one scene: TRACKED vs reference {e_tracked:.3g}, FAST vs f64 sum {e_fast64:.3g}, reference vs f64 sum {e_ref64:.3g}")
+    assert e_tracked <= TRACKED_WORST_CASE_TOL and e_tracked <= NORTH_STAR_TOL
+    assert e_fast64 <= 2e-6
