@@ -549,6 +549,7 @@ __global__ __launch_bounds__(64) void cycle_scan(SceneParams P, const SrcStatic*
     // ---- the tile records (the walk left PATH_ROW for every tile of a Cycle source) ----
     const float ds_e[2] = {e0.dt * (float)s.clip_rate, e1.dt * (float)s.clip_rate};
     bool rows_pass0 = false;
+    uint32_t row_tiles = 0u;           // bit t: tile t of the record tiles takes the row path (cycle_render renders those tiles only)
 #pragma unroll
     for (int t = 0; t < REC_TILES; ++t) {
         if ((uint32_t)t >= n_rec_tiles) break;
@@ -602,12 +603,12 @@ __global__ __launch_bounds__(64) void cycle_scan(SceneParams P, const SrcStatic*
                 }
             }
         }
-        if (!staged) rows_pass0 = true;
+        if (!staged) { rows_pass0 = true; row_tiles |= 1u << t; }
         recs[(size_t)t * rec_stride + i] = r;
     }
     if (rows_pass0 || n > (uint32_t)(REC_TILES * TILE_FRAMES)) {
         const uint32_t k = atomicAdd(&rlist[par], 1u);
-        rlist[2u + k] = i | (rows_pass0 ? 0x80000000u : 0u);
+        rlist[2u + k] = i | (rows_pass0 ? (0x80000000u | (row_tiles << 29)) : 0u);      // (slots below 2^29: oddio_hip_scene_play_cycle)
     }
 }
 
@@ -623,8 +624,12 @@ __global__ __launch_bounds__(64 * CYCLE_WAVES) void cycle_render(SceneParams P, 
     const uint32_t q = blockIdx.x * CYCLE_WAVES + (uint32_t)wv;
     if (q >= rlist[par]) return;
     const uint32_t entry = rlist[2u + q];
-    const uint32_t i = entry & 0x7fffffffu;
+    const uint32_t i = entry & 0x1fffffffu;
     const uint32_t first_pass = (entry >> 31) ? 0u : (uint32_t)(REC_TILES * TILE_FRAMES);    // (pass 0 = the record tiles: rows only if cycle_scan asked for them)
+    // Round 6: ... and only for the tiles that take the row path (bits 29-30).  Most sources of a callback that touch their loop's end do so in
+    // ONE tile; the other is staged like a clip's.  The kernel is bound by its bytes (the window in, 4 KB of row per ear and tile out).
+    const uint32_t row_tiles = (entry >> 29) & 3u;
+    static_assert(REC_TILES == 2 && TILE_FRAMES == 512, "two record tiles of 32 lanes each");
     const SrcStatic s = st[i];
     const FxRegs fxch = load_fx_chain(s, st);
     const uint32_t len = s.clip_len;
@@ -642,8 +647,14 @@ __global__ __launch_bounds__(64 * CYCLE_WAVES) void cycle_render(SceneParams P, 
             // samples touched ~35 lines per load instruction: the kernel was bound by that).  It starts at the first frame's
             // index and is linear modulo the clip length; a pass that needs more than the stage, or more than one lap of the
             // clip, reads global memory directly.
-            const CycleCk v0 = c[pass0 >> 4];
-            const float span = (float)m * ds;
+            // frames [fa, fb) of the pass are rendered: all of a later pass; the row-path tiles of pass 0
+            uint32_t fa = 0u, fb = m;
+            if (pass0 == 0u) {
+                if (!(row_tiles & 1u)) fa = (uint32_t)TILE_FRAMES < m ? (uint32_t)TILE_FRAMES : m;
+                if (!(row_tiles & 2u)) fb = (uint32_t)TILE_FRAMES < m ? (uint32_t)TILE_FRAMES : m;
+            }
+            const CycleCk v0 = c[(pass0 + fa) >> 4];
+            const float span = (float)(fb > fa ? fb - fa : 0u) * ds;
             const bool staged = ds > 0.0f && span * 1.0001f + 8.0f < (float)CYCLE_WIN_CAP && span * 1.0001f + 8.0f < (float)len;
             const uint32_t w_count = staged ? (uint32_t)(span * 1.0001f) + 8u : 0u;
             uint32_t w_start = v0.base + f32_as_index(v0.offset);
@@ -657,7 +668,7 @@ __global__ __launch_bounds__(64 * CYCLE_WAVES) void cycle_render(SceneParams P, 
             }
             wave_sync();
             const uint32_t f0 = pass0 + 16u * (uint32_t)lane;
-            if (f0 < n) {
+            if (f0 < n && f0 - pass0 >= fa && f0 - pass0 < fb) {
                 const uint32_t done = f0 & ~255u;
                 const uint32_t len_c = (n - done) < 256u ? (n - done) : 256u;
                 const uint32_t cnt = (len_c - (f0 - done)) < 16u ? (len_c - (f0 - done)) : 16u;
