@@ -64,6 +64,21 @@ struct DeviceGuard {
     ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
 };
 
+// Set-up fills and device-to-device copies made by the control thread.  hipMemset of device memory (and a D2D hipMemcpy) returns before
+// the fill has run, as their CUDA namesakes do, and the fill runs on the NULL stream -- which the scenes' and mixers' own streams
+// (hipStreamNonBlocking) do not wait for.  Normally the fill is over long before the first kernel of a `sample` call gets to the memory;
+// with another process keeping the GPU busy it is not: round 6's soak under two concurrent processes met sources that vanished for a
+// callback (a late fill of `d_len` after the first insert), and once a memory fault (a late 0xff fill of the id -> slot table).
+// Every such fill is waited for before the call that made it returns; these are control-thread paths, never inside `sample`.
+static hipError_t memset_now(void* p, int value, size_t bytes) {
+    const hipError_t e = hipMemset(p, value, bytes);
+    return e != hipSuccess ? e : hipStreamSynchronize(nullptr);
+}
+static hipError_t copy_now(void* dst, const void* src, size_t bytes, hipMemcpyKind kind) {
+    const hipError_t e = hipMemcpy(dst, src, bytes, kind);
+    return e != hipSuccess ? e : hipStreamSynchronize(nullptr);
+}
+
 // The host-output calls wait for a ticket that the callback's last kernel stores in pinned memory (a D2H copy + hipStreamSynchronize
 // costs 30-50 us of wake-up latency per callback, the ticket ~5).  The spin is bounded by what the caller's callbacks have been
 // taking -- 8 x the longest recent wait, at least 2 ms, at most 200 ms -- after which the caller falls back to the stream
@@ -127,7 +142,7 @@ static int frames_alloc(int device, uint32_t rate, size_t len, uint32_t channels
     if (!g.ok) { delete f; return fail(ODDIO_HIP_ENODEV, "hipSetDevice(%d) failed", device); }
     hipError_t e = hipMalloc(&f->dev, total * sizeof(float));
     if (e != hipSuccess) { delete f; return fail(ODDIO_HIP_ENOMEM, "hipMalloc(%zu floats): %s", total, hipGetErrorString(e)); }
-    e = hipMemset(f->dev + (padded - 4), 0, (total - (padded - 4)) * sizeof(float));   // zero tail pad: S(i) = 0 for i >= len (and the mono sum's pads)
+    e = memset_now(f->dev + (padded - 4), 0, (total - (padded - 4)) * sizeof(float));   // zero tail pad: S(i) = 0 for i >= len (and the mono sum's pads)
     if (e != hipSuccess) { (void)hipFree(f->dev); delete f; return fail((int)e, "hipMemset: %s", hipGetErrorString(e)); }
     *out = f;
     return 0;
@@ -139,7 +154,7 @@ extern "C" int oddio_hip_frames_from_slice(int device, uint32_t rate, const floa
     int rc = frames_alloc(device, rate, len, 1, &f);
     if (rc) return rc;
     DeviceGuard g(device);
-    hipError_t e = hipMemcpy(f->dev, samples, len * sizeof(float), hipMemcpyHostToDevice);
+    hipError_t e = copy_now(f->dev, samples, len * sizeof(float), hipMemcpyHostToDevice);
     if (e != hipSuccess) { (void)hipFree(f->dev); delete f; return fail((int)e, "hipMemcpy H2D: %s", hipGetErrorString(e)); }
     *out = f;
     return 0;
@@ -151,12 +166,12 @@ extern "C" int oddio_hip_frames_from_slice_stereo(int device, uint32_t rate, con
     int rc = frames_alloc(device, rate, n_frames, 2, &f);
     if (rc) return rc;
     DeviceGuard g(device);
-    hipError_t e = hipMemcpy(f->dev, interleaved, 2 * n_frames * sizeof(float), hipMemcpyHostToDevice);
+    hipError_t e = copy_now(f->dev, interleaved, 2 * n_frames * sizeof(float), hipMemcpyHostToDevice);
     if (e == hipSuccess) {
         // the mono sum (0.0 + L) + R, downmix.rs:27-29's channels().sum() on the frames themselves
         std::vector<float> mono(n_frames);
         for (size_t i = 0; i < n_frames; ++i) mono[i] = (0.0f + interleaved[2 * i]) + interleaved[2 * i + 1];
-        e = hipMemcpy(f->dev + oddio_hip::downmix_presum_offset((uint32_t)n_frames), mono.data(), n_frames * sizeof(float), hipMemcpyHostToDevice);
+        e = copy_now(f->dev + oddio_hip::downmix_presum_offset((uint32_t)n_frames), mono.data(), n_frames * sizeof(float), hipMemcpyHostToDevice);
         f->has_mono_sum = e == hipSuccess;
     }
     if (e != hipSuccess) { (void)hipFree(f->dev); delete f; return fail((int)e, "hipMemcpy H2D: %s", hipGetErrorString(e)); }
@@ -171,7 +186,7 @@ extern "C" int oddio_hip_frames_from_device(int device, uint32_t rate, const flo
         int rc = frames_alloc(device, rate, len, 1, &f);
         if (rc) return rc;
         DeviceGuard g(device);
-        hipError_t e = hipMemcpy(f->dev, dev_samples, len * sizeof(float), hipMemcpyDeviceToDevice);
+        hipError_t e = copy_now(f->dev, dev_samples, len * sizeof(float), hipMemcpyDeviceToDevice);
         if (e != hipSuccess) { (void)hipFree(f->dev); delete f; return fail((int)e, "hipMemcpy D2D: %s", hipGetErrorString(e)); }
         *out = f;
         return 0;
@@ -367,7 +382,7 @@ static int adapt_configure(AdaptHost& a, int device, hipStream_t stream, int ena
     if (!a.d_state) HIP_TRY(hipMalloc(&a.d_state, sizeof(float)));
     const float avg_squared = initial_rms * initial_rms;                                        // adapt.rs:28
     HIP_TRY(hipStreamSynchronize(stream));
-    HIP_TRY(hipMemcpy(a.d_state, &avg_squared, sizeof(float), hipMemcpyHostToDevice));
+    HIP_TRY(copy_now(a.d_state, &avg_squared, sizeof(float), hipMemcpyHostToDevice));
     a.tau = tau; a.max_gain = max_gain; a.low = low; a.high = high;
     a.on = true;
     return 0;
