@@ -81,6 +81,7 @@ def build_gpu_scene(device: int, n_sources: int, clip_len: int, seed: int, start
     ids = np.array([h.id for h in handles], dtype=np.uint32)
     # a zero-frame callback is `sample(interval, &mut [])`: set.update() inserts the sources, no time passes
     prime = torch.zeros((1, 2), dtype=torch.float32, device=dev)
+    torch.cuda.synchronize()   # (the fill runs on torch's stream, which the library's own streams do not wait for)
     scene.sample_device(np.float32(1.0) / np.float32(RATE), prime.data_ptr(), 0)
     scene.synchronize()
     freq = torch.from_numpy(sc["freq_hz"][:n_clips]).to(dev).double()
@@ -465,6 +466,7 @@ def multi_gpu_selfcheck(device: int, rank: int, world: int, dist, reduce_pref: s
     dev = torch.device("cuda", device)
     gen = torch.Generator(device=dev).manual_seed(SEED)
     clips = (torch.rand((S, CL), device=dev, dtype=torch.float32, generator=gen) * 2.0 - 1.0).contiguous()   # (the same on every rank)
+    torch.cuda.synchronize(dev)   # (torch's stream made the clips; the scenes' streams do not wait for it)
     frames = [oa.Frames.from_device_ptr(RATE, clips.data_ptr() + 4 * CL * i, CL, device=device, copy=False) for i in range(S)]
     sc = synth.make_scene(SEED, S, cube=10.0)
     interval = np.float32(1.0) / np.float32(RATE)
@@ -474,6 +476,7 @@ def multi_gpu_selfcheck(device: int, rank: int, world: int, dist, reduce_pref: s
         outs = []
         for _ in range(2):
             o = torch.zeros((N_FRAMES, 2), dtype=torch.float32, device=dev)
+            torch.cuda.synchronize()   # (the fill runs on torch's stream, which the library's own streams do not wait for)
             scene.sample_device(interval, o.data_ptr(), N_FRAMES)
             scene.synchronize()
             outs.append(o.cpu().numpy())
@@ -669,6 +672,7 @@ def bench_mixer(device: int, frames_bank) -> dict:
     for i in range(S2):
         control.play(oa.MonoToStereo(oa.FramesSignal(frames_bank[i], 0.25)))
     dev_out = torch.zeros((N_FRAMES, 2), dtype=torch.float32, device=torch.device("cuda", device))
+    torch.cuda.synchronize()   # (the fill runs on torch's stream, which the library's own streams do not wait for)
     for _ in range(6):
         mixer.sample_device(interval, dev_out.data_ptr(), N_FRAMES)
     mixer.synchronize()
@@ -764,6 +768,7 @@ def bench_buffered(args, device: int, shared=None) -> dict:
                  for k in range(4)]
     torch.cuda.synchronize(dev)
     out = torch.zeros((N_FRAMES, 2), dtype=torch.float32, device=dev)
+    torch.cuda.synchronize()   # (the fill runs on torch's stream, which the library's own streams do not wait for)
     interval = np.float32(1.0) / np.float32(RATE)
     # callbacks a clip lasts at the highest speed; every source's FramesSignal clock is put back before that
     span = max(4, int((L - int(start_seconds * RATE)) / (N_FRAMES * 1.1)) - 4)
@@ -1055,6 +1060,7 @@ def main():
         g = build_gpu_scene(device, S, L, args.seed + rank, start_seconds, args.clips)
     scene, control = g["scene"], g["control"]
     out = torch.zeros((N_FRAMES, 2), dtype=torch.float32, device=torch.device("cuda", device))
+    torch.cuda.synchronize()   # (the fill runs on torch's stream, which the library's own streams do not wait for)
     interval = np.float32(1.0) / np.float32(RATE)
     # callbacks a clip lasts before sources would run off its end; rewind before that
     span = max(1, (L - int(start_seconds * RATE)) // N_FRAMES - 8)

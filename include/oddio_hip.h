@@ -355,7 +355,10 @@ int oddio_hip_scene_synchronize(oddio_hip_scene* scene);
 /* Make the scene enqueue on a caller-owned hipStream_t (e.g. the stream a framework's collectives
  * run on) instead of its private stream. */
 int oddio_hip_scene_set_stream(oddio_hip_scene* scene, void* hip_stream);
-/* The scene's hipStream_t (for callers that order their own work after sample_device). */
+/* The scene's hipStream_t (for callers that order their own work after sample_device -- or BEFORE it: the scene's private stream is
+ * hipStreamNonBlocking and does not wait for the NULL stream, so device memory handed to the scene (borrowed clips, update arrays,
+ * the dev_out of a *_sample_device call) must be complete, or ordered by an event this stream waits for, before the call that uses it;
+ * hipMemset and device-to-device hipMemcpy return before they have run.  See INTEGRATION.md, "Streams"). */
 int oddio_hip_scene_stream(oddio_hip_scene* scene, void** hip_stream);
 /* Seek::seek applied to every live source (src/signal.rs:48-51): t += seconds. */
 int oddio_hip_scene_seek_all(oddio_hip_scene* scene, float seconds);

@@ -367,6 +367,7 @@ def test_control_and_motion_updates_from_device_memory():
             d_ids = torch.from_numpy(np.concatenate([ids, [4000000000]]).astype(np.int64)).to(dev).to(torch.int32)
             d_vals = torch.from_numpy(np.concatenate([vals, [9.0]]).astype(np.float32)).to(dev)
             keep += [d_ids, d_vals]
+            torch.cuda.synchronize()   # (torch's stream converted the ids: the scene's stream does not wait for it)
             gains[5][0].set_amplitude_ratio(0.77); gains[5][1].set_amplitude_ratio(0.77)      # ahead of the batch: the batch wins
             control.set_control_device(n_src + 1, d_ids.data_ptr(), 0, d_vals.data_ptr())
             for i in range(n_src):
@@ -377,6 +378,7 @@ def test_control_and_motion_updates_from_device_memory():
             d_pos = torch.from_numpy(sc2["position"]).to(dev).contiguous()
             d_vel = torch.from_numpy(sc2["velocity"]).to(dev).contiguous()
             keep += [d_ids, d_pos, d_vel]
+            torch.cuda.synchronize()
             control.set_motion_device(n_src, d_ids.data_ptr(), d_pos.data_ptr(), d_vel.data_ptr(), False)
             for i in range(n_src):
                 rh[i].set_motion(sc2["position"][i], sc2["velocity"][i], False)

@@ -39,6 +39,7 @@ def test_sample_device_matches_host_path(torch_cuda):
     cb, sb, hb, fb = build(oa, synth, n_src, clips, sc, device_ptrs=ptrs, torch=torch)
     sb.set_profiling(True)
     out = torch.zeros((1024, 2), dtype=torch.float32, device="cuda")
+    torch.cuda.synchronize()   # (the fill runs on torch's stream, which the library's own streams do not wait for)
     for step in range(4):
         if step == 2:
             pos = sc["position"] + np.float32(0.25)
@@ -73,6 +74,7 @@ def test_postfx_device_and_stream(torch_cuda):
     scene.set_stream(torch.cuda.current_stream().cuda_stream)
     control.play(oa.Constant(1.0), oa.SpatialOptions(position=[0.0, 0.0, -1.0]))
     out = torch.zeros((256, 2), dtype=torch.float32, device="cuda")
+    torch.cuda.synchronize()   # (the fill runs on torch's stream, which the library's own streams do not wait for)
     scene.sample_device(INTERVAL, out.data_ptr(), 256)
     torch.cuda.synchronize()        # the scene's work is on torch's stream now
     o = out.cpu().numpy()
@@ -109,6 +111,7 @@ def test_sample_device_removal_and_insertion_order_is_the_references(torch_cuda)
             oscene.play(oc.FramesSignal(oc.Frames(rate, clips[i]), 0.02), oc.SpatialOptions(sc["position"][i], sc["velocity"][i], 0.1))
     play(n0)
     outs = torch.zeros((n_cb, 1024, 2), dtype=torch.float32, device="cuda")
+    torch.cuda.synchronize()   # (the fill runs on torch's stream, which the library's own streams do not wait for)
     refs = []
     for cb in range(n_cb):
         if cb in (2, 3, 5, 6, 9):

@@ -190,6 +190,7 @@ def test_random_operations_unsynchronised(seed, exact):
     scene.set_exact_updates(exact)
     sizes, wants = [], []
     dev_out = torch.zeros((60, 1536, 2), dtype=torch.float32, device="cuda")
+    torch.cuda.synchronize()   # (the fill runs on torch's stream, which the library's own streams do not wait for)
     scene.set_mode(oa.MODE_FAST if fast else oa.MODE_ORDERED)
     scene.set_postfx((0, 1, 0)[seed % 3])
     ref_scene = oc.SpatialScene()

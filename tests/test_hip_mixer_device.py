@@ -42,6 +42,7 @@ def test_device_output_ordered_is_bit_exact_with_removals(n_src):
     control, mixer, ref, handles, rhandles = _play_all(n_src, 61)
     mixer.set_mode(oa.MODE_ORDERED)
     out = torch.zeros((N, 2), dtype=torch.float32, device="cuda:0")
+    torch.cuda.synchronize()   # (the fill runs on torch's stream, which the library's own streams do not wait for)
     for cb in range(7):
         if cb == 3:
             for j in (2, 3, n_src - 1):
@@ -88,6 +89,7 @@ def test_mono_mixer_device_output():
         ref.play(oc.FramesSignal(oc.Frames(RATE, clip), 0.0))
     mixer.set_mode(oa.MODE_ORDERED)
     out = torch.zeros((N,), dtype=torch.float32, device="cuda:0")
+    torch.cuda.synchronize()   # (the fill runs on torch's stream, which the library's own streams do not wait for)
     for cb in range(3):
         mixer.sample_device(INTERVAL, out.data_ptr(), N)
         mixer.synchronize()

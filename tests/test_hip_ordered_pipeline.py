@@ -50,6 +50,7 @@ def test_pipelined_callbacks_with_removals_plays_and_motion(torch_cuda):
     lens = np.where(np.arange(n_src) % 5 == 2, rng.integers(3 * N, 9 * N, n_src), 14 * N + 999)   # a fifth of the clips end on the way
     sc, clips, frames, control, scene, ref, handles, rhandles = _scenes(n_src, 31, lens)
     outs = torch.zeros((n_cb, N, 2), dtype=torch.float32, device="cuda")
+    torch.cuda.synchronize()   # (the fill runs on torch's stream, which the library's own streams do not wait for)
     refs = []
     for cb in range(n_cb):
         if cb in (3, 7):                                         # new sources land behind whatever has been compacted by then
@@ -88,6 +89,7 @@ def test_pipelined_and_serial_callbacks_interleaved(torch_cuda):
     lens = np.full(n_src, 40 * N)
     sc, clips, frames, control, scene, ref, handles, rhandles = _scenes(n_src, 32, lens)
     out = torch.zeros((N, 2), dtype=torch.float32, device="cuda")
+    torch.cuda.synchronize()   # (the fill runs on torch's stream, which the library's own streams do not wait for)
     plan = ["dev", "dev", "dev", "host", "dev", "dev", "zero", "dev", "prof", "prof", "dev", "dev", "fast", "fast", "dev", "dev", "seek", "dev", "dev", "dev"]
     pending = []                                                 # (device tensor, reference) of un-synchronised callbacks
     for k, what in enumerate(plan):
@@ -108,6 +110,7 @@ def test_pipelined_and_serial_callbacks_interleaved(torch_cuda):
             np.testing.assert_array_equal(scene.sample_n(INTERVAL, N), want, err_msg=f"step {k} ({what})")
         else:
             buf = torch.zeros((N, 2), dtype=torch.float32, device="cuda")
+            torch.cuda.synchronize()   # (the fill runs on torch's stream, which the library's own streams do not wait for)
             scene.sample_device(INTERVAL, buf.data_ptr(), N)
             pending.append((k, what, buf, want))
     scene.synchronize()

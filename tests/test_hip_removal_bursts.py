@@ -51,6 +51,7 @@ def test_thousands_of_sources_stop_in_one_callback(device_mode):
     if device_mode:
         import torch
         dev_out = torch.zeros((12, N, 2), dtype=torch.float32, device="cuda")
+        torch.cuda.synchronize()   # (the fill runs on torch's stream, which the library's own streams do not wait for)
     lens, wants = [], []
     late = None
     for cb in range(12):
