@@ -17,3 +17,10 @@ leg "TRACKED, bounds-checked build"    ODDIO_FUZZ_MODE=tracked ODDIO_HIP_PAIR_MI
 leg "FAST, fused walk"                 ODDIO_FUZZ_MODE=fast ODDIO_HIP_PAIR_MIN_GROUPS=1 ODDIO_HIP_FUSED_WALK=1
 leg "TRACKED, fused walk"              ODDIO_FUZZ_MODE=tracked ODDIO_HIP_PAIR_MIN_GROUPS=1 ODDIO_HIP_FUSED_WALK=1
 leg "FAST, Downmix stereo windows"     ODDIO_FUZZ_MODE=fast ODDIO_HIP_PAIR_MIN_GROUPS=1 ODDIO_HIP_DOWNMIX_PRESUM=0
+# round 6, after the late-fill defect: the same fuzz with a second process on the GPU -- timing that one process never produces
+( while true; do python $R/bench.py --workload buffered --steps 200 --warmup 2 --no-cpu-baseline --sustained 0 > /dev/null 2>&1; done ) &
+NEIGHBOUR=$!
+sleep 25
+leg "FAST beside a memory-bound neighbour"     ODDIO_FUZZ_MODE=fast ODDIO_HIP_PAIR_MIN_GROUPS=1
+leg "ORDERED beside a memory-bound neighbour"  ODDIO_FUZZ_MODE=
+kill $NEIGHBOUR 2>/dev/null; wait $NEIGHBOUR 2>/dev/null
