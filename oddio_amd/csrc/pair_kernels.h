@@ -150,7 +150,10 @@ struct PairWalk {
 constexpr int PAIR_WALK_STAGE = 64 * (sizeof(PairRec) / 4 + 1) * 4;      // bytes of a wave's transposition stage (wave_aos_*)
 static_assert(2 * PAIR_WALK_STAGE <= PAIR_LDS_TOTAL, "the walk's two transposition stages fit the workgroup's LDS");
 
-template <bool FULL, bool FUSED, bool TRACK = false, bool WALK = false>
+// LANE16 (with FULL): a callback of 16 k < 1024 frames -- every lane's 16 frames lie wholly inside or wholly outside `out`, so the lanes
+// inside run the full-callback loop (no per-sample select, sums accumulated in place) and the others sit the sources out; what the
+// reference's sizes of 10 / 20 ms (480 / 960 frames) and any other multiple of 16 take instead of the ragged instantiations.
+template <bool FULL, bool FUSED, bool TRACK = false, bool WALK = false, bool LANE16 = false>
 __global__ __launch_bounds__(128, MIX_WAVES_PER_SIMD) void spatial_mix_pair(SceneParams P, const SrcStatic* __restrict__ st,
                                                                             const EarParams* __restrict__ ear_in, const PairRec* __restrict__ recs_in,
                                                                             float* __restrict__ partials, const float* __restrict__ init,
@@ -158,6 +161,7 @@ __global__ __launch_bounds__(128, MIX_WAVES_PER_SIMD) void spatial_mix_pair(Scen
                                                                             const uint32_t* __restrict__ n_sources_ptr, PairWalk W) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[PAIR_LDS_TOTAL];
     static_assert(!WALK || !TRACK, "the second pass of a tracked callback reads the records of the first pass's walk");
+    static_assert(!LANE16 || (FULL && !WALK), "lane-granular callbacks run the full-callback loop on the lanes inside the callback");
     const uint32_t n_sources = WALK ? W.d_len[0] : *n_sources_ptr;
     // (WALK: the tables this workgroup has just written are read through the pointers they were written through)
     const EarParams* ear = WALK ? W.ear : ear_in;
@@ -202,6 +206,7 @@ __global__ __launch_bounds__(128, MIX_WAVES_PER_SIMD) void spatial_mix_pair(Scen
     // phase-B role: chunk c, block b -> the 16 consecutive frames 256 c + 16 b ..
     const int cB = lane >> 4, bB = lane & 15;
     const uint32_t frame0 = 16u * (uint32_t)lane;
+    const bool lane_on = !LANE16 || frame0 < P.n_frames;     // (LANE16: n_frames % 16 == 0)
     const float fbase = (float)frame0;
 #pragma unroll
     for (int k = 0; k < 16; ++k) { acc[k] = 0.0f; fi[k] = fbase + (float)k; }   // `i as f32` (spatial.rs:459)
@@ -367,13 +372,13 @@ __global__ __launch_bounds__(128, MIX_WAVES_PER_SIMD) void spatial_mix_pair(Scen
             const float frac0_ = reinterpret_cast<const float*>(blkB0 + cur * BLK_SRC)[0];   /* checkpoint 0 */           \
             const int fast_e = wv ? (flags_j & SFLAG_FAST_R) : (flags_j & SFLAG_FAST_L);                                  \
             pair_repack_padded(win_bytes, nvec_j, lane, wv, P.bounds_err);                                                \
-            mix_source_lds<FULL, true, false, true, FUSED, false, false, PAIR_WIN_CAP, true, FUSED>(win_bytes, wrel4, cx0, bB, fast_e, frac0_, acc, fi, frame0, n_frames, fg, ct.y, ct.z, ct.w, 4 * nvec_j, P.bounds_err, \
+            if (lane_on) mix_source_lds<FULL, true, false, true, FUSED, false, false, PAIR_WIN_CAP, true, FUSED>(win_bytes, wrel4, cx0, bB, fast_e, frac0_, acc, fi, frame0, n_frames, fg, ct.y, ct.z, ct.w, 4 * nvec_j, P.bounds_err, \
                                                                                              0, 0, (int)((cur_info >> 28) & 7u)); \
         } else if ((VAR) == 0) {                                                                                          \
-            mix_source_lds<FULL, false, true, false, FUSED, false, false, PAIR_WIN_CAP, false, FUSED>(win_bytes, wrel4, cx0, bB, 0, 0.0f, acc, fi, frame0, n_frames, 1.0f, ct.y, ct.z, ct.w, 4 * nvec_j, P.bounds_err); \
+            if (lane_on) mix_source_lds<FULL, false, true, false, FUSED, false, false, PAIR_WIN_CAP, false, FUSED>(win_bytes, wrel4, cx0, bB, 0, 0.0f, acc, fi, frame0, n_frames, 1.0f, ct.y, ct.z, ct.w, 4 * nvec_j, P.bounds_err); \
         } else {                                                                                                          \
             const float fg = (flags_j & SFLAG_FG) ? st[g * MIX_GROUP + (uint32_t)cur].fixed_gain : 1.0f;                  \
-            mix_source_lds<FULL, true, false, false, FUSED, false, false, PAIR_WIN_CAP, true, FUSED>(win_bytes, wrel4, cx0, bB, 0, 0.0f, acc, fi, frame0, n_frames, fg, ct.y, ct.z, ct.w, 4 * nvec_j, P.bounds_err, \
+            if (lane_on) mix_source_lds<FULL, true, false, false, FUSED, false, false, PAIR_WIN_CAP, true, FUSED>(win_bytes, wrel4, cx0, bB, 0, 0.0f, acc, fi, frame0, n_frames, fg, ct.y, ct.z, ct.w, 4 * nvec_j, P.bounds_err, \
                                                                                               0, 0, (int)((cur_info >> 28) & 7u)); \
         }                                                                                                                 \
         buf = PAIR_NEXT_BUF(buf, 1);                                                                                      \

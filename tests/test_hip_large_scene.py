@@ -156,7 +156,7 @@ def test_config3_ordered_mode_is_bit_exact(big):
 TRACKED_VS_REFERENCE_TOL = 3e-6      # ODDIO_HIP_MODE_TRACKED against the reference's sequential sum (measured ~1e-6): inside the north_star's 1e-5
 
 
-@pytest.mark.parametrize("n_src,n_frames", [(S_BIG, N), (65536, N), (65536, 512), (S_BIG, 384)])
+@pytest.mark.parametrize("n_src,n_frames", [(S_BIG, N), (65536, N), (65536, 512), (S_BIG, 384), (S_BIG, 768)])   # (768: spatial_mix_pair<.., LANE16>)
 def test_tracked_mode_is_within_the_north_star_tolerance_of_the_reference(big, n_src, n_frames):
     """ODDIO_HIP_MODE_TRACKED (pair_kernels.h TRACK): two passes of the FAST-mode kernel whose second one restarts every workgroup's
     running sums at the prefix of the first one's partial sums -- the reference's sequential f32 sum, rounding errors included, to

@@ -146,7 +146,7 @@ def _render_oracle(sources, n_frames, n_cb, only=None):
     return outs, len(scene)
 
 
-@pytest.mark.parametrize("n_src,n_frames", [(100, 1024), (57, 700), (16, 1024), (9, 1024)])
+@pytest.mark.parametrize("n_src,n_frames", [(100, 1024), (57, 700), (16, 1024), (9, 1024), (57, 768), (40, 960)])   # (768 / 960: the LANE16 instantiations)
 def test_pair_kernel_unfused_is_the_sum_of_exact_contributions(monkeypatch, n_src, n_frames):
     import oddio_amd as oa
     n_cb = 4
@@ -198,3 +198,24 @@ def test_walk_inside_the_mix_kernel_leaves_the_same_bits(monkeypatch, mode_name,
     assert live0 == live1 < n_src            # sources were removed on the way
     for cb in range(n_cb):
         np.testing.assert_array_equal(fused[cb], plain[cb], err_msg=f"callback {cb}")
+
+
+@pytest.mark.parametrize("mode_name,n_src,n_frames", [("FAST", 100, 768), ("FAST", 41, 528), ("FAST_UNFUSED", 57, 960), ("TRACKED", 100, 640),
+                                                      ("TRACKED", 70, 1008)])
+def test_lane_granular_callbacks_leave_the_same_bits(monkeypatch, mode_name, n_src, n_frames):
+    """Callbacks of 16 k < 1024 frames take spatial_mix_pair<.., LANE16>: the full-callback loop on the lanes whose 16 frames lie inside
+    the callback, the other lanes sitting the sources out (pair_kernels.h).  The same operations on the same values as the ragged
+    instantiations (ODDIO_HIP_LANE16=0), so the same bits -- through every source variant of the kernel, a listener rotation, motion
+    updates and sources that finish inside the run; and, FAST mode, within the north_star's 1e-5 of the reference."""
+    import oddio_amd as oa
+    n_cb = 5
+    sources = _sources(1300 + n_src, n_src, with_sine=mode_name == "FAST", short_clip=1800)
+    monkeypatch.setenv("ODDIO_HIP_LANE16", "0")
+    ragged, live0 = _render_hip(monkeypatch, getattr(oa, "MODE_" + mode_name), sources, n_frames, n_cb, pair=True)
+    monkeypatch.setenv("ODDIO_HIP_LANE16", "1")
+    lane16, live1 = _render_hip(monkeypatch, getattr(oa, "MODE_" + mode_name), sources, n_frames, n_cb, pair=True)
+    ref, ref_live = _render_oracle(sources, n_frames, n_cb)
+    assert live0 == live1 == ref_live < n_src
+    for cb in range(n_cb):
+        np.testing.assert_array_equal(lane16[cb], ragged[cb], err_msg=f"callback {cb}")
+        assert np.abs(lane16[cb] - ref[cb]).max() <= 1e-5 * np.abs(ref[cb]).max(), cb

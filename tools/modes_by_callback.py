@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """ms per callback of the headline scene in its three sum modes (FAST, TRACKED, ORDERED) by callback length (what each mode promises
-about the output is tested in tests/test_hip_large_scene.py, not here).  `python tools/modes_by_callback.py [sources]`."""
+about the output is tested in tests/test_hip_large_scene.py, not here).  `python tools/modes_by_callback.py [sources [n,n,..]]`."""
 import os
 import sys
 import time
@@ -22,8 +22,12 @@ def main():
     interval = np.float32(1.0) / np.float32(bench.RATE)
     out = torch.zeros((1024, 2), dtype=torch.float32, device="cuda")
     modes = ((oa.MODE_FAST, "FAST"), (oa.MODE_TRACKED, "TRACKED"), (oa.MODE_ORDERED, "ORDERED"))
+    keep = os.environ.get("MODES")          # e.g. MODES=FAST,TRACKED
+    if keep:
+        modes = tuple(m for m in modes if m[1] in keep.split(","))
     print(f"{S} sources; ms per callback (8 callbacks enqueued back to back after 3 untimed)")
-    for n in (128, 256, 512, 768, 1024):
+    sizes = tuple(int(v) for v in sys.argv[2].split(",")) if len(sys.argv) > 2 else (128, 256, 512, 768, 1024)
+    for n in sizes:
         rewind = lambda k: scene.seek_all(-float(k * n) / bench.RATE)
         ms = {}
         for mode, name in modes:
@@ -38,7 +42,7 @@ def main():
             scene.synchronize()
             ms[name] = (time.perf_counter() - t0) / 8 * 1e3
             rewind(8)
-        print(f"{n:5d} frames: FAST {ms['FAST']:.4f}  TRACKED {ms['TRACKED']:.4f}  ORDERED {ms['ORDERED']:.4f} ms", flush=True)
+        print(f"{n:5d} frames: " + "  ".join(f"{name} {v:.4f}" for name, v in ms.items()) + " ms", flush=True)
         assert len(scene) == S
 
 
