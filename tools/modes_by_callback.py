@@ -25,7 +25,8 @@ def main():
     keep = os.environ.get("MODES")          # e.g. MODES=FAST,TRACKED
     if keep:
         modes = tuple(m for m in modes if m[1] in keep.split(","))
-    print(f"{S} sources; ms per callback (8 callbacks enqueued back to back after 3 untimed)")
+    reps = int(os.environ.get("REPS", "8"))     # (callbacks per timing; the clips last 64 callbacks of 1024 frames)
+    print(f"{S} sources; ms per callback ({reps} callbacks enqueued back to back after 3 untimed)")
     sizes = tuple(int(v) for v in sys.argv[2].split(",")) if len(sys.argv) > 2 else (128, 256, 512, 768, 1024)
     for n in sizes:
         rewind = lambda k: scene.seek_all(-float(k * n) / bench.RATE)
@@ -37,11 +38,11 @@ def main():
             rewind(3)
             scene.synchronize()
             t0 = time.perf_counter()
-            for _ in range(8):
+            for _ in range(reps):
                 scene.sample_device(interval, out.data_ptr(), n)
             scene.synchronize()
-            ms[name] = (time.perf_counter() - t0) / 8 * 1e3
-            rewind(8)
+            ms[name] = (time.perf_counter() - t0) / reps * 1e3
+            rewind(reps)
         print(f"{n:5d} frames: " + "  ".join(f"{name} {v:.4f}" for name, v in ms.items()) + " ms", flush=True)
         assert len(scene) == S
 

@@ -13,7 +13,7 @@ after = int(sys.argv[3]) if len(sys.argv) > 3 else 16
 def _timed_kernel(name):      # the FAST instantiation of the Seek set: spatial_mix<true, false, true[, false[, false]]> (older trees: <true, false>)
     if name.startswith("void oddio_hip::spatial_mix_pair<"):      # round 5: large FAST-mode scenes (pair_kernels.h): <FULL, FUSED>
         a = [x.strip() for x in name[name.index("<") + 1:name.index(">")].split(",")]
-        return a[:2] == ["true", "true"]
+        return a[:2] == ["true", "true"] and a[4:5] != ["true"]      # (not <.., LANE16>: callbacks of 16 k < 1024 frames)
     if not name.startswith("void oddio_hip::spatial_mix<"):
         return False
     a = [x.strip() for x in name[name.index("<") + 1:name.index(">")].split(",")]
