@@ -21,6 +21,11 @@ INTERVAL = np.float32(1.0) / np.float32(48000)
 # soak options (tests/soak_fuzz.py): more live sources / operations per callback than the default 60 / 0-4
 LIVE_MAX = int(os.environ.get("ODDIO_FUZZ_LIVE", "60"))
 OPS_MAX = int(os.environ.get("ODDIO_FUZZ_OPS", "5"))
+# soak options: the callback lengths drawn from (default: the list every recorded seed was run with); ODDIO_FUZZ_FRAMES=528,640,768,960,1008,1024 with
+# ODDIO_HIP_PAIR_MIN_GROUPS=1 hunts spatial_mix_pair's lane-granular instantiations (LANE16), ODDIO_FUZZ_PLAIN=1 keeps Cycle / Downmix sources -- which
+# take a scene off the pair kernel -- out of the draw
+FRAME_CHOICES = [int(v) for v in os.environ["ODDIO_FUZZ_FRAMES"].split(",")] if os.environ.get("ODDIO_FUZZ_FRAMES") else [1024, 1024, 512, 256, 1, 300, 1300, 1536]
+PLAIN_KINDS = os.environ.get("ODDIO_FUZZ_PLAIN", "") not in ("", "0")
 ODDIO_FUZZ_CHAINS = os.environ.get("ODDIO_FUZZ_CHAINS", "1") != "0"    # random nests of FixedGain / Reinhard (/ Tanh) around played sources
 
 
@@ -55,7 +60,7 @@ def test_random_operations_bit_exact(seed):
             op = rng.choice(["play", "play", "buffered", "motion", "motion", "rotation", "control", "drop"])
             if op in ("play", "buffered") and len(live) < LIVE_MAX:
                 clip_no += 1
-                kind = rng.choice(["frames", "frames", "cycle", "constant"] + (["downmix"] if op == "play" else []))
+                kind = rng.choice(["frames", "frames", "constant"] if PLAIN_KINDS else ["frames", "frames", "cycle", "constant"] + (["downmix"] if op == "play" else []))
                 rate = int(rng.choice([48000, 44100, 22050]))
                 pos, vel = _vec(rng, 12.0), _vec(rng, 25.0)
                 radius = float(rng.choice([0.1, 0.5]))
@@ -139,7 +144,7 @@ def test_random_operations_bit_exact(seed):
                 if live[k][0].is_finished():                 # dropping the handle frees the id for reuse
                     live[k][0].release()
                     live.pop(k)
-        n = int(rng.choice([1024, 1024, 512, 256, 1, 300, 1300, 1536]))
+        n = int(rng.choice(FRAME_CHOICES))
         a = ref.sample_n(INTERVAL, n)
         b = scene.sample_n(INTERVAL, n)
         if fast:
@@ -204,7 +209,7 @@ def test_random_operations_unsynchronised(seed, exact):
             op = rng.choice(["play", "play", "buffered", "motion", "motion", "rotation", "control", "drop"])
             if op in ("play", "buffered") and len(live) < LIVE_MAX:
                 clip_no += 1
-                kind = rng.choice(["frames", "frames", "cycle", "constant"] + (["downmix"] if op == "play" else []))
+                kind = rng.choice(["frames", "frames", "constant"] if PLAIN_KINDS else ["frames", "frames", "cycle", "constant"] + (["downmix"] if op == "play" else []))
                 rate = int(rng.choice([48000, 44100, 22050]))
                 pos, vel = _vec(rng, 12.0), _vec(rng, 25.0)
                 radius = float(rng.choice([0.1, 0.5]))
@@ -288,7 +293,7 @@ def test_random_operations_unsynchronised(seed, exact):
                 if live[k][1].is_finished():                 # (the oracle's answer: the device may be callbacks behind)
                     live[k][0].release()
                     live.pop(k)
-        n = int(rng.choice([1024, 1024, 512, 256, 1, 300, 1300, 1536]))
+        n = int(rng.choice(FRAME_CHOICES))
         wants.append(ref.sample_n(INTERVAL, n))
         sizes.append(n)
         scene.sample_device(INTERVAL, dev_out[cb].data_ptr(), n)
